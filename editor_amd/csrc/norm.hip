@@ -1,0 +1,621 @@
+// Memory-bound row kernels of the EDITOR hot path, gfx950.
+// All HBM-bound: one wavefront per token row, 16-byte vector accesses, fp32 statistics.
+//   LayerNorm fwd/bwd         nn.LayerNorm in Block / BlockMask (vit_pytorch.py:206,211,215-220,268-297)
+//   exact-erf GELU fwd/bwd    nn.GELU() in Mlp / MlpMasked     (vit_pytorch.py:130,141,149,163)
+//   im2col for the 16x16 patch conv + token assembly (cls / pos / SIE)   (vit_pytorch.py:449-458,625-637)
+//   SFTS mask apply + background-consistency loss fwd/bwd               (SFTS.py:208-225)
+//   masked-mean pooling fwd/bwd                                          (make_model.py:186-203)
+//   column sums (bias grads), partial-row reductions, dtype casts
+#include "common.h"
+#include "../../include/editor_hip.h"
+
+namespace {
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ float4 ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ void st(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+};
+template <> struct Vec4<bf16_t> {
+    static __device__ __forceinline__ float4 ld(const bf16_t* p) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, float4 v) {
+        uint2 u; u.x = pack_bf16x2(v.x, v.y); u.y = pack_bf16x2(v.z, v.w);
+        *reinterpret_cast<uint2*>(p) = u;
+    }
+};
+
+constexpr int kMaxV = 4;   // float4 chunks per lane: D <= 64*4*4 = 1024
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward: y = (x-mean)*rstd*gamma+beta, optionally * rowmask (AttentionMask / MlpMasked zero
+// the LN output of unselected tokens, vit_pytorch.py:245,162).  One wave per row.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, long M, int D, const uint8_t* __restrict__ rowmask, int mask_period,
+    T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 8;                       // D / (64*4)
+    const float* xr = x + row * D;
+    float4 v[kMaxV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+        v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    const float keep = (rowmask && !rowmask[mask_period ? row % mask_period : row]) ? 0.f : 1.f;
+    T* yr = y + row * D;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+        const int c0 = (i * 64 + lane) * 4;
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c0);
+        const float4 bt = *reinterpret_cast<const float4*>(beta + c0);
+        float4 o;
+        o.x = ((v[i].x - mean) * rstd * g.x + bt.x) * keep;
+        o.y = ((v[i].y - mean) * rstd * g.y + bt.y) * keep;
+        o.z = ((v[i].z - mean) * rstd * g.z + bt.z) * keep;
+        o.w = ((v[i].w - mean) * rstd * g.w + bt.w) * keep;
+        Vec4<T>::st(yr + c0, o);
+    }
+    if (lane == 0) { if (mean_out) mean_out[row] = mean; if (rstd_out) rstd_out[row] = rstd; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward.  dx_out = dx_in (optional residual-branch gradient) + d/dx LN;  per-block partial
+// dgamma/dbeta rows go to `partials` [gridDim.x][2][D] and are folded by reduce_rows_kernel (deterministic).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
+    const float* __restrict__ gamma, const float* __restrict__ mean_in, const float* __restrict__ rstd_in, long M, int D,
+    const uint8_t* __restrict__ rowmask, int mask_period, const float* __restrict__ dx_in, float* __restrict__ dx_out,
+    float* __restrict__ partials)
+{
+    __shared__ float red[4][2][1024];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nv = D >> 8;
+    float4 g[kMaxV], dg[kMaxV], db[kMaxV];
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) {
+        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i];
+        if (i < nv) g[i] = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
+    }
+    for (long row = (long)blockIdx.x * 4 + w; row < M; row += (long)gridDim.x * 4) {
+        const bool keep = !(rowmask && !rowmask[mask_period ? row % mask_period : row]);
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float4 xh[kMaxV], d[kMaxV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+            const int c0 = (i * 64 + lane) * 4;
+            const float4 xv = *reinterpret_cast<const float4*>(x + row * D + c0);
+            d[i] = keep ? Vec4<T>::ld(dy + row * D + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            dg[i].x += d[i].x * xh[i].x; dg[i].y += d[i].y * xh[i].y; dg[i].z += d[i].z * xh[i].z; dg[i].w += d[i].w * xh[i].w;
+            db[i].x += d[i].x; db[i].y += d[i].y; db[i].z += d[i].z; db[i].w += d[i].w;
+            d[i].x *= g[i].x; d[i].y *= g[i].y; d[i].z *= g[i].z; d[i].w *= g[i].w;
+            s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+            s2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+            const int c0 = (i * 64 + lane) * 4;
+            float4 o;
+            o.x = rstd * (d[i].x - s1 - xh[i].x * s2);
+            o.y = rstd * (d[i].y - s1 - xh[i].y * s2);
+            o.z = rstd * (d[i].z - s1 - xh[i].z * s2);
+            o.w = rstd * (d[i].w - s1 - xh[i].w * s2);
+            if (dx_in) {
+                const float4 r = *reinterpret_cast<const float4*>(dx_in + row * D + c0);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            *reinterpret_cast<float4*>(dx_out + row * D + c0) = o;
+        }
+    }
+    if (!partials) return;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+        const int c0 = (i * 64 + lane) * 4;
+        *reinterpret_cast<float4*>(&red[w][0][c0]) = dg[i];
+        *reinterpret_cast<float4*>(&red[w][1][c0]) = db[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+        const int which = c / D, col = c % D;
+        partials[((long)blockIdx.x * 2 + which) * D + col] =
+            (red[0][which][col] + red[1][which][col]) + (red[2][which][col] + red[3][which][col]);
+    }
+}
+
+// out[c] (+)= sum_p partials[p][c]
+__global__ void reduce_rows_kernel(const float* __restrict__ partials, int P, long ncol, float* __restrict__ out,
+                                   int accumulate, float scale)
+{
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    float s0 = 0.f, s1 = 0.f;
+    int p = 0;
+    for (; p + 1 < P; p += 2) { s0 += partials[(long)p * ncol + c]; s1 += partials[(long)(p + 1) * ncol + c]; }
+    if (p < P) s0 += partials[(long)p * ncol + c];
+    const float s = (s0 + s1) * scale;
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// column sums of a (M,N) activation-gradient matrix -> partials [gridDim.y][N]  (bias gradients)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, long M, int N, long ld,
+                                                     float* __restrict__ partials)
+{
+    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c0 >= N) return;
+    const long rows_per = (M + gridDim.y - 1) / gridDim.y;
+    const long r0 = (long)blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    long r = r0;
+    for (; r + 1 < r1; r += 2) {
+        const float4 u = Vec4<T>::ld(dy + r * ld + c0), v = Vec4<T>::ld(dy + (r + 1) * ld + c0);
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    if (r < r1) { const float4 u = Vec4<T>::ld(dy + r * ld + c0); a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+    *reinterpret_cast<float4*>(partials + (long)blockIdx.y * N + c0) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GELU (exact erf) forward / backward, elementwise on 4-element vectors
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float a) { return 0.5f * a * (1.f + erff(a * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float a) {
+    return 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.3989422804014327f * __expf(-0.5f * a * a);
+}
+template <typename T>
+__global__ void gelu_fwd_kernel(const T* __restrict__ a, T* __restrict__ g, long n4)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = Vec4<T>::ld(a + i * 4);
+        v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+        Vec4<T>::st(g + i * 4, v);
+    }
+}
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ a, const T* __restrict__ dg, T* __restrict__ da, long n4)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = Vec4<T>::ld(a + i * 4), d = Vec4<T>::ld(dg + i * 4);
+        Vec4<T>::st(da + i * 4, make_float4(d.x * gelu_grad_f(v.x), d.y * gelu_grad_f(v.y),
+                                           d.z * gelu_grad_f(v.z), d.w * gelu_grad_f(v.w)));
+    }
+}
+
+// dtype casts (fp32 master weights -> bf16 MFMA operands, fp32 grads -> bf16 GEMM operands)
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long n4)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        Vec4<TO>::st(out + i * 4, Vec4<TI>::ld(in + i * 4));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Patch embedding glue.  im2col of non-overlapping 16x16 patches: row (b*N+p), col (c*256 + i*16 + j)
+// == Conv2d(k=16,s=16) weight layout (768,3,16,16) flattened (vit_pytorch.py:438,455-457).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void im2col16_kernel(const float* __restrict__ img, int B, int C, int H, int W, T* __restrict__ out)
+{
+    const int px = W >> 4, py = H >> 4;
+    const long total4 = (long)B * py * px * C * 64;                 // float4 groups
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (long)gridDim.x * blockDim.x) {
+        const int j4 = (int)(e & 3);
+        long r = e >> 2;
+        const int i = (int)(r & 15); r >>= 4;
+        const int c = (int)(r % C); r /= C;
+        const int p = (int)(r % (py * px));
+        const int b = (int)(r / (py * px));
+        const int y = (p / px) * 16 + i, x0 = (p % px) * 16 + j4 * 4;
+        const float4 v = *reinterpret_cast<const float4*>(img + (((long)b * C + c) * H + y) * W + x0);
+        Vec4<T>::st(out + ((long)b * py * px + p) * (C * 256) + c * 256 + i * 16 + j4 * 4, v);
+    }
+}
+
+// x[b,0,:] = cls + pos[0] + coef*sie[cam[b]] ; x[b,1+p,:] = patch[b*N+p,:] + pos[1+p] + coef*sie[cam[b]]
+// (vit_pytorch.py:627-637).  patch already contains the conv bias.  nmod: the batch holds nmod modality
+// copies stacked along the sample axis that share cam labels (cam index = b % Bcam).
+template <typename T>
+__global__ void embed_assemble_kernel(const T* __restrict__ patch, const float* __restrict__ cls,
+    const float* __restrict__ pos, const float* __restrict__ sie, const long* __restrict__ cam, int Bcam, float coef,
+    long Btot, int Tn, int D, float* __restrict__ x)
+{
+    const int d4 = D >> 2;
+    const long total = Btot * Tn * d4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(e % d4) * 4;
+        const long rt = e / d4;
+        const int tk = (int)(rt % Tn);
+        const long b = rt / Tn;
+        float4 v = tk == 0 ? *reinterpret_cast<const float4*>(cls + c0)
+                           : Vec4<T>::ld(patch + (b * (Tn - 1) + tk - 1) * D + c0);
+        const float4 p = *reinterpret_cast<const float4*>(pos + (long)tk * D + c0);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        if (sie) {
+            const float4 s = *reinterpret_cast<const float4*>(sie + cam[b % Bcam] * D + c0);
+            v.x += coef * s.x; v.y += coef * s.y; v.z += coef * s.z; v.w += coef * s.w;
+        }
+        *reinterpret_cast<float4*>(x + rt * D + c0) = v;
+    }
+}
+
+// backward of the assembly: dpatch = dx[:,1:,:] (cast), dpos[t] = sum_b dx[b,t], rowsum[b] = sum_t dx[b,t]
+template <typename T>
+__global__ void embed_bwd_patch_kernel(const float* __restrict__ dx, long Btot, int Tn, int D, T* __restrict__ dpatch)
+{
+    const int d4 = D >> 2;
+    const long total = Btot * (Tn - 1) * d4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(e % d4) * 4;
+        const long rp = e / d4;
+        const long b = rp / (Tn - 1);
+        const int p = (int)(rp % (Tn - 1));
+        Vec4<T>::st(dpatch + rp * D + c0, *reinterpret_cast<const float4*>(dx + (b * Tn + p + 1) * D + c0));
+    }
+}
+// dpos[t,:] = sum_b dx[b,t,:]   grid (Tn, ceil(D/1024)), 256 thr x float4
+__global__ void embed_bwd_pos_kernel(const float* __restrict__ dx, long Btot, int Tn, int D, float* __restrict__ dpos)
+{
+    const int tk = blockIdx.x, c0 = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (c0 >= D) return;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long b = 0; b < Btot; ++b) {
+        const float4 v = *reinterpret_cast<const float4*>(dx + (b * Tn + tk) * D + c0);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dpos + (long)tk * D + c0) = a;
+}
+// dsie[c,:] = coef * sum_{b: cam[b%Bcam]==c} sum_t dx[b,t,:]    grid (ncam, ceil(D/1024))
+__global__ void embed_bwd_sie_kernel(const float* __restrict__ dx, const long* __restrict__ cam, int Bcam, long Btot,
+                                     int Tn, int D, float coef, float* __restrict__ dsie)
+{
+    const int c = blockIdx.x, c0 = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (c0 >= D) return;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long b = 0; b < Btot; ++b) {
+        if (cam[b % Bcam] != c) continue;
+        for (int tk = 0; tk < Tn; ++tk) {
+            const float4 v = *reinterpret_cast<const float4*>(dx + (b * Tn + tk) * D + c0);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    *reinterpret_cast<float4*>(dsie + (long)c * D + c0) = make_float4(coef * a.x, coef * a.y, coef * a.z, coef * a.w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10  SFTS mask apply + BCC loss (SFTS.py:208-225).  feat: (nmod, B, T, D) fp32 (final-LN tokens of each
+// modality), index (B, T-1) uint8.  out = feat with unselected patch rows zeroed; loss partial sums of
+// sum_{pairs} (bg_a - bg_b)^2 over unselected rows -> partials[gridDim.x].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sfts_apply_kernel(const float* __restrict__ feat, const uint8_t* __restrict__ index,
+    int nmod, long B, int Tn, int D, float* __restrict__ out, float* __restrict__ partials)
+{
+    __shared__ float red[16];
+    const int d4 = D >> 2;
+    const long total = B * Tn * d4;
+    const long mstride = B * Tn * (long)D;
+    float acc = 0.f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(e % d4) * 4;
+        const long rt = e / d4;
+        const int tk = (int)(rt % Tn);
+        const long b = rt / Tn;
+        const bool sel = tk == 0 || index[b * (Tn - 1) + tk - 1];
+        float4 v[3];
+        for (int m = 0; m < nmod; ++m) {
+            v[m] = *reinterpret_cast<const float4*>(feat + m * mstride + rt * D + c0);
+            *reinterpret_cast<float4*>(out + m * mstride + rt * D + c0) = sel ? v[m] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (!sel && partials) {
+            for (int i = 0; i < nmod; ++i) for (int j = i + 1; j < nmod; ++j) {
+                const float a = v[i].x - v[j].x, b2 = v[i].y - v[j].y, c = v[i].z - v[j].z, d = v[i].w - v[j].w;
+                acc += (a * a + b2 * b2) + (c * c + d * d);
+            }
+        }
+    }
+    if (partials) {
+        acc = block_sum(acc, red);
+        if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+    }
+}
+// backward: dfeat_m = dout_m on selected rows; on unselected patch rows dfeat_m = gscale * sum_{j!=m} (f_m - f_j)
+// with gscale = dloss * 2 / (B*(T-1)*D)
+__global__ __launch_bounds__(256) void sfts_apply_bwd_kernel(const float* __restrict__ feat, const uint8_t* __restrict__ index,
+    const float* __restrict__ dout, const float* __restrict__ dloss, float gnorm, int nmod, long B, int Tn, int D,
+    float* __restrict__ dfeat)
+{
+    const int d4 = D >> 2;
+    const long total = B * Tn * d4;
+    const long mstride = B * Tn * (long)D;
+    const float gs = dloss ? dloss[0] * gnorm : 0.f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(e % d4) * 4;
+        const long rt = e / d4;
+        const int tk = (int)(rt % Tn);
+        const long b = rt / Tn;
+        const bool sel = tk == 0 || index[b * (Tn - 1) + tk - 1];
+        if (sel) {
+            for (int m = 0; m < nmod; ++m)
+                *reinterpret_cast<float4*>(dfeat + m * mstride + rt * D + c0) =
+                    *reinterpret_cast<const float4*>(dout + m * mstride + rt * D + c0);
+        } else {
+            float4 v[3], s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int m = 0; m < nmod; ++m) {
+                v[m] = *reinterpret_cast<const float4*>(feat + m * mstride + rt * D + c0);
+                s.x += v[m].x; s.y += v[m].y; s.z += v[m].z; s.w += v[m].w;
+            }
+            const float n = (float)nmod;
+            for (int m = 0; m < nmod; ++m)
+                *reinterpret_cast<float4*>(dfeat + m * mstride + rt * D + c0) =
+                    make_float4(gs * (n * v[m].x - s.x), gs * (n * v[m].y - s.y), gs * (n * v[m].z - s.z), gs * (n * v[m].w - s.w));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K12  pooling of the fused tokens (make_model.py:186-203): per (modality m, sample b):
+//   cls = x[b, m*T, :] ; patch = sum_{t>=1} x[b, m*T+t, :] / num[b],  num[b] = #rows of modality 0 with row-sum != 0
+// x: (B, nmod*T, D) fp32.  out: (nmod, B, 2D) = [cls, patch].  One block per sample.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ x, long B, int nmod, int Tn, int D,
+                                                       float* __restrict__ out, float* __restrict__ num_out)
+{
+    __shared__ int cnt;
+    const long b = blockIdx.x;
+    const float* xb = x + b * (long)nmod * Tn * D;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    // num: rows of modality 0 (RGB) whose sum over D is non-zero (make_model.py:197-198)
+    for (int tk = 1 + (threadIdx.x >> 6); tk < Tn; tk += 4) {
+        float s = 0.f;
+        for (int c = (threadIdx.x & 63); c < D; c += 64) s += xb[(long)tk * D + c];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0 && s != 0.f) atomicAdd(&cnt, 1);
+    }
+    __syncthreads();
+    const float num = (float)cnt;
+    if (threadIdx.x == 0) num_out[b] = num;
+    for (int m = 0; m < nmod; ++m) {
+        const float* xm = xb + (long)m * Tn * D;
+        float* o = out + ((long)m * B + b) * 2 * D;
+        for (int c = threadIdx.x; c < D; c += 256) {
+            float s = 0.f;
+            for (int tk = 1; tk < Tn; ++tk) s += xm[(long)tk * D + c];
+            o[c] = xm[c];
+            o[D + c] = s / num;
+        }
+    }
+}
+// dx[b, m*T, :] = dout[m,b,:D] ; dx[b, m*T+t, :] = dout[m,b,D:] / num[b]  (num is a count: no gradient)
+__global__ void pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ num, long B, int nmod, int Tn,
+                                int D, float* __restrict__ dx)
+{
+    const long total = B * nmod * Tn * (long)D;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % D);
+        long r = e / D;
+        const int tk = (int)(r % Tn); r /= Tn;
+        const int m = (int)(r % nmod);
+        const long b = r / nmod;
+        const float* o = dout + ((long)m * B + b) * 2 * D;
+        dx[e] = tk == 0 ? o[c] : o[D + c] / num[b];
+    }
+}
+
+// y = x * rowmask (BlockMask's final re-mask, vit_pytorch.py:331-332) in place / or backward of it
+__global__ void rowmask_mul_kernel(float* __restrict__ x, const uint8_t* __restrict__ rowmask, int period, long M, int D)
+{
+    const int d4 = D >> 2;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < M * d4; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / d4;
+        if (!rowmask[period ? row % period : row])
+            *reinterpret_cast<float4*>(x + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+inline unsigned grid_for(long n, int block = 256, long cap = 256L * 16) {
+    long g = (n + block - 1) / block;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+#define DISPATCH_T(is_bf16, CALL) do { if (is_bf16) { using TT = bf16_t; CALL; } else { using TT = float; CALL; } } while (0)
+
+extern "C" int editor_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, long M, int D,
+    const uint8_t* rowmask, int mask_period, void* y, int y_bf16, float* mean, float* rstd, hipStream_t stream)
+{
+    if (D % 256 || D > 1024 || M <= 0) return (int)hipErrorInvalidValue;
+    DISPATCH_T(y_bf16, hipLaunchKernelGGL(layernorm_fwd_kernel<TT>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream,
+               x, gamma, beta, eps, M, D, rowmask, mask_period, (TT*)y, mean, rstd));
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_layernorm_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
+    const float* rstd, long M, int D, const uint8_t* rowmask, int mask_period, const float* dx_in, float* dx_out,
+    float* dgamma, float* dbeta, float* workspace, int ws_rows, hipStream_t stream)
+{
+    if (D % 256 || D > 1024 || M <= 0 || ws_rows < 1) return (int)hipErrorInvalidValue;
+    long blocks = (M + 3) / 4;
+    if (blocks > ws_rows) blocks = ws_rows;
+    DISPATCH_T(dy_bf16, hipLaunchKernelGGL(layernorm_bwd_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, stream,
+               (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out, dgamma ? workspace : nullptr));
+    EDITOR_LAUNCH_CHECK();
+    if (dgamma) {
+        // workspace rows are [block][2][D]: treat as P rows of 2D columns, then split
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, stream, workspace, (int)blocks,
+                           (long)2 * D, workspace + (long)ws_rows * 2 * D, 0, 1.f);
+        EDITOR_LAUNCH_CHECK();
+        hipError_t e = hipMemcpyAsync(dgamma, workspace + (long)ws_rows * 2 * D, sizeof(float) * D, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return (int)e;
+        e = hipMemcpyAsync(dbeta, workspace + (long)ws_rows * 2 * D + D, sizeof(float) * D, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+extern "C" int editor_colsum(const void* dy, int dy_bf16, long M, int N, long ld, float* out, float* workspace,
+                             int ws_rows, hipStream_t stream)
+{
+    if (N % 4 || ws_rows < 1) return (int)hipErrorInvalidValue;
+    int gy = (int)((M + 255) / 256);
+    if (gy > ws_rows) gy = ws_rows;
+    if (gy < 1) gy = 1;
+    DISPATCH_T(dy_bf16, hipLaunchKernelGGL(colsum_kernel<TT>, dim3((N / 4 + 255) / 256, gy), dim3(256), 0, stream,
+               (const TT*)dy, M, N, ld, workspace));
+    EDITOR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, workspace, gy, (long)N, out, 0, 1.f);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_reduce_rows(const float* partials, int P, long ncol, float* out, int accumulate, float scale,
+                                  hipStream_t stream)
+{
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, stream, partials, P, ncol,
+                       out, accumulate, scale);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_gelu_fwd(const void* a, void* g, long n, int bf16, hipStream_t stream)
+{
+    if (n % 4) return (int)hipErrorInvalidValue;
+    DISPATCH_T(bf16, hipLaunchKernelGGL(gelu_fwd_kernel<TT>, dim3(grid_for(n / 4)), dim3(256), 0, stream, (const TT*)a, (TT*)g, n / 4));
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int editor_gelu_bwd(const void* a, const void* dg, void* da, long n, int bf16, hipStream_t stream)
+{
+    if (n % 4) return (int)hipErrorInvalidValue;
+    DISPATCH_T(bf16, hipLaunchKernelGGL(gelu_bwd_kernel<TT>, dim3(grid_for(n / 4)), dim3(256), 0, stream,
+               (const TT*)a, (const TT*)dg, (TT*)da, n / 4));
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_cast_f32_to_bf16(const float* in, uint16_t* out, long n, hipStream_t stream)
+{
+    if (n % 4) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid_for(n / 4)), dim3(256), 0, stream, in, out, n / 4);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int editor_cast_bf16_to_f32(const uint16_t* in, float* out, long n, hipStream_t stream)
+{
+    if (n % 4) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid_for(n / 4)), dim3(256), 0, stream, in, out, n / 4);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_im2col16(const float* img, int B, int C, int H, int W, void* out, int out_bf16, hipStream_t stream)
+{
+    if ((H & 15) || (W & 15)) return (int)hipErrorInvalidValue;
+    const long total4 = (long)B * (H >> 4) * (W >> 4) * C * 64;
+    DISPATCH_T(out_bf16, hipLaunchKernelGGL(im2col16_kernel<TT>, dim3(grid_for(total4)), dim3(256), 0, stream, img, B, C, H, W, (TT*)out));
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_embed_assemble(const void* patch, int patch_bf16, const float* cls, const float* pos,
+    const float* sie, const long* cam, int Bcam, float coef, long Btot, int T, int D, float* x, hipStream_t stream)
+{
+    if (D % 4) return (int)hipErrorInvalidValue;
+    const long total = Btot * T * (D / 4);
+    DISPATCH_T(patch_bf16, hipLaunchKernelGGL(embed_assemble_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, stream,
+               (const TT*)patch, cls, pos, sie, cam, Bcam, coef, Btot, T, D, x));
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_embed_assemble_bwd(const float* dx, const long* cam, int Bcam, int ncam, float coef, long Btot,
+    int T, int D, void* dpatch, int dpatch_bf16, float* dpos, float* dsie, hipStream_t stream)
+{
+    if (D % 4) return (int)hipErrorInvalidValue;
+    const long total = Btot * (T - 1) * (D / 4);
+    DISPATCH_T(dpatch_bf16, hipLaunchKernelGGL(embed_bwd_patch_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, stream,
+               dx, Btot, T, D, (TT*)dpatch));
+    EDITOR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(T, (D + 1023) / 1024), dim3(256), 0, stream, dx, Btot, T, D, dpos);
+    EDITOR_LAUNCH_CHECK();
+    if (dsie) {
+        hipLaunchKernelGGL(embed_bwd_sie_kernel, dim3(ncam, (D + 1023) / 1024), dim3(256), 0, stream, dx, cam, Bcam, Btot,
+                           T, D, coef, dsie);
+        EDITOR_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int editor_sfts_apply(const float* feat, const uint8_t* index, int nmod, long B, int T, int D, float* out,
+                                 float* loss, float* workspace, int ws_len, hipStream_t stream)
+{
+    if (D % 4 || nmod < 2 || nmod > 3) return (int)hipErrorInvalidValue;
+    const long total = B * T * (D / 4);
+    unsigned g = grid_for(total);
+    if (loss && (int)g > ws_len) g = (unsigned)ws_len;
+    hipLaunchKernelGGL(sfts_apply_kernel, dim3(g), dim3(256), 0, stream, feat, index, nmod, B, T, D, out,
+                       loss ? workspace : nullptr);
+    EDITOR_LAUNCH_CHECK();
+    if (loss) {   // MSELoss mean over B*(T-1)*D elements, summed over modality pairs (SFTS.py:221)
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, stream, workspace, (int)g, 1L, loss, 0,
+                           1.f / ((float)B * (T - 1) * D));
+        EDITOR_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int editor_sfts_apply_bwd(const float* feat, const uint8_t* index, const float* dout, const float* dloss,
+                                     int nmod, long B, int T, int D, float* dfeat, hipStream_t stream)
+{
+    if (D % 4 || nmod < 2 || nmod > 3) return (int)hipErrorInvalidValue;
+    const long total = B * T * (D / 4);
+    hipLaunchKernelGGL(sfts_apply_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, feat, index, dout, dloss,
+                       2.f / ((float)B * (T - 1) * D), nmod, B, T, D, dfeat);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_pool_fwd(const float* x, long B, int nmod, int T, int D, float* out, float* num, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)B), dim3(256), 0, stream, x, B, nmod, T, D, out, num);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int editor_pool_bwd(const float* dout, const float* num, long B, int nmod, int T, int D, float* dx,
+                               hipStream_t stream)
+{
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_for(B * nmod * T * (long)D)), dim3(256), 0, stream, dout, num, B, nmod, T, D, dx);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int editor_rowmask_mul(float* x, const uint8_t* rowmask, int period, long M, int D, hipStream_t stream)
+{
+    if (D % 4) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(rowmask_mul_kernel, dim3(grid_for(M * (D / 4))), dim3(256), 0, stream, x, rowmask, period, M, D);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}

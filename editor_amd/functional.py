@@ -1,0 +1,231 @@
+"""Autograd nodes of the EDITOR hot path.  Each Function's forward AND backward is a fixed sequence of
+HIP kernel launches through the C ABI (editor_amd.ops); torch only owns the tensors, the streams and
+the graph that hands parameter gradients to nn.Parameter.grad (so DDP hooks / optimizers are unchanged).
+
+Granularity is one node per transformer block (12 backbone blocks + 3 modality blocks + 1 joint block),
+so gradient buckets become ready block by block and the RCCL all-reduce overlaps the rest of backward.
+
+Activation dtype: torch.bfloat16 (performance mode, bf16 MFMA with fp32 accumulation) or torch.float32
+(parity mode, exact-f32 MFMA).  The residual stream, LayerNorm statistics, losses and every parameter
+gradient are fp32 in both modes.
+"""
+import torch
+
+from . import ops
+
+_BF16_CACHE = {}
+
+
+def act_weight(w, dtype):
+    """fp32 master parameter -> GEMM operand dtype (bf16 copies are cached per parameter version)."""
+    if dtype == torch.float32:
+        return w.detach()
+    key = id(w)
+    ent = _BF16_CACHE.get(key)
+    ver = w._version
+    if ent is None or ent[0] != ver or ent[1].data_ptr() == 0 or ent[2] != w.data_ptr():
+        ent = (ver, ops.cast(w.detach().contiguous().view(-1), torch.bfloat16).view(w.shape), w.data_ptr())
+        _BF16_CACHE[key] = ent
+    return ent[1]
+
+
+def _linear_fwd(x2d, w_act, bias, out_dtype):
+    """y = x W^T + b;  x (M,K) act dtype, W (N,K)."""
+    m, k = x2d.shape
+    n = w_act.shape[0]
+    y = torch.empty(m, n, dtype=out_dtype, device=x2d.device)
+    ops.gemm(x2d, w_act, y, m, n, k, k, k, n, 0, 0, bias=bias)
+    return y
+
+
+def _linear_bwd(dy, x2d, w_act, need_bias, splitk):
+    """dx = dy W ; dW = dy^T x (fp32) ; db = colsum(dy)."""
+    m, n = dy.shape
+    k = x2d.shape[1]
+    dx = torch.empty(m, k, dtype=x2d.dtype, device=dy.device)
+    ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1)                       # B stored (Kred=n, Nout=k)
+    dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
+    ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, splitk=splitk)          # both stored (Kred=m, .)
+    db = ops.colsum(dy) if need_bias else None
+    return dx, dw, db
+
+
+def _splitk_for(m):
+    return max(1, min(64, m // 2048))
+
+
+class TransformerBlockFn(torch.autograd.Function):
+    """Block.forward(get_att=True) (vit_pytorch.py:215-220) and the masked blocks of BlockMask.forward
+    (vit_pytorch.py:311-317,327-328 with AttentionMask :240-258 / MlpMasked :158-168).
+
+    x (B,T,D) fp32.  mask (B,T) uint8 or None.  probs_out: (B,heads,T,T) fp32 buffer that receives the
+    softmax output (non-differentiable, feeds the rollout) or None.  rowscale: (B*T) fp32 per-row
+    drop-path scale keep/keep_prob (vit_pytorch.py:52-69) or None; two independent draws (attn, mlp).
+    """
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, mask, probs_out,
+                heads, eps, act_dtype, rowscale_attn, rowscale_mlp):
+        b, t, d = x.shape
+        m = b * t
+        hd = d // heads
+        x2d = x.reshape(m, d)
+        wq, wp, w1, w2 = (act_weight(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w))
+        h1, mean1, rstd1 = ops.layernorm_fwd(x2d, n1w, n1b, eps, act_dtype, mask, 0)
+        qkv = _linear_fwd(h1, wq, qkvb, act_dtype)
+        ao, probs = ops.attention_fwd(qkv, b, t, heads, hd, mask, probs_out)
+        x1 = x2d.clone()
+        ops.gemm(ao, wp, x1, m, d, d, d, d, d, 0, 0, beta=1.0, bias=projb, rowscale=rowscale_attn)
+        h2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, eps, act_dtype, mask, 0)
+        a = _linear_fwd(h2, w1, fc1b, act_dtype)
+        g = ops.gelu_fwd(a)
+        x2 = x1.clone()
+        hidden = w2.shape[1]
+        ops.gemm(g, w2, x2, m, d, hidden, hidden, hidden, d, 0, 0, beta=1.0, bias=fc2b, rowscale=rowscale_mlp)
+        keep_probs = probs if act_dtype == torch.float32 else None
+        ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
+                              qkvw, projw, fc1w, fc2w, mask, keep_probs, rowscale_attn, rowscale_mlp)
+        ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None)
+        return x2.view(b, t, d)
+
+    @staticmethod
+    def backward(ctx, dx2):
+        (x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w, qkvw, projw, fc1w, fc2w, mask,
+         probs, rs_attn, rs_mlp) = ctx.saved_tensors
+        b, t, d, heads, act_dtype, hb_qkv, hb_proj, hb_fc1, hb_fc2 = ctx.meta
+        m = b * t
+        hd = d // heads
+        sk = _splitk_for(m)
+        wq, wp, w1, w2 = (act_weight(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w))
+        dx2 = dx2.contiguous().view(m, d)
+        # ---- MLP branch:  x2 = x1 + rs * fc2(gelu(fc1(LN2(x1))))
+        dy = _scaled_cast(dx2, rs_mlp, act_dtype)
+        dg, dw2, db2 = _linear_bwd(dy, g, w2, hb_fc2, sk)
+        da = ops.gelu_bwd(a, dg)
+        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, sk)
+        dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w, mean2, rstd2, mask, 0, dx_in=dx2)
+        # ---- attention branch:  x1 = x + rs * proj(attn(qkv(LN1(x))))
+        dy = _scaled_cast(dx1, rs_attn, act_dtype)
+        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, sk)
+        dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, mask, probs, ao)
+        dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, sk)
+        dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1)
+        return (dx.view(b, t, d), dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2,
+                None, None, None, None, None, None, None)
+
+
+def _scaled_cast(dx, rowscale, dtype):
+    if rowscale is not None:
+        dx = dx * rowscale.view(-1, 1)        # rare path (DROP_PATH > 0): plain elementwise scale
+    return ops.cast(dx, dtype)
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """PatchEmbed_overlap (vit_pytorch.py:449-458) + cls/pos/SIE assembly (:625-637) for stride 16.
+    img (Btot,3,H,W) fp32 (modalities stacked on the batch axis), cam (Bcam) int64."""
+
+    @staticmethod
+    def forward(ctx, img, conv_w, conv_b, cls, pos, sie, cam, coef, act_dtype):
+        btot = img.shape[0]
+        d = conv_w.shape[0]
+        kdim = conv_w[0].numel()
+        cols = ops.im2col16(img, act_dtype)
+        w = act_weight(conv_w, act_dtype).view(d, kdim)
+        patch = _linear_fwd(cols, w, conv_b, act_dtype)
+        t = pos.shape[1]
+        x = ops.embed_assemble(patch, cls.view(-1), pos.view(t, d), None if sie is None else sie.view(-1, d),
+                               cam, coef, btot, t, d)
+        ctx.save_for_backward(cols, conv_w, cam)
+        ctx.meta = (coef, act_dtype, None if sie is None else sie.shape[0], cls.shape, pos.shape,
+                    None if sie is None else sie.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        cols, conv_w, cam = ctx.saved_tensors
+        coef, act_dtype, ncam, cls_shape, pos_shape, sie_shape = ctx.meta
+        dx = dx.contiguous()
+        dpatch, dpos, dsie = ops.embed_assemble_bwd(dx, cam, ncam or 0, coef, act_dtype)
+        d = conv_w.shape[0]
+        kdim = cols.shape[1]
+        mrows = cols.shape[0]
+        dw = torch.empty(d, kdim, dtype=torch.float32, device=dx.device)
+        ops.gemm(dpatch, cols, dw, d, kdim, mrows, d, kdim, kdim, 1, 1, splitk=_splitk_for(mrows))
+        db = ops.colsum(dpatch)
+        dcls = dpos[0].clone().view(cls_shape)
+        return (None, dw.view(conv_w.shape), db, dcls, dpos.view(pos_shape),
+                None if dsie is None else dsie.view(sie_shape), None, None, None)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm with fp32 output, optionally followed by the row re-mask of BlockMask
+    (out_norm + `x * mask3`, vit_pytorch.py:329-332) or the backbone's final norm (:643)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, mask):
+        shape = x.shape
+        x2d = x.reshape(-1, shape[-1])
+        y, mean, rstd = ops.layernorm_fwd(x2d, w, b, eps, torch.float32, mask, 0)
+        ctx.save_for_backward(x2d, w, mean, rstd, mask)
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, w, mean, rstd, mask = ctx.saved_tensors
+        dx, dw, db = ops.layernorm_bwd(dy.contiguous().view(x2d.shape), x2d, w, mean, rstd, mask, 0)
+        return dx.view(dy.shape), dw, db, None, None
+
+
+class SFTSApplyFn(torch.autograd.Function):
+    """SFTS.forward's differentiable half (SFTS.py:208-225): zero the unselected patch tokens of every
+    modality and (training) the background-consistency loss over the unselected ones."""
+
+    @staticmethod
+    def forward(ctx, feat, index, training):
+        out, loss = ops.sfts_apply(feat, index, training)
+        ctx.save_for_backward(feat, index)
+        ctx.training = training
+        if training:
+            return out, loss.view(())
+        return out, feat.new_zeros(())
+
+    @staticmethod
+    def backward(ctx, dout, dloss):
+        feat, index = ctx.saved_tensors
+        dl = dloss.contiguous().view(1).float() if ctx.training else None
+        return ops.sfts_apply_bwd(feat, index, dout.contiguous(), dl), None, None
+
+
+class PoolFn(torch.autograd.Function):
+    """cls + masked-mean pooling per modality of the fused tokens (make_model.py:186-203)."""
+
+    @staticmethod
+    def forward(ctx, x, nmod, t):
+        out, num = ops.pool_fwd(x.contiguous(), nmod, t)
+        ctx.save_for_backward(num)
+        ctx.meta = (nmod, t)
+        ctx.mark_non_differentiable(num)
+        return out, num
+
+    @staticmethod
+    def backward(ctx, dout, _dnum):
+        (num,) = ctx.saved_tensors
+        nmod, t = ctx.meta
+        return ops.pool_bwd(dout.contiguous(), num, nmod, t), None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """Small fp32 nn.Linear (REDUCE layers, classifier heads; make_model.py:162-171,205-209)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        y = _linear_fwd(x.contiguous(), w.detach(), b, torch.float32)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dw, db = _linear_bwd(dy.contiguous(), x.contiguous(), w.detach(), ctx.has_bias, 1)
+        return dx, dw, db

@@ -1,0 +1,407 @@
+"""Drop-in counterpart of the reference's `modeling.make_model` for the MI355X-native hot path.
+
+Same factory, same forward signature and return tuples, same 216(+6 with AL) state-dict keys as
+/root/reference/modeling/make_model.py:86-258,371-374 - so engine/processor.py, tools/train.py, the
+optimizer's name-based parameter groups (solver/make_optimizer.py:6-19) and checkpoints work unchanged.
+The nn.Module tree only CONTAINS parameters; every forward/backward computation is a HIP kernel launched
+through libeditor_hip.so (editor_amd.functional).  There is no PyTorch/CPU fallback: calling forward on a
+CPU tensor raises.
+
+MI355X-first differences in HOW (not WHAT) it computes:
+  * the shared backbone runs ONCE on the three modalities stacked on the batch axis (3B samples), so every
+    GEMM sees M = 3*B*T rows and the shared weights stream from HBM once;
+  * attention probabilities are written once per layer into one (L,3B,h,T,T) buffer and consumed by a
+    row-vector rollout kernel (no 129x129 matmul chain);
+  * top-k tie order of torch's CPU kernel is reproduced on device (libstdc++ heap/introselect).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as fn
+from .. import ops
+
+_ARCH = {
+    # name: (embed_dim, depth, heads, mlp_ratio, qkv_bias)   vit_pytorch.py:693-727
+    "vit_base_patch16_224": (768, 12, 12, 4.0, True),
+    "deit_base_patch16_224": (768, 12, 12, 4.0, True),
+    "deit_small_patch16_224": (384, 12, 6, 4.0, True),
+    "vit_small_patch16_224": (768, 8, 8, 3.0, False),
+    # extension (BASELINE.json config 5): not in the reference's factory (make_model.py:363-368)
+    "vit_large_patch16_224": (1024, 24, 16, 4.0, True),
+}
+
+
+def _trunc_normal_(t, std=0.02):
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+def _act_dtype(cfg):
+    name = getattr(cfg.MODEL, "COMPUTE_DTYPE", "bf16")
+    return torch.float32 if name in ("f32", "fp32", "float32") else torch.bfloat16
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers (names == reference state-dict keys)
+# ------------------------------------------------------------------------------------------------
+class _Attn(nn.Module):
+    def __init__(self, dim, bias):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=bias)
+        self.proj = nn.Linear(dim, dim, bias=bias)
+
+
+class _BackboneAttn(nn.Module):
+    def __init__(self, dim, qkv_bias):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)                      # vit_pytorch.py:181: proj always has a bias
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden, bias=True):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden, bias=bias)
+        self.fc2 = nn.Linear(hidden, dim, bias=bias)
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, hidden, qkv_bias, eps):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = _BackboneAttn(dim, qkv_bias)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = _Mlp(dim, hidden)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, embed_dim, kernel_size=16, stride=16)
+
+
+def _init_linear_ln(mod):
+    for m in mod.modules():
+        if isinstance(m, nn.Linear):
+            _trunc_normal_(m.weight, 0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+
+class Trans(nn.Module):
+    """Parameter layout of the reference's ViT `Trans` (vit_pytorch.py:461-534)."""
+
+    def __init__(self, img_size, embed_dim, depth, heads, mlp_ratio, qkv_bias, camera, sie_xishu, drop_path_rate):
+        super().__init__()
+        self.embed_dim, self.depth, self.heads = embed_dim, depth, heads
+        self.num_y, self.num_x = img_size[0] // 16, img_size[1] // 16
+        self.num_patches = self.num_y * self.num_x
+        self.img_size = tuple(img_size)
+        self.patch_embed = _PatchEmbed(embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches + 1, embed_dim))
+        self.cam_num = camera
+        self.sie_xishu = sie_xishu
+        if camera > 1:
+            self.sie_embed = nn.Parameter(torch.zeros(camera, 1, embed_dim))
+            _trunc_normal_(self.sie_embed, 0.02)
+        self.drop_rates = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]   # vit_pytorch.py:511
+        self.blocks = nn.ModuleList([_Block(embed_dim, int(embed_dim * mlp_ratio), qkv_bias, 1e-6)
+                                     for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.fc = nn.Linear(embed_dim, 1000)                 # unused in forward, kept for key compatibility
+        _trunc_normal_(self.cls_token, 0.02)
+        _trunc_normal_(self.pos_embed, 0.02)
+        _init_linear_ln(self)
+        w = self.patch_embed.proj.weight                     # vit_pytorch.py:439-442
+        w.data.normal_(0, math.sqrt(2.0 / (w.shape[2] * w.shape[3] * w.shape[0])))
+
+    def load_param(self, model_path):
+        """ImageNet checkpoint loading (vit_pytorch.py:646-671): skip head/dist, resize pos_embed."""
+        param_dict = torch.load(model_path, map_location="cpu")
+        for key in ("model", "state_dict"):
+            if key in param_dict:
+                param_dict = param_dict[key]
+        sd = self.state_dict()
+        for k, v in param_dict.items():
+            if "head" in k or "dist" in k:
+                continue
+            if "patch_embed.proj.weight" in k and v.dim() < 4:
+                v = v.reshape(self.patch_embed.proj.weight.shape[0], -1, 16, 16)
+            elif k == "pos_embed" and v.shape != self.pos_embed.shape:
+                if "distilled" in model_path:
+                    v = torch.cat([v[:, 0:1], v[:, 2:]], dim=1)
+                v = resize_pos_embed(v, self.num_y, self.num_x)
+            try:
+                sd[k].copy_(v)
+            except Exception:                                # the reference prints and continues (:665-671)
+                print("shape do not match in k :{}".format(k))
+
+
+def resize_pos_embed(posemb, height, width):
+    """vit_pytorch.py:674-690: bilinear resize of the grid part of a (1, 1+g*g, D) position table."""
+    tok, grid = posemb[:, :1], posemb[0, 1:]
+    gs = int(math.sqrt(len(grid)))
+    grid = grid.reshape(1, gs, gs, -1).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, size=(height, width), mode="bilinear")
+    grid = grid.permute(0, 2, 3, 1).reshape(1, height * width, -1)
+    return torch.cat([tok, grid], dim=1)
+
+
+class build_transformer(nn.Module):
+    """make_model.py:35-82 (holds `.base`)."""
+
+    def __init__(self, num_classes, cfg, camera_num):
+        super().__init__()
+        ttype = cfg.MODEL.TRANSFORMER_TYPE
+        dim, depth, heads, mlp_ratio, qkv_bias = _ARCH[ttype]
+        self.token_dim = dim
+        cams = camera_num if cfg.MODEL.SIE_CAMERA else 0
+        self.base = Trans(cfg.INPUT.SIZE_TRAIN, dim, depth, heads, mlp_ratio, qkv_bias, cams, cfg.MODEL.SIE_COE,
+                          cfg.MODEL.DROP_PATH)
+        if cfg.MODEL.PRETRAIN_CHOICE == "imagenet":
+            self.base.load_param(cfg.MODEL.PRETRAIN_PATH_T)
+
+
+class _Wavelet(nn.Module):
+    def __init__(self, names):
+        super().__init__()
+        s = 1.0 / math.sqrt(2.0)
+        taps = {"h0": [s, s], "h1": [s, -s], "g0": [s, s], "g1": [s, -s]}   # reversed dec_* / rec_* (lowlevel.py:970-974,916-920)
+        for n in names:
+            shape = (1, 1, 2, 1) if n.endswith("col") else (1, 1, 1, 2)
+            self.register_buffer(n, torch.tensor(taps[n[:2]], dtype=torch.float32).reshape(shape))
+
+
+class FrequencyIndex(nn.Module):
+    """Buffer layout of Frequency_based_Token_Selection (Frequency.py:10-18); compute is in HIP."""
+
+    def __init__(self, keep, stride=16):
+        super().__init__()
+        self.DWT = _Wavelet(["h0_col", "h1_col", "h0_row", "h1_row"])
+        self.IDWT = _Wavelet(["g0_col", "g1_col", "g0_row", "g1_row"])
+        self.keep = int(keep)
+        self.stride = stride
+        if stride != 16:
+            raise NotImplementedError("the HIP frequency kernel tiles 16x16 windows (STRIDE_SIZE 16)")
+
+    def forward(self, x, y, z=None, **_):
+        mask, _ = ops.frequency_mask(x, y, z, self.keep)
+        return mask.bool()
+
+
+class OCFRCenters(nn.Module):
+    def __init__(self, dim, num_class):
+        super().__init__()
+        for n in ("RGB", "NIR", "TIR"):
+            setattr(self, n + "_centers", nn.Parameter(torch.zeros(num_class, dim), requires_grad=False))
+
+
+class BlockMask(nn.Module):
+    """Parameter layout of the HMA head (vit_pytorch.py:261-307)."""
+
+    def __init__(self, dim, num_class, mlp_ratio=4.0, momentum=0.8):
+        super().__init__()
+        hidden = int(dim * mlp_ratio)
+        for tag in ("R", "N", "T"):
+            setattr(self, "norm" + tag, nn.LayerNorm(dim))
+            setattr(self, "attn" + tag, _Attn(dim, False))
+            setattr(self, "norm" + tag + "_", nn.LayerNorm(dim))
+            setattr(self, "mlp" + tag, _Mlp(dim, hidden, False))
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = _Attn(dim, False)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = _Mlp(dim, hidden, False)
+        self.out_norm = nn.LayerNorm(dim)
+        self.memory_cls = OCFRCenters(dim, num_class)
+        self.momentum = momentum
+        _init_linear_ln(self)
+
+
+def _block_args(norm1, attn, norm2, mlp):
+    return (norm1.weight, norm1.bias, attn.qkv.weight, attn.qkv.bias, attn.proj.weight, attn.proj.bias,
+            norm2.weight, norm2.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias)
+
+
+# ------------------------------------------------------------------------------------------------
+# EDITOR
+# ------------------------------------------------------------------------------------------------
+class EDITOR(nn.Module):
+    def __init__(self, num_classes, cfg, camera_num):
+        super().__init__()
+        self.BACKBONE = build_transformer(num_classes, cfg, camera_num)
+        dim = self.BACKBONE.token_dim
+        self.num_patches = (cfg.INPUT.SIZE_TRAIN[0] // cfg.MODEL.STRIDE_SIZE[0]) * \
+                           (cfg.INPUT.SIZE_TRAIN[1] // cfg.MODEL.STRIDE_SIZE[1])
+        self.ratio = (1 / self.num_patches) * int(cfg.MODEL.HEAD_KEEP)           # make_model.py:92
+        self.head_k = int(self.num_patches * self.ratio)                        # SFTS.py:155
+        self.FREQ_INDEX = FrequencyIndex(cfg.MODEL.FREQUENCY_KEEP, cfg.MODEL.STRIDE_SIZE[0])
+        self.hma_heads = getattr(cfg.MODEL, "HMA_HEADS", 12 if dim % 12 == 0 else 16)    # make_model.py:97
+        self.FUSE_block = BlockMask(dim, num_classes, 4.0, 0.8)
+        for tag in ("RGB", "NIR", "TIR"):
+            lin = nn.Linear(2 * dim, dim)
+            nn.init.kaiming_normal_(lin.weight, a=0, mode="fan_out")            # make_model.py:10-14
+            nn.init.constant_(lin.bias, 0.0)
+            setattr(self, tag + "_REDUCE", lin)
+        self.FUSE_HEAD = nn.Linear(3 * dim, num_classes, bias=False)
+        self.FUSE_BN = nn.BatchNorm1d(3 * dim)
+        nn.init.normal_(self.FUSE_HEAD.weight, std=0.001)                       # make_model.py:26-31
+        self.BACKBONE_HEAD = nn.Linear(dim, num_classes, bias=False)
+        self.BACKBONE_BN = nn.BatchNorm1d(dim)
+        nn.init.normal_(self.BACKBONE_HEAD.weight, std=0.001)
+        self.AL = cfg.MODEL.AL
+        if self.AL:
+            self.AL_HEAD = nn.Linear(3 * dim, num_classes, bias=False)
+            self.AL_BN = nn.BatchNorm1d(3 * dim)
+            nn.init.normal_(self.AL_HEAD.weight, std=0.001)
+        self.act_dtype = _act_dtype(cfg)
+        self.teacher_index = None            # optional (B,N) bool: force the SFTS selection (bf16 protocol)
+        self.last_aux = {}
+
+    # -- checkpoint compatibility (make_model.py:144-148) ---------------------------------------
+    def load_param(self, trained_path):
+        param_dict = torch.load(trained_path, map_location="cpu")
+        sd = self.state_dict()
+        for k in param_dict:
+            sd[k.replace("module.", "")].copy_(param_dict[k])
+        print("Loading pretrained model from {}".format(trained_path))
+
+    # -- stages ------------------------------------------------------------------------------------
+    def _backbone(self, imgs, cam):
+        """Trans.forward (vit_pytorch.py:623-644) on the stacked (3B,3,H,W) batch.  Returns final-LN
+        tokens (3B,T,D) fp32 and the (L,3B,h,T,T) softmax buffer."""
+        base = self.BACKBONE.base
+        if tuple(imgs.shape[-2:]) != base.img_size:
+            raise AssertionError(f"Input image size ({imgs.shape[-2]}*{imgs.shape[-1]}) doesn't match model "
+                                 f"({base.img_size[0]}*{base.img_size[1]}).")
+        btot = imgs.shape[0]
+        t = base.num_patches + 1
+        sie = base.sie_embed if base.cam_num > 1 else None
+        x = fn.PatchEmbedFn.apply(imgs, base.patch_embed.proj.weight, base.patch_embed.proj.bias, base.cls_token,
+                                  base.pos_embed, sie, cam if sie is not None else None, float(base.sie_xishu),
+                                  self.act_dtype)
+        probs = torch.empty(base.depth, btot, base.heads, t, t, dtype=torch.float32, device=imgs.device)
+        for i, blk in enumerate(base.blocks):
+            rs_a = rs_m = None
+            p = base.drop_rates[i]
+            if self.training and p > 0.0:                                       # vit_pytorch.py:52-69
+                rs_a = self._drop_rows(btot, t, p, imgs.device)
+                rs_m = self._drop_rows(btot, t, p, imgs.device)
+            x = fn.TransformerBlockFn.apply(x, *_block_args(blk.norm1, blk.attn, blk.norm2, blk.mlp), None,
+                                            probs[i], base.heads, 1e-6, self.act_dtype, rs_a, rs_m)
+        x = fn.LayerNormFn.apply(x, base.norm.weight, base.norm.bias, 1e-6, None)
+        return x, probs
+
+    @staticmethod
+    def _drop_rows(b, t, p, device):
+        keep = 1.0 - p
+        r = torch.floor(keep + torch.rand(b, device=device)) / keep
+        return r.repeat_interleave(t).contiguous()
+
+    def _select(self, probs, mask_fre, b):
+        """Part_Attention x3 + union with the frequency mask (SFTS.py:145-164,183-187) -> (B,N) uint8."""
+        l, btot, h, t, _ = probs.shape
+        scores = ops.attn_rollout(probs)                                        # (3B, h, N)
+        m = ops.topk_mask(scores.view(btot * h, t - 1), self.head_k, group=h)    # (3B, N)
+        nmod = btot // b
+        index = ops.mask_or(m[:b], m[b:2 * b], m[2 * b:3 * b] if nmod > 2 else None, mask_fre)
+        self.last_aux = {"scores": scores, "attn_masks": m.view(nmod, b, t - 1), "mask_fre": mask_fre, "index": index}
+        return index
+
+    def _hma(self, feats_s, index, label):
+        """BlockMask.forward (vit_pytorch.py:309-352): feats_s (3,B,T,D) fp32 -> fused (B,3T,D), loss_ocfr."""
+        fb = self.FUSE_block
+        nmod, b, t, d = feats_s.shape
+        mask = torch.cat([torch.ones(b, 1, dtype=torch.uint8, device=index.device), index], dim=1).contiguous()
+        mods = []
+        for i, tag in enumerate(("R", "N", "T")):
+            args = _block_args(getattr(fb, "norm" + tag), getattr(fb, "attn" + tag), getattr(fb, "norm" + tag + "_"),
+                               getattr(fb, "mlp" + tag))
+            mods.append(fn.TransformerBlockFn.apply(feats_s[i], *args, mask, None, self.hma_heads, 1e-5,
+                                                    self.act_dtype, None, None))
+        loss_ocfr = None
+        if self.training:
+            loss_ocfr = self._ocfr([m_[:, 0] for m_ in mods], label)
+        x = torch.cat(mods, dim=1)
+        mask3 = mask.repeat(1, nmod).contiguous()
+        x = fn.TransformerBlockFn.apply(x, *_block_args(fb.norm1, fb.attn1, fb.norm2, fb.mlp), mask3, None,
+                                        self.hma_heads, 1e-5, self.act_dtype, None, None)
+        x = fn.LayerNormFn.apply(x, fb.out_norm.weight, fb.out_norm.bias, 1e-5, mask3.view(-1))
+        return x, loss_ocfr
+
+    def _ocfr(self, cls_feats, label):
+        """OCFR.forward (OCFR.py:44-84).  Tiny (3 x (B,D)); host-side tensor ops on device for now."""
+        mc = self.FUSE_block.memory_cls
+        mom = torch.tensor(self.FUSE_block.momentum, dtype=torch.float32, device=label.device)
+        uniq, inv = torch.unique(label, return_inverse=True)
+        cnt = torch.bincount(inv, minlength=uniq.numel()).clamp_min(1).unsqueeze(1).float()
+        loss = 0.0
+        for f, name in zip(cls_feats, ("RGB", "NIR", "TIR")):
+            centers = getattr(mc, name + "_centers")
+            fnorm = F.normalize(f, dim=1)
+            with torch.no_grad():
+                batch_c = torch.zeros(uniq.numel(), f.shape[1], device=f.device).index_add_(0, inv, fnorm) / cnt
+                centers[uniq] = mom * batch_c + (1 - mom) * centers[uniq]
+                target = centers[uniq][inv]
+            loss = loss + F.mse_loss(target, fnorm)
+        return loss
+
+    # -- forward (make_model.py:150-258) ----------------------------------------------------------
+    def forward(self, x, cam_label=None, label=None, view_label=None, img_path=None, mode=1, writer=None, epoch=None):
+        rgb, nir, tir = x["RGB"], x["NI"], x["TI"]
+        if not rgb.is_cuda:
+            raise RuntimeError("EDITOR (MI355X build): inputs must be on the GPU; there is no CPU fallback path")
+        b = rgb.shape[0]
+        dim = self.BACKBONE.token_dim
+        with torch.no_grad():
+            mask_fre, _ = ops.frequency_mask(rgb.contiguous(), nir.contiguous(), tir.contiguous(), self.FREQ_INDEX.keep)
+        imgs = torch.cat([rgb, nir, tir], dim=0).contiguous()
+        feats, probs = self._backbone(imgs, cam_label)
+        t = feats.shape[1]
+        with torch.no_grad():
+            index = self._select(probs, mask_fre, b)
+            if self.teacher_index is not None:
+                index = self.teacher_index.to(index.device).to(torch.uint8).contiguous()
+                self.last_aux["index"] = index
+        del probs
+        feats = feats.view(3, b, t, dim)
+        cls_tri = [feats[i, :, 0] for i in range(3)]
+        training = self.training
+        if training:
+            if self.AL:
+                ori = torch.cat(cls_tri, dim=-1)
+                ori_score = fn.LinearFn.apply(self._bn(self.AL_BN, ori), self.AL_HEAD.weight, None)
+            else:
+                mod_scores = [fn.LinearFn.apply(self._bn(self.BACKBONE_BN, c), self.BACKBONE_HEAD.weight, None)
+                              for c in cls_tri]
+        feats_s, loss_bcc = fn.SFTSApplyFn.apply(feats, index, training)
+        fused, loss_ocfr = self._hma(feats_s, index, label)
+        pooled, num = fn.PoolFn.apply(fused, 3, t)
+        if training and writer is not None:
+            writer.add_scalar("num_count", num.mean(), epoch)                      # make_model.py:199-200
+        red = [fn.LinearFn.apply(pooled[i], getattr(self, tag + "_REDUCE").weight, getattr(self, tag + "_REDUCE").bias)
+               for i, tag in enumerate(("RGB", "NIR", "TIR"))]
+        cls4t = torch.cat(red, dim=-1)
+        self.last_aux.update(num=num, loss_bcc=loss_bcc, loss_ocfr=loss_ocfr)
+        if not training:
+            return cls4t
+        score = fn.LinearFn.apply(self._bn(self.FUSE_BN, cls4t), self.FUSE_HEAD.weight, None)
+        aux_loss = loss_bcc + loss_ocfr
+        if self.AL:
+            return score, cls4t, ori_score, ori, aux_loss
+        return (score, cls4t, mod_scores[0], cls_tri[0], mod_scores[1], cls_tri[1], mod_scores[2], cls_tri[2],
+                aux_loss)
+
+    def _bn(self, bn, x):
+        return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, self.training, bn.momentum, bn.eps)
+
+
+def make_model(cfg, num_class, camera_num):
+    model = EDITOR(num_class, cfg, camera_num)
+    print("===========Building EDITOR===========")
+    return model

@@ -1,0 +1,237 @@
+"""Thin tensor-level wrappers over the C ABI (include/editor_hip.h).  No math happens here: each
+function allocates outputs with torch (device memory plumbing) and launches HIP kernels on the
+current stream.  Every function raises on CPU tensors - there is no fallback path."""
+import torch
+
+from . import _lib
+
+call = _lib.call
+
+
+# ---------------------------------------------------------------------------------------------
+# token selection
+# ---------------------------------------------------------------------------------------------
+def freq_counts(rgb, nir, tir):
+    """Frequency.py:65-84,42-56 -> (B, N) int32 positive-pixel counts per 16x16 patch."""
+    b, c, h, w = rgb.shape
+    counts = torch.empty(b, (h // 16) * (w // 16), dtype=torch.int32, device=rgb.device)
+    call("editor_freq_counts_f32", rgb.contiguous(), nir.contiguous(),
+         None if tir is None else tir.contiguous(), b, c, h, w, counts)
+    return counts
+
+
+def topk_mask(vals, k, group=1):
+    """torch.topk -> sort -> scatter_ bool rows (torch CPU tie order); `group` rows OR together."""
+    rows, n = vals.shape
+    mask = torch.empty(rows // group, n, dtype=torch.uint8, device=vals.device)
+    if vals.dtype == torch.int32:
+        call("editor_topk_mask_i32", vals.contiguous(), rows, n, int(k), int(group), mask)
+    elif vals.dtype == torch.float32:
+        call("editor_topk_mask_f32", vals.contiguous(), rows, n, int(k), int(group), mask)
+    else:
+        raise TypeError(vals.dtype)
+    return mask
+
+
+def frequency_mask(rgb, nir, tir, keep):
+    counts = freq_counts(rgb, nir, tir)
+    return topk_mask(counts, keep), counts
+
+
+def attn_rollout(probs):
+    """probs: (L, B, H, T, T) fp32 contiguous -> (B, H, T-1) CLS-row rollout scores (SFTS.py:150-153)."""
+    l, b, h, t, _ = probs.shape
+    scores = torch.empty(b, h, t - 1, dtype=torch.float32, device=probs.device)
+    call("editor_attn_rollout_f32", probs, l, b * h, t, b * h * t * t, scores)
+    return scores
+
+
+def mask_or(a, b=None, c=None, d=None):
+    out = torch.empty_like(a)
+    call("editor_mask_or", a, b, c, d, out, a.numel())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def workspace(device, nfloats):
+    """Per-device fp32 scratch for partial reductions (kernels never allocate)."""
+    key = (device.type, device.index)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nfloats:
+        ws = torch.empty(max(int(nfloats), 1 << 22), dtype=torch.float32, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def _is_bf16(t):
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def _ptr(t, off=0):
+    """raw device address of element `off` of tensor t (for sub-matrix operands)."""
+    if not t.is_cuda:
+        raise RuntimeError("EDITOR ops need GPU tensors (no CPU fallback)")
+    return t.data_ptr() + off * t.element_size()
+
+
+WS_ROWS = 512
+
+
+# ---------------------------------------------------------------------------------------------
+# row kernels
+# ---------------------------------------------------------------------------------------------
+def layernorm_fwd(x2d, gamma, beta, eps, out_dtype, rowmask=None, mask_period=0, want_stats=True):
+    m, d = x2d.shape
+    y = torch.empty(m, d, dtype=out_dtype, device=x2d.device)
+    mean = torch.empty(m, dtype=torch.float32, device=x2d.device) if want_stats else None
+    rstd = torch.empty(m, dtype=torch.float32, device=x2d.device) if want_stats else None
+    call("editor_layernorm_fwd", x2d, gamma, beta, float(eps), m, d, rowmask, int(mask_period), y, _is_bf16(y), mean, rstd)
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x2d, gamma, mean, rstd, rowmask=None, mask_period=0, dx_in=None, want_param_grads=True):
+    m, d = x2d.shape
+    dx = torch.empty(m, d, dtype=torch.float32, device=x2d.device)
+    dg = torch.empty(d, dtype=torch.float32, device=x2d.device) if want_param_grads else None
+    db = torch.empty(d, dtype=torch.float32, device=x2d.device) if want_param_grads else None
+    ws = workspace(x2d.device, (WS_ROWS + 1) * 2 * d)
+    call("editor_layernorm_bwd", dy, _is_bf16(dy), x2d, gamma, mean, rstd, m, d, rowmask, int(mask_period), dx_in, dx,
+         dg, db, ws, WS_ROWS)
+    return dx, dg, db
+
+
+def colsum(dy):
+    m, n = dy.shape
+    out = torch.empty(n, dtype=torch.float32, device=dy.device)
+    ws = workspace(dy.device, WS_ROWS * n)
+    call("editor_colsum", dy, _is_bf16(dy), m, n, n, out, ws, WS_ROWS)
+    return out
+
+
+def gelu_fwd(a):
+    g = torch.empty_like(a)
+    call("editor_gelu_fwd", a, g, a.numel(), _is_bf16(a))
+    return g
+
+
+def gelu_bwd(a, dg):
+    da = torch.empty_like(a)
+    call("editor_gelu_bwd", a, dg, da, a.numel(), _is_bf16(a))
+    return da
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    if x.dtype == torch.float32 and dtype == torch.bfloat16:
+        call("editor_cast_f32_to_bf16", x, out, x.numel())
+    elif x.dtype == torch.bfloat16 and dtype == torch.float32:
+        call("editor_cast_bf16_to_f32", x, out, x.numel())
+    else:
+        raise TypeError((x.dtype, dtype))
+    return out
+
+
+def im2col16(img, dtype):
+    b, c, h, w = img.shape
+    out = torch.empty(b * (h // 16) * (w // 16), c * 256, dtype=dtype, device=img.device)
+    call("editor_im2col16", img, b, c, h, w, out, _is_bf16(out))
+    return out
+
+
+def embed_assemble(patch, cls, pos, sie, cam, coef, btot, t, d):
+    x = torch.empty(btot, t, d, dtype=torch.float32, device=patch.device)
+    call("editor_embed_assemble", patch, _is_bf16(patch), cls, pos, sie, cam, 0 if cam is None else cam.numel(),
+         float(coef), btot, t, d, x)
+    return x
+
+
+def embed_assemble_bwd(dx, cam, ncam, coef, dtype):
+    btot, t, d = dx.shape
+    dpatch = torch.empty(btot * (t - 1), d, dtype=dtype, device=dx.device)
+    dpos = torch.empty(t, d, dtype=torch.float32, device=dx.device)
+    dsie = torch.empty(ncam, d, dtype=torch.float32, device=dx.device) if ncam else None
+    call("editor_embed_assemble_bwd", dx, cam, 0 if cam is None else cam.numel(), int(ncam), float(coef), btot, t, d,
+         dpatch, _is_bf16(dpatch), dpos, dsie)
+    return dpatch, dpos, dsie
+
+
+def sfts_apply(feat, index, want_loss):
+    nmod, b, t, d = feat.shape
+    out = torch.empty_like(feat)
+    loss = torch.empty(1, dtype=torch.float32, device=feat.device) if want_loss else None
+    ws = workspace(feat.device, 4096)
+    call("editor_sfts_apply", feat, index, nmod, b, t, d, out, loss, ws, 4096)
+    return out, loss
+
+
+def sfts_apply_bwd(feat, index, dout, dloss):
+    nmod, b, t, d = feat.shape
+    dfeat = torch.empty_like(feat)
+    call("editor_sfts_apply_bwd", feat, index, dout, dloss, nmod, b, t, d, dfeat)
+    return dfeat
+
+
+def pool_fwd(x, nmod, t):
+    b, _, d = x.shape
+    out = torch.empty(nmod, b, 2 * d, dtype=torch.float32, device=x.device)
+    num = torch.empty(b, dtype=torch.float32, device=x.device)
+    call("editor_pool_fwd", x, b, nmod, t, d, out, num)
+    return out, num
+
+
+def pool_bwd(dout, num, nmod, t):
+    _, b, d2 = dout.shape
+    dx = torch.empty(b, nmod * t, d2 // 2, dtype=torch.float32, device=dout.device)
+    call("editor_pool_bwd", dout, num, b, nmod, t, d2 // 2, dx)
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------
+# contractions
+# ---------------------------------------------------------------------------------------------
+def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=0.0, bias=None, rowscale=None,
+         splitk=1, a_off=0, b_off=0, c_off=0):
+    """c = alpha * op(a) op(b) (+bias) (+beta*c) (*rowscale); dtype picks the kernel family
+    (fp32 -> exact-f32 MFMA, bf16 -> bf16 MFMA with fp32 accumulate; c may be fp32 for bf16 inputs)."""
+    if a.dtype == torch.float32:
+        assert b.dtype == torch.float32 and c.dtype == torch.float32
+        call("editor_gemm_f32", _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), m, n, k, lda, ldb, ldc,
+             int(trans_a), int(trans_b), 1, 0, 0, 0, 1, 0, 0, 0, float(alpha), float(beta), bias, rowscale, int(splitk))
+    elif a.dtype == torch.bfloat16:
+        assert b.dtype == torch.bfloat16
+        call("editor_gemm_bf16", _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), 1 if c.dtype == torch.float32 else 0,
+             m, n, k, lda, ldb, ldc, int(trans_a), int(trans_b), float(alpha), float(beta), bias, rowscale, int(splitk))
+    else:
+        raise TypeError(a.dtype)
+
+
+def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None):
+    """Attention / AttentionMask core on packed qkv (b*t, 3*heads*hd) -> (b*t, heads*hd)."""
+    d = heads * hd
+    out = torch.empty(b * t, d, dtype=qkv.dtype, device=qkv.device)
+    scale = hd ** -0.5
+    if qkv.dtype == torch.float32:
+        if probs is None:
+            probs = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
+        call("editor_attention_fwd_f32", qkv, b, t, heads, hd, scale, mask, out, probs)
+    else:
+        call("editor_attention_fwd_bf16", qkv, b, t, heads, hd, scale, mask, out, probs)
+    return out, probs
+
+
+def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, probs=None, out=None):
+    dqkv = torch.empty_like(qkv)
+    scale = hd ** -0.5
+    if qkv.dtype == torch.float32:
+        ws = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
+        call("editor_attention_bwd_f32", qkv, dout, probs, b, t, heads, hd, scale, dqkv, ws)
+    else:
+        call("editor_attention_bwd_bf16", qkv, dout, out, b, t, heads, hd, scale, mask, dqkv)
+    return dqkv

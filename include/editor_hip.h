@@ -1,0 +1,123 @@
+/* libeditor_hip.so - C ABI of the MI355X-native EDITOR hot path (gfx950 / CDNA4).
+ *
+ * The reference (924973292/EDITOR) is 100 % Python: its "operator interface" for this path is the
+ * sequence of PyTorch ops inside modeling/make_model.py:150-258.  Each entry point below replaces one
+ * of those op sequences (file:line given per function); the Python host (editor_amd/) binds them with
+ * ctypes exactly as INTEGRATION.md shows.
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator); kernels never
+ *     allocate or free; workspaces are passed in;
+ *   - every launch is asynchronous on `stream` (hipStream_t; pass torch.cuda.current_stream().cuda_stream);
+ *   - return value is a hipError_t as int (0 = success); no exceptions, no global mutable state;
+ *   - dtype suffix: _f32 = float activations, _bf16 = bfloat16 activations (raw uint16 bits);
+ *     statistics, residual stream, losses and parameter gradients are always fp32;
+ *   - masks are uint8 (0/1), row-major; token rows are (sample, token) row-major.
+ */
+#ifndef EDITOR_HIP_H
+#define EDITOR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* editor_stream_t;   /* == hipStream_t */
+
+/* ---- token selection (non-differentiable) ---------------------------------------------------- */
+
+/* Frequency.py:65-84 + :42-56 - 4-level Haar DWT of each modality (pytorch_wavelets AFB2D, lowlevel.py:336-347),
+ * coefficient mean over modalities, inverse DWT (SFB2D, lowlevel.py:671-680), channel mean, count of >0 pixels
+ * per 16x16 window.  rgb/nir/tir: (B,C,H,W) fp32 NCHW (tir may be NULL: two-modality form);
+ * counts: (B, H/16*W/16) int32, patches row-major as PatchEmbed flattens them (vit_pytorch.py:457). */
+int editor_freq_counts_f32(const float* rgb, const float* nir, const float* tir, int B, int C, int H, int W,
+                           int32_t* counts, editor_stream_t stream);
+
+/* torch.topk(k) -> sort -> scatter_ to a bool row (Frequency.py:58-62, SFTS.py:155-158) with torch's CPU tie
+ * order (libstdc++ partial_sort if k*64<=n else nth_element).  vals: (rows,n); `group` consecutive rows OR
+ * into one mask row (SFTS.py:159-162: OR over heads); mask: (rows/group, n) uint8, fully overwritten. */
+int editor_topk_mask_i32(const int32_t* vals, int rows, int n, int k, int group, uint8_t* mask, editor_stream_t stream);
+int editor_topk_mask_f32(const float* vals, int rows, int n, int k, int group, uint8_t* mask, editor_stream_t stream);
+
+/* Part_Attention rollout (SFTS.py:150-153): CLS row of A_{L-1} @ ... @ A_0 without the CLS column.
+ * probs: L tensors of (BH,T,T) fp32 spaced `layer_stride` floats apart; scores: (BH, T-1) fp32. */
+int editor_attn_rollout_f32(const float* probs, int L, int BH, int T, long layer_stride, float* scores,
+                            editor_stream_t stream);
+
+/* index = a | b | c | d (SFTS.py:185-187); b, c, d may be NULL. */
+int editor_mask_or(const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d, uint8_t* out, long n,
+                   editor_stream_t stream);
+
+/* ---- row kernels (HBM-bound) -------------------------------------------------------------------- */
+
+/* nn.LayerNorm over D (vit_pytorch.py:206,211,268-297,519); x fp32 (M,D) residual stream; y fp32 or bf16.
+ * rowmask (uint8, may be NULL): rows with mask 0 produce y = 0 (AttentionMask/MlpMasked zero the LN output of
+ * unselected tokens, vit_pytorch.py:245,162); mask row = row % mask_period (0 = no wrap).  mean/rstd: (M) fp32. */
+int editor_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, long M, int D,
+                         const uint8_t* rowmask, int mask_period, void* y, int y_bf16, float* mean, float* rstd,
+                         editor_stream_t stream);
+/* backward: dx_out = (dx_in ? dx_in : 0) + dLN/dx ; dgamma/dbeta (D) fp32 (NULL to skip).
+ * workspace: (ws_rows+1)*2*D floats. */
+int editor_layernorm_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
+                         const float* rstd, long M, int D, const uint8_t* rowmask, int mask_period,
+                         const float* dx_in, float* dx_out, float* dgamma, float* dbeta, float* workspace,
+                         int ws_rows, editor_stream_t stream);
+/* out[n] = sum_m dy[m,n]  (bias gradients of every nn.Linear).  workspace: ws_rows*N floats. */
+int editor_colsum(const void* dy, int dy_bf16, long M, int N, long ld, float* out, float* workspace, int ws_rows,
+                  editor_stream_t stream);
+int editor_reduce_rows(const float* partials, int P, long ncol, float* out, int accumulate, float scale,
+                       editor_stream_t stream);
+/* nn.GELU() exact erf (vit_pytorch.py:130,141) and its derivative */
+int editor_gelu_fwd(const void* a, void* g, long n, int bf16, editor_stream_t stream);
+int editor_gelu_bwd(const void* a, const void* dg, void* da, long n, int bf16, editor_stream_t stream);
+int editor_cast_f32_to_bf16(const float* in, uint16_t* out, long n, editor_stream_t stream);
+int editor_cast_bf16_to_f32(const uint16_t* in, float* out, long n, editor_stream_t stream);
+
+/* PatchEmbed_overlap with stride == patch == 16 (vit_pytorch.py:449-458): im2col rows (b*N+p), cols (c,i,j). */
+int editor_im2col16(const float* img, int B, int C, int H, int W, void* out, int out_bf16, editor_stream_t stream);
+/* cls token + pos_embed + SIE_COE * sie_embed[cam] (vit_pytorch.py:627-637).  Btot samples may hold several
+ * modalities stacked on the batch axis sharing `cam` (length Bcam): cam index = b % Bcam.  sie may be NULL. */
+int editor_embed_assemble(const void* patch, int patch_bf16, const float* cls, const float* pos, const float* sie,
+                          const long* cam, int Bcam, float coef, long Btot, int T, int D, float* x,
+                          editor_stream_t stream);
+int editor_embed_assemble_bwd(const float* dx, const long* cam, int Bcam, int ncam, float coef, long Btot, int T, int D,
+                              void* dpatch, int dpatch_bf16, float* dpos, float* dsie, editor_stream_t stream);
+
+/* SFTS.forward mask application + BCC loss (SFTS.py:208-225).  feat/out: (nmod,B,T,D) fp32; index (B,T-1) uint8;
+ * loss (1) fp32 or NULL (eval); workspace: ws_len floats. */
+int editor_sfts_apply(const float* feat, const uint8_t* index, int nmod, long B, int T, int D, float* out,
+                      float* loss, float* workspace, int ws_len, editor_stream_t stream);
+int editor_sfts_apply_bwd(const float* feat, const uint8_t* index, const float* dout, const float* dloss, int nmod,
+                          long B, int T, int D, float* dfeat, editor_stream_t stream);
+/* cls + masked-mean pooling of the fused tokens (make_model.py:186-203). x (B,nmod*T,D) -> out (nmod,B,2D), num (B) */
+int editor_pool_fwd(const float* x, long B, int nmod, int T, int D, float* out, float* num, editor_stream_t stream);
+int editor_pool_bwd(const float* dout, const float* num, long B, int nmod, int T, int D, float* dx,
+                    editor_stream_t stream);
+int editor_rowmask_mul(float* x, const uint8_t* rowmask, int period, long M, int D, editor_stream_t stream);
+
+/* ---- contractions ---------------------------------------------------------------------------------- */
+
+/* C = alpha * opA(A) opB(B) (+bias[n]) (+beta*C) (*rowscale[m]) on the exact-fp32 matrix cores.
+ * transA=0: A stored (M,K) row-major, 1: stored (K,M).  transB=0: B stored (N,K) (nn.Linear weight layout),
+ * 1: stored (K,N).  Two batch levels (count, element strides).  splitk>1 accumulates with fp32 atomics.
+ * Replaces F.linear / torch.matmul in vit_pytorch.py:139-145,184-198,240-258 and make_model.py:162-171,205-209. */
+int editor_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
+                    int transA, int transB, int batch1, long sA1, long sB1, long sC1, int batch2, long sA2, long sB2,
+                    long sC2, float alpha, float beta, const float* bias, const float* rowscale, int splitk,
+                    editor_stream_t stream);
+
+/* Attention.forward / AttentionMask.forward on packed qkv rows (B*T, 3*heads*hd) (vit_pytorch.py:184-198,240-258).
+ * mask (B,T) uint8 or NULL.  out (B*T, heads*hd).  probs (B,heads,T,T) fp32: the softmax output the backbone
+ * returns (vit_pytorch.py:638-644); REQUIRED in the f32 form (it is also the score buffer). */
+int editor_attention_fwd_f32(const float* qkv, int B, int T, int heads, int hd, float scale, const uint8_t* mask,
+                             float* out, float* probs, editor_stream_t stream);
+int editor_attention_bwd_f32(const float* qkv, const float* dout, const float* probs, int B, int T, int heads, int hd,
+                             float scale, float* dqkv, float* workspace, editor_stream_t stream);
+
+/* ---- bring-up probes (tests only) ------------------------------------------------------------- */
+int editor_probe_tr16(const int* addr, uint16_t* out, editor_stream_t stream);
+int editor_probe_mfma16(const float* A, const float* B, float* D, editor_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,169 @@
+"""Generate tests/golden/*.npz from the REFERENCE itself (run in the build container only).
+
+    python tests/golden/capture_golden.py
+
+Imports /root/reference with the shims of tools/ref_shims.py, drives it
+with this repo's seeded generator (editor_amd/synth.py: inputs AND weights by parameter name)
+and stores only small OUTPUTS; tests regenerate the inputs from (seed, cfg).  The reference has
+no tests / golden vectors of its own, so these captures are the parity pins.
+Nothing from the reference's source travels: fixtures are numeric arrays.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from editor_amd import config, synth          # noqa: E402
+from tools import ref_shims                    # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = v
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print("wrote", name, os.path.getsize(path) // 1024, "KiB")
+
+
+def build(preset, seed, **over):
+    cfg, c, cams = config.preset(preset, **over)
+    m = ref_shims.build_reference_model(cfg, c, cams)
+    synth.fill_state_dict_(m.state_dict(), seed)
+    return m, cfg, c, cams
+
+
+def f1_frequency():
+    """F1: mask_fre + positive counts for B=128 at the three input sizes (Frequency.py:65-84)."""
+    for tag, (h, w) in {"256x128": (256, 128), "128x256": (128, 256), "384x128": (384, 128)}.items():
+        cfg = config.make_cfg(size_train=(h, w))
+        m = ref_shims.build_reference_model(cfg, 8, 2)
+        for kind, smooth in (("u8", False), ("smooth", True)):
+            img, _, _, _ = synth.make_batch(11, 128, h, w, 2, smooth=smooth)
+            fi = m.FREQ_INDEX
+            with torch.no_grad():
+                mask = fi(x=img["RGB"], y=img["NI"], z=img["TI"], img_path=None)
+                # counts: same torch calls the reference's mask() makes (Frequency.py:44-56)
+                coeff = [fi.DWT(img[k]) for k in ("RGB", "NI", "TI")]
+                low = (coeff[0][0] + coeff[1][0] + coeff[2][0]) / 3
+                high = [(coeff[0][1][j] + coeff[1][1][j] + coeff[2][1][j]) / 3 for j in range(4)]
+                inv = fi.IDWT((low, high)).mean(dim=1)
+                cnt = torch.stack([F.unfold(inv[b][None, None], 16, stride=16).gt(0).sum(1).view(-1)
+                                   for b in range(inv.shape[0])]).to(torch.int32)
+            save(f"f1_freq_{tag}_{kind}", mask=mask, counts=cnt, seed=11, smooth=smooth,
+                 inv_sample=inv[0, :16, :16])
+
+
+def f2_f3_eval(preset="RGBNT201", seed=21, batch=4, tag="vitb"):
+    """F2 (per-modality Part_Attention masks + CLS-row scores) and F3 (index, num, cls4t), eval."""
+    m, cfg, c, cams = build(preset, seed, drop_path=0.0)
+    m.eval()
+    h, w = cfg.INPUT.SIZE_TRAIN
+    img, label, cam, view = synth.make_batch(seed + 1, batch, h, w, cams)
+    rec = {}
+    with torch.no_grad():
+        for key, name in (("RGB", "rgb"), ("NI", "nir"), ("TI", "tir")):
+            feat, attn = m.BACKBONE(img[key], cam_label=cam, view_label=view)
+            last = attn[0]
+            for a in attn[1:]:
+                last = torch.matmul(a, last)
+            rec["scores_" + name] = last[:, :, 0, 1:]
+            _, pm = m.SFTS.part_select(attn)
+            rec["mask_" + name] = pm
+            rec["feat_" + name] = feat[:, :3, :16]              # small slice of the final-LN tokens
+            rec["attn0_" + name] = attn[0][:2, :2, :4, :]
+            rec["attn11_" + name] = attn[-1][:2, :2, :4, :]
+        cls4t = m(img, cam_label=cam, view_label=view)
+        mask_fre = m.FREQ_INDEX(x=img["RGB"], y=img["NI"], z=img["TI"], img_path=None)
+    rec["index"] = rec["mask_rgb"] | rec["mask_nir"] | rec["mask_tir"] | mask_fre
+    save(f"f3_eval_{tag}", cls4t=cls4t, mask_fre=mask_fre, seed=seed, batch=batch, preset=preset, **rec)
+
+
+def f4_f5_train(preset, seed, batch, instances, tag, al=None):
+    """F4 full train tuple + loss parts + OCFR centre rows; F5 selected grads after one backward."""
+    over = dict(drop_path=0.0)
+    if al is not None:
+        over["al"] = al
+    m, cfg, c, cams = build(preset, seed, **over)
+    m.train()
+    h, w = cfg.INPUT.SIZE_TRAIN
+    img, label, cam, view = synth.make_batch(seed + 1, batch, h, w, cams, instances=instances)
+    parts = {}
+    m.SFTS.register_forward_hook(lambda mod, i, o: parts.__setitem__("loss_bcc", o[-1].detach().clone()))
+    m.FUSE_block.register_forward_hook(lambda mod, i, o: parts.__setitem__("loss_ocfr", o[1].detach().clone()))
+    wr = ref_shims.Writer()
+    out = m(img, label=label, cam_label=cam, view_label=view, img_path=None, writer=wr, epoch=1)
+    sys.path.insert(0, os.path.join(ROOT))
+    from oracle.editor_ref import projection_loss
+    loss = projection_loss(out)
+    loss.backward()
+    rec = {"out%d" % i: o for i, o in enumerate(out)}
+    grads = {}
+    named = dict(m.named_parameters())
+    # small tensors are stored whole ("g:"), large ones as a leading slice + norm ("gs:"/"gn:")
+    for name in ["FUSE_HEAD.weight", "RGB_REDUCE.bias", "TIR_REDUCE.weight", "BACKBONE.base.cls_token",
+                 "BACKBONE.base.pos_embed", "BACKBONE.base.sie_embed", "BACKBONE.base.norm.weight",
+                 "BACKBONE.base.patch_embed.proj.bias", "BACKBONE.base.patch_embed.proj.weight",
+                 "FUSE_block.out_norm.bias", "FUSE_block.normR.weight", "FUSE_BN.weight",
+                 "BACKBONE.base.blocks.0.norm1.bias", "BACKBONE.base.blocks.11.mlp.fc2.bias",
+                 "BACKBONE.base.blocks.0.attn.qkv.weight", "BACKBONE.base.blocks.0.attn.qkv.bias",
+                 "BACKBONE.base.blocks.11.mlp.fc1.weight", "BACKBONE.base.blocks.5.attn.proj.weight",
+                 "BACKBONE.base.blocks.7.mlp.fc2.weight",
+                 "FUSE_block.attn1.qkv.weight", "FUSE_block.mlpN.fc2.weight", "FUSE_block.mlp.fc1.weight",
+                 "FUSE_block.attnT.proj.weight", "AL_HEAD.weight", "BACKBONE_HEAD.weight",
+                 "BACKBONE_BN.bias", "AL_BN.weight"]:
+        if name not in named or named[name].grad is None:
+            continue
+        g = named[name].grad
+        if g.numel() <= 4096:
+            grads["g:" + name] = g
+        else:
+            g2 = g.reshape(g.shape[0], -1) if g.dim() > 1 else g.reshape(1, -1)
+            grads["gs:" + name] = g2[:16, :16]
+            grads["gn:" + name] = g.norm()
+    uniq = label.unique()
+    cen = {"cen_" + t: getattr(m.FUSE_block.memory_cls, t + "_centers")[uniq][:, :32]
+           for t in ("RGB", "NIR", "TIR")}
+    bn = {"bn_mean": m.FUSE_BN.running_mean[:64], "bn_var": m.FUSE_BN.running_var[:64]}
+    save(f"f4_train_{tag}", loss=loss, num_count=wr.scalars["num_count"], seed=seed, batch=batch,
+         instances=instances, preset=preset, al=cfg.MODEL.AL, **rec, **parts, **grads, **cen, **bn)
+
+
+def f6_blocks(seed=41):
+    """F6: single Block / BlockMask in->out pairs (vit_pytorch.py:201-224, 309-352) at D=768,h=12."""
+    m, cfg, c, cams = build("RGBNT201", seed, drop_path=0.0)
+    m.eval()
+    x = synth.normal(seed, "blk/x", (2, 129, 768), 1.0)
+    with torch.no_grad():
+        y, a = m.BACKBONE.base.blocks[3](x, get_att=True)
+        feats = [synth.normal(seed, "hma/%d" % i, (2, 129, 768), 1.0) for i in range(3)]
+        idx = synth.integers(seed, "hma/mask", (2, 128), 2).bool()
+        fs = [torch.cat([f[:, :1], f[:, 1:] * idx.unsqueeze(-1)], 1) for f in feats]
+        z = m.FUSE_block(fs[0], fs[1], fs[2], mask=idx.unsqueeze(-1), label=None)
+    save("f6_blocks", block3_out=y[:, :8, :64], block3_attn=a[:, :2, :8, :], hma_out=z[:, ::16, :64],
+         hma_out_norm=z.norm(), seed=seed)
+
+
+if __name__ == "__main__":
+    assert ref_shims.have_reference(), "run in the build container (needs /root/reference)"
+    which = sys.argv[1:] or ["f1", "f3", "f4", "f6"]
+    if "f1" in which:
+        f1_frequency()
+    if "f3" in which:
+        f2_f3_eval("RGBNT201", 21, 4, "vitb_256x128")
+        f2_f3_eval("MSVR310", 23, 2, "vitb_384x128")
+    if "f4" in which:
+        f4_f5_train("RGBNT201", 31, 16, 8, "vitb_al1")
+        f4_f5_train("RGBNT100", 33, 16, 8, "vitb_al0")
+    if "f6" in which:
+        f6_blocks()
