@@ -105,6 +105,14 @@ int editor_gemm_f32(const float* A, const float* B, float* C, int M, int N, int 
                     long sC2, float alpha, float beta, const float* bias, const float* rowscale, int splitk,
                     editor_stream_t stream);
 
+/* bf16 MFMA form of the same contraction (fp32 accumulate; C bf16 or fp32 per c_f32).  No batching.
+ * Requirements: 16-byte aligned pointers, lda/ldb multiples of 8, N and ldc multiples of 4, the contiguous
+ * extent of each operand a multiple of 8.  transA/transB select the LDS transpose-read path
+ * (ds_read_b64_tr_b16) so dgrad / wgrad need no materialised transposes.  splitk>1 requires c_f32. */
+int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda, long ldb,
+                     long ldc, int transA, int transB, float alpha, float beta, const float* bias,
+                     const float* rowscale, int splitk, editor_stream_t stream);
+
 /* Attention.forward / AttentionMask.forward on packed qkv rows (B*T, 3*heads*hd) (vit_pytorch.py:184-198,240-258).
  * mask (B,T) uint8 or NULL.  out (B*T, heads*hd).  probs (B,heads,T,T) fp32: the softmax output the backbone
  * returns (vit_pytorch.py:638-644); REQUIRED in the f32 form (it is also the score buffer). */

@@ -1,0 +1,193 @@
+"""Unit parity of the HIP row / contraction kernels against plain PyTorch fp32 on CPU
+(per-kernel numerics; the end-to-end parity against the oracle is tests/test_gpu_model.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from editor_amd import ops
+    return ops
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("d", [768, 256, 1024])
+def test_layernorm_fwd_bwd(ops, dtype, d):
+    m = 517
+    x = torch.randn(m, d, generator=_g(1)) * 2 + 0.3
+    w = torch.rand(d, generator=_g(2)) + 0.5
+    b = torch.randn(d, generator=_g(3)) * 0.1
+    mask = (torch.rand(m, generator=_g(4)) > 0.4).to(torch.uint8)
+    for use_mask in (False, True):
+        xr = x.clone().requires_grad_(True)
+        wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y_ref = F.layer_norm(xr, (d,), wr, br, 1e-6)
+        if use_mask:
+            y_ref = y_ref * mask.view(-1, 1).float()
+        dy = torch.randn(m, d, generator=_g(5))
+        dyq = dy.to(dtype).float()
+        y_ref.backward(dyq)
+        mk = mask.cuda() if use_mask else None
+        y, mean, rstd = ops.layernorm_fwd(x.cuda(), w.cuda(), b.cuda(), 1e-6, dtype, mk, 0)
+        tol = 1e-5 if dtype == torch.float32 else 6e-3
+        assert rel_err(y.float().cpu(), y_ref.detach()) < tol
+        res = torch.randn(m, d, generator=_g(6))
+        dx, dg, db = ops.layernorm_bwd(dy.to(dtype).cuda(), x.cuda(), w.cuda(), mean, rstd, mk, 0, dx_in=res.cuda())
+        assert rel_err(dx.cpu(), xr.grad + res) < 2e-5
+        assert rel_err(dg.cpu(), wr.grad) < 2e-5
+        assert rel_err(db.cpu(), br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_f32_layouts(ops, ta, tb):
+    m, n, k = 197, 171, 203
+    a = torch.randn((k, m) if ta else (m, k), generator=_g(1))
+    b = torch.randn((k, n) if tb else (n, k), generator=_g(2))
+    bias = torch.randn(n, generator=_g(3))
+    c0 = torch.randn(m, n, generator=_g(4))
+    ref = 0.7 * ((a.t() if ta else a).double() @ (b if tb else b.t()).double()) + bias.double() + 0.5 * c0.double()
+    c = c0.clone().cuda()
+    ops.gemm(a.cuda(), b.cuda(), c, m, n, k, a.shape[1], b.shape[1], n, ta, tb, alpha=0.7, beta=0.5, bias=bias.cuda())
+    assert rel_err(c.cpu(), ref) < 1e-6
+    # split-K with atomics
+    c = torch.empty(m, n, device="cuda")
+    ops.gemm(a.cuda(), b.cuda(), c, m, n, k, a.shape[1], b.shape[1], n, ta, tb, splitk=5)
+    assert rel_err(c.cpu(), (a.t() if ta else a).double() @ (b if tb else b.t()).double()) < 1e-6
+
+
+def test_gemm_f32_rowscale(ops):
+    m, n, k = 130, 64, 96
+    a, b = torch.randn(m, k, generator=_g(1)), torch.randn(n, k, generator=_g(2))
+    rs = torch.rand(m, generator=_g(3))
+    c0 = torch.randn(m, n, generator=_g(4))
+    c = c0.clone().cuda()
+    ops.gemm(a.cuda(), b.cuda(), c, m, n, k, k, k, n, 0, 0, beta=1.0, rowscale=rs.cuda())
+    # C = rowscale * (A B^T) + 1.0 * C   (drop-path scaled branch added to the residual)
+    assert rel_err(c.cpu(), rs.view(-1, 1) * (a @ b.t()) + c0) < 1e-6
+
+
+def _attn_ref(qkv, b, t, heads, hd, mask):
+    d = heads * hd
+    q, k, v = qkv.view(b, t, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)) * hd ** -0.5
+    if mask is not None:
+        mm = mask.float().view(b, 1, t, 1)
+        s = s.masked_fill((mm @ mm.transpose(-2, -1)) == 0, -65504.0)
+        p = s.softmax(-1) * mm
+    else:
+        p = s.softmax(-1)
+    return (p @ v).transpose(1, 2).reshape(b * t, d), p
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("t,use_mask", [(129, False), (129, True), (193, False), (387, True), (50, False)])
+def test_attention_fwd_bwd(ops, dtype, t, use_mask):
+    b, heads, hd = 3, 12, 64
+    d = heads * hd
+    qkv = (torch.randn(b * t, 3 * d, generator=_g(1)) * 1.5).to(dtype).float()
+    mask = None
+    if use_mask:
+        mask = (torch.rand(b, t, generator=_g(2)) > 0.5).to(torch.uint8)
+        mask[:, 0] = 1
+    qr = qkv.clone().requires_grad_(True)
+    o_ref, p_ref = _attn_ref(qr, b, t, heads, hd, mask)
+    do = torch.randn(b * t, d, generator=_g(3)).to(dtype).float()
+    o_ref.backward(do)
+    probs = torch.zeros(b, heads, t, t, device="cuda")
+    mk = None if mask is None else mask.cuda()
+    o, p = ops.attention_fwd(qkv.to(dtype).cuda(), b, t, heads, hd, mk, probs)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel_err(o.float().cpu(), o_ref.detach()) < tol
+    assert rel_err(p.cpu(), p_ref.detach()) < (2e-5 if dtype == torch.float32 else 1e-2)
+    dqkv = ops.attention_bwd(qkv.to(dtype).cuda(), do.to(dtype).cuda(), b, t, heads, hd, mk, p, o)
+    assert rel_err(dqkv.float().cpu(), qr.grad) < (3e-5 if dtype == torch.float32 else 2.5e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gelu(ops, dtype):
+    a = (torch.randn(4096 * 4, generator=_g(1)) * 2).to(dtype)
+    ar = a.float().requires_grad_(True)
+    g_ref = F.gelu(ar)
+    dg = torch.randn(a.shape, generator=_g(2)).to(dtype)
+    g_ref.backward(dg.float())
+    g = ops.gelu_fwd(a.cuda())
+    da = ops.gelu_bwd(a.cuda(), dg.cuda())
+    tol = 1e-6 if dtype == torch.float32 else 5e-3
+    assert rel_err(g.float().cpu(), g_ref.detach()) < tol
+    assert rel_err(da.float().cpu(), ar.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_colsum_cast(ops, dtype):
+    x = torch.randn(3001, 768, generator=_g(1)).to(dtype)
+    s = ops.colsum(x.cuda())
+    assert rel_err(s.cpu(), x.float().sum(0)) < 1e-5
+    y = torch.randn(1024, 64, generator=_g(2))
+    assert torch.equal(ops.cast(y.cuda(), torch.bfloat16).cpu(), y.bfloat16())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_patch_embed_fn(dtype):
+    from editor_amd import functional as fn
+    b, cams, h, w, d = 4, 3, 64, 32, 256
+    n = (h // 16) * (w // 16)
+    g = _g(7)
+    img = torch.randn(2 * b, 3, h, w, generator=g)
+    cw = (torch.randn(d, 3, 16, 16, generator=g) * 0.05)
+    cb, cls = torch.randn(d, generator=g) * 0.1, torch.randn(1, 1, d, generator=g)
+    pos, sie = torch.randn(1, n + 1, d, generator=g), torch.randn(cams, 1, d, generator=g)
+    cam = torch.randint(0, cams, (b,), generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (cw, cb, cls, pos, sie)]
+    x = F.conv2d(img, leaves[0], leaves[1], stride=16).flatten(2).transpose(1, 2)
+    x = torch.cat([leaves[2].expand(2 * b, -1, -1), x], 1) + leaves[3] + 3.0 * leaves[4][cam.repeat(2)]
+    dx = torch.randn(x.shape, generator=g)
+    x.backward(dx)
+    dl = [t.clone().cuda().requires_grad_(True) for t in (cw, cb, cls, pos, sie)]
+    y = fn.PatchEmbedFn.apply(img.cuda(), *dl, cam.cuda(), 3.0, dtype)
+    y.backward(dx.cuda())
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(y.cpu(), x.detach()) < tol
+    for a, r in zip(dl, leaves):
+        assert rel_err(a.grad.cpu(), r.grad) < tol
+
+
+def test_sfts_apply_and_pool(oracle):
+    from editor_amd import functional as fn
+    b, t, d = 6, 33, 256
+    g = _g(3)
+    feat = torch.randn(3, b, t, d, generator=g)
+    index = torch.rand(b, t - 1, generator=g) > 0.5
+    fr = feat.clone().requires_grad_(True)
+    outs, loss = oracle.sfts_apply([fr[0], fr[1], fr[2]], index, True)
+    dout = torch.randn(3, b, t, d, generator=g)
+    (sum((o * dd).sum() for o, dd in zip(outs, dout)) + 1.7 * loss).backward()
+    fg = feat.clone().cuda().requires_grad_(True)
+    o, l = fn.SFTSApplyFn.apply(fg, index.to(torch.uint8).cuda(), True)
+    ((o * dout.cuda()).sum() + 1.7 * l).backward()
+    assert rel_err(o.cpu(), torch.stack(outs).detach()) == 0
+    assert rel_err(l.cpu(), loss.detach()) < 1e-5
+    assert rel_err(fg.grad.cpu(), fr.grad) < 1e-5
+    # pooling
+    x = torch.stack(outs).detach().permute(1, 0, 2, 3).reshape(b, 3 * t, d).contiguous()
+    xr = x.clone().requires_grad_(True)
+    parts = [xr[:, i * t:(i + 1) * t] for i in range(3)]
+    num = (parts[0][:, 1:].sum(2) != 0).sum(1, keepdim=True)
+    ref = torch.stack([torch.cat([p[:, 0], p[:, 1:].sum(1) / num], -1) for p in parts])
+    dr = torch.randn(ref.shape, generator=g)
+    ref.backward(dr)
+    xg = x.clone().cuda().requires_grad_(True)
+    out, n_ = fn.PoolFn.apply(xg, 3, t)
+    out.backward(dr.cuda())
+    assert torch.equal(n_.cpu().long(), num.view(-1))
+    assert rel_err(out.cpu(), ref.detach()) < 1e-5
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-5
