@@ -1,0 +1,395 @@
+// Fused bf16 multi-head attention (forward + backward) for the EDITOR hot path, gfx950 / CDNA4.
+// Restates Attention.forward (vit_pytorch.py:184-198) and AttentionMask.forward (:240-258) on packed
+// qkv rows (B*T, 3*heads*64); sequences are short (T = 129 / 193 backbone, 387 joint HMA block), so the
+// whole key range of one (sample, head) lives in LDS and a wavefront keeps a FULL score row block in registers:
+// no online-softmax rescaling, and the softmax output can be emitted (the backbone returns it,
+// vit_pytorch.py:638-644; the rollout consumes it).
+//
+// One workgroup per (sample, head); each wavefront owns 16-row "own" tiles and sweeps all "other" rows:
+//   FWD   own = queries, LDS = K,V      S^T = K Q^T -> softmax over keys -> O^T = V^T P^T
+//   DQ    own = queries, LDS = K,V      recompute P^T, dP^T = V dO^T, dS^T, dQ^T = K^T dS^T ; writes lse, delta
+//   DKV   own = keys,    LDS = Q,dO     P = exp(S - lse), dP = dO V^T, dS ; dV^T = dO^T P, dK^T = Q^T dS
+// Every product is a v_mfma_f32_16x16x32_bf16 whose accumulator layout (lane = own column, 4 consecutive
+// other-rows) is directly the next product's B operand after a bf16 pack - no cross-lane movement - using a
+// permuted reduction order that the transposed operand (ds_read_b64_tr_b16 from the row-major LDS image)
+// follows.  Outputs are written as 8-byte (4 x bf16) stores.
+#include "common.h"
+#include "../../include/editor_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+
+namespace {
+
+constexpr int HD = 64;                 // head dim (ViT-B/L, DeiT-S backbones)
+constexpr int ROWB = HD * 2;           // bytes per LDS image row
+constexpr float kLog2e = 1.4426950408889634f;
+
+// LDS image of (rows x 64) bf16: 16-byte chunk c of row r lives at r*128 + ((c ^ (r&7)) << 4)
+__device__ __forceinline__ int img_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
+
+// cooperative load of rows [0,T) of one head slice (64 columns starting at col0 of a row-major matrix with leading
+// dimension ld) into an LDS image of Tp rows; rows >= T are zero filled.
+__device__ __forceinline__ void load_image(char* img, const bf16_t* __restrict__ base, long ld, int T, int Tp)
+{
+    for (int e = threadIdx.x; e < Tp * 8; e += blockDim.x) {
+        const int row = e >> 3, c = e & 7;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < T) v = *reinterpret_cast<const uint4*>(base + (long)row * ld + c * 8);
+        *reinterpret_cast<uint4*>(img + img_off(row, c)) = v;
+    }
+}
+
+// k-major fragment: lane (i = l&15, g = l>>4) <- image[row0 + i][s*32 + g*8 .. +8]
+__device__ __forceinline__ short8_t frag_k(const char* img, int row0, int s, int lane)
+{
+    return *reinterpret_cast<const short8_t*>(img + img_off(row0 + (lane & 15), s * 4 + (lane >> 4)));
+}
+
+// transposed fragment for the reduction over image ROWS: lane (i, g) <- image[row(kappa)][dt*16 + i] with the
+// permuted reduction index  kappa = 8g+e  <->  row = 32*s2 + 16*(e>>2) + 4g + (e&3)   (matches the packed
+// accumulator operand).  Two ds_read_b64_tr_b16: each 16-lane group presents a [4 rows][16 cols] block.
+__device__ __forceinline__ short8_t frag_t(const char* img, int s2, int dt, int lane)
+{
+    const int i = lane & 15, g = lane >> 4;
+    const int r0 = 32 * s2 + 4 * g + (i >> 2), r1 = r0 + 16;
+    const int d0 = dt * 16 + (i & 3) * 4;
+    const int c = d0 >> 3, sub = (d0 & 4) << 1;
+    typedef __attribute__((address_space(3))) short4_t* lds_p;
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + img_off(r0, c) + sub));
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + img_off(r1, c) + sub));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// own-side fragment straight from global: lane (i, g) <- M[row0 + i][s*32 + g*8 .. +8] (zeros beyond T)
+__device__ __forceinline__ short8_t frag_own(const bf16_t* __restrict__ base, long ld, int row0, int T, int s, int lane)
+{
+    const int row = row0 + (lane & 15);
+    if (row >= T) return short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    return *reinterpret_cast<const short8_t*>(base + (long)row * ld + s * 32 + (lane >> 4) * 8);
+}
+
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d)
+{
+    uint2 u; u.x = pack_bf16x2(a, b); u.y = pack_bf16x2(c, d); return u;
+}
+__device__ __forceinline__ short8_t join(uint2 lo, uint2 hi)
+{
+    union { uint32_t u[4]; short8_t s; } x;
+    x.u[0] = lo.x; x.u[1] = lo.y; x.u[2] = hi.x; x.u[3] = hi.y;
+    return x.s;
+}
+__device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+struct AttnArgs {
+    const bf16_t* qkv; const bf16_t* dout; const bf16_t* out_fwd;
+    bf16_t* out; bf16_t* dqkv; float* probs; float* lse; float* delta;
+    const uint8_t* mask;
+    int T, heads; float scale;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// FWD and DQ passes (own = queries; LDS holds the K and V images)
+// ---------------------------------------------------------------------------------------------------------
+template <int NT, bool BWD>
+__global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Tp = NT * 16;
+    char* kimg = smem;
+    char* vimg = smem + Tp * ROWB;
+    const int T = a.T, D = a.heads * HD;
+    const int b = blockIdx.x / a.heads, hh = blockIdx.x % a.heads;
+    const long ld = 3L * D;
+    const bf16_t* qbase = a.qkv + (long)b * T * ld + hh * HD;
+    load_image(kimg, qbase + D, ld, T, Tp);
+    load_image(vimg, qbase + 2 * D, ld, T, Tp);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const uint8_t* mk = a.mask ? a.mask + (long)b * T : nullptr;
+    // validity bits of this lane's keys: key(t, r) = 16t + 4g + r
+    unsigned long long kv0 = 0ull, kv1 = 0ull;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * t + 4 * lg + r;
+            const bool ok = key < T && (!mk || mk[key]);
+            const int bit = t * 4 + r;
+            if (ok) { if (bit < 64) kv0 |= 1ull << bit; else kv1 |= 1ull << (bit - 64); }
+        }
+    const float sc = a.scale * kLog2e;
+
+    for (int q0 = w * 16; q0 < T; q0 += nw * 16) {
+        const int q = q0 + li;
+        const bool qok = q < T && (!mk || mk[q]);
+        short8_t qf[2], dof[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qf[s] = frag_own(qbase, ld, q0, T, s, lane);
+        // ---- S^T tiles: lane holds column q, rows keys 16t + 4g + r -----------------------------------------
+        float4_t p[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(kimg, t * 16, s, lane), qf[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int bit = t * 4 + r;
+                const bool ok = bit < 64 ? (kv0 >> bit) & 1ull : (kv1 >> (bit - 64)) & 1ull;
+                acc[r] = ok ? acc[r] * sc : -INFINITY;
+                mx = fmaxf(mx, acc[r]);
+            }
+            p[t] = acc;
+        }
+        mx = group_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p[t][r] = exp2f(p[t][r] - mx); sum += p[t][r]; }
+        sum = group_sum(sum);
+        const float inv = (qok && sum > 0.f) ? 1.f / sum : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[t][r] *= inv;
+
+        if (!BWD) {
+            if (a.probs && q < T) {                 // softmax output (B,h,T,T) fp32 for the rollout
+                float* pr = a.probs + (((long)b * a.heads + hh) * T + q) * T;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = 16 * t + 4 * lg + r;
+                        if (key < T) pr[key] = p[t][r];
+                    }
+            }
+            // ---- O^T = V^T P^T -------------------------------------------------------------------------------
+            float4_t o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < NT / 2; ++s2) {
+                const short8_t pf = join(pack4(p[2 * s2][0], p[2 * s2][1], p[2 * s2][2], p[2 * s2][3]),
+                                         pack4(p[2 * s2 + 1][0], p[2 * s2 + 1][1], p[2 * s2 + 1][2], p[2 * s2 + 1][3]));
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(vimg, s2, dt, lane), pf, o[dt], 0, 0, 0);
+            }
+            if (q < T) {
+                bf16_t* orow = a.out + ((long)b * T + q) * D + hh * HD + 4 * lg;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *reinterpret_cast<uint2*>(orow + dt * 16) = pack4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+            }
+        } else {
+            // ---- delta[q] = sum_d dO[q,d] * O[q,d] ; lse[q] ------------------------------------------------------
+            const bf16_t* dobase = a.dout + (long)b * T * D + hh * HD;
+            const bf16_t* obase = a.out_fwd + (long)b * T * D + hh * HD;
+            float dl = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                dof[s] = frag_own(dobase, D, q0, T, s, lane);
+                const short8_t of = frag_own(obase, D, q0, T, s, lane);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl += bf16_to_f32((bf16_t)dof[s][e]) * bf16_to_f32((bf16_t)of[e]);
+            }
+            dl = group_sum(dl);
+            if (lg == 0 && q < T) {
+                const long idx = ((long)b * a.heads + hh) * T + q;
+                a.delta[idx] = dl;
+                // lse in log2 units of the scaled scores; +inf for masked queries so that P == 0 downstream
+                a.lse[idx] = (qok && sum > 0.f) ? mx + log2f(sum) : INFINITY;
+            }
+            // ---- dS^T = P^T * (dP^T - delta) * scale, packed per tile ------------------------------------------
+            uint2 ds[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float4_t dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(vimg, t * 16, s, lane), dof[s], dp, 0, 0, 0);
+                ds[t] = pack4(p[t][0] * (dp[0] - dl) * a.scale, p[t][1] * (dp[1] - dl) * a.scale,
+                              p[t][2] * (dp[2] - dl) * a.scale, p[t][3] * (dp[3] - dl) * a.scale);
+            }
+            // ---- dQ^T = K^T dS^T ----------------------------------------------------------------------------------
+            float4_t dq[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < NT / 2; ++s2) {
+                const short8_t df = join(ds[2 * s2], ds[2 * s2 + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(kimg, s2, dt, lane), df, dq[dt], 0, 0, 0);
+            }
+            if (q < T) {
+                bf16_t* drow = a.dqkv + ((long)b * T + q) * ld + hh * HD + 4 * lg;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *reinterpret_cast<uint2*>(drow + dt * 16) = pack4(dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DKV pass (own = keys; LDS holds the Q and dO images + lse/delta of every query)
+// ---------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Tp = NT * 16;
+    char* qimg = smem;
+    char* doimg = smem + Tp * ROWB;
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * Tp * ROWB);
+    float* dl_s = lse_s + Tp;
+    const int T = a.T, D = a.heads * HD;
+    const int b = blockIdx.x / a.heads, hh = blockIdx.x % a.heads;
+    const long ld = 3L * D;
+    const bf16_t* qbase = a.qkv + (long)b * T * ld + hh * HD;
+    load_image(qimg, qbase, ld, T, Tp);
+    load_image(doimg, a.dout + (long)b * T * D + hh * HD, D, T, Tp);
+    const uint8_t* mk = a.mask ? a.mask + (long)b * T : nullptr;
+    for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
+        const long idx = ((long)b * a.heads + hh) * T + t;
+        const bool ok = t < T && (!mk || mk[t]);
+        lse_s[t] = ok ? a.lse[idx] : INFINITY;
+        dl_s[t] = ok ? a.delta[idx] : 0.f;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const float sc = a.scale * kLog2e;
+
+    for (int k0 = w * 16; k0 < T; k0 += nw * 16) {
+        const int key = k0 + li;
+        const bool kok = key < T && (!mk || mk[key]);
+        short8_t kf[2], vf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            kf[s] = frag_own(qbase + D, ld, k0, T, s, lane);
+            vf[s] = frag_own(qbase + 2 * D, ld, k0, T, s, lane);
+        }
+        float4_t dv[4], dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dv[dt] = float4_t{0.f, 0.f, 0.f, 0.f}; dk[dt] = dv[dt]; }
+#pragma unroll 1
+        for (int u2 = 0; u2 < NT / 2; ++u2) {
+            uint2 pk[2], dsk[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int u = 2 * u2 + half;
+                float4_t s_ = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    s_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(qimg, u * 16, s, lane), kf[s], s_, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(doimg, u * 16, s, lane), vf[s], dp, 0, 0, 0);
+                }
+                float pv[4], dsv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = 16 * u + 4 * lg + r;
+                    const float l = lse_s[qq];
+                    const float pp = kok ? exp2f(s_[r] * sc - l) : 0.f;      // l == +inf -> 0
+                    pv[r] = pp;
+                    dsv[r] = pp * (dp[r] - dl_s[qq]) * a.scale;
+                }
+                pk[half] = pack4(pv[0], pv[1], pv[2], pv[3]);
+                dsk[half] = pack4(dsv[0], dsv[1], dsv[2], dsv[3]);
+            }
+            const short8_t pf = join(pk[0], pk[1]), df = join(dsk[0], dsk[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(doimg, u2, dt, lane), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(qimg, u2, dt, lane), df, dk[dt], 0, 0, 0);
+            }
+        }
+        if (key < T) {
+            bf16_t* krow = a.dqkv + ((long)b * T + key) * ld + D + hh * HD + 4 * lg;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *reinterpret_cast<uint2*>(krow + dt * 16) = pack4(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
+                *reinterpret_cast<uint2*>(krow + D + dt * 16) = pack4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+            }
+        }
+    }
+}
+
+template <typename K>
+int set_lds(K kern, size_t bytes)
+{
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+inline int pick_nt(int T) { return T <= 160 ? 10 : (T <= 224 ? 14 : (T <= 416 ? 26 : 0)); }
+inline int pick_threads(int T) { const int tiles = (T + 15) / 16; return (tiles % 3 == 0) ? 192 : 256; }
+
+template <int NT>
+int launch_all(const AttnArgs& a, int B, int mode, hipStream_t stream)
+{
+    const int threads = pick_threads(a.T);
+    const size_t img = (size_t)2 * NT * 16 * ROWB;
+    const dim3 grid(B * a.heads);
+    int rc;
+    if (mode == 0) {
+        auto k = attn_q_pass_kernel<NT, false>;
+        if ((rc = set_lds(k, img))) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(threads), img, stream, a);
+        EDITOR_LAUNCH_CHECK();
+    } else {
+        auto k1 = attn_q_pass_kernel<NT, true>;
+        if ((rc = set_lds(k1, img))) return rc;
+        hipLaunchKernelGGL(k1, grid, dim3(threads), img, stream, a);
+        EDITOR_LAUNCH_CHECK();
+        auto k2 = attn_kv_pass_kernel<NT>;
+        const size_t lds2 = img + (size_t)2 * NT * 16 * sizeof(float);
+        if ((rc = set_lds(k2, lds2))) return rc;
+        hipLaunchKernelGGL(k2, grid, dim3(threads), lds2, stream, a);
+        EDITOR_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int dispatch(const AttnArgs& a, int B, int mode, hipStream_t stream)
+{
+    switch (pick_nt(a.T)) {
+        case 10: return launch_all<10>(a, B, mode, stream);
+        case 14: return launch_all<14>(a, B, mode, stream);
+        case 26: return launch_all<26>(a, B, mode, stream);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+extern "C" int editor_attention_fwd_bf16(const uint16_t* qkv, int B, int T, int heads, int hd, float scale,
+                                         const uint8_t* mask, uint16_t* out, float* probs, hipStream_t stream)
+{
+    if (hd != HD || T < 1 || B < 1) return (int)hipErrorInvalidValue;
+    AttnArgs a{qkv, nullptr, nullptr, out, nullptr, probs, nullptr, nullptr, mask, T, heads, scale};
+    return dispatch(a, B, 0, stream);
+}
+
+extern "C" int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, int B, int T,
+    int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace, hipStream_t stream)
+{
+    if (hd != HD || T < 1 || B < 1 || !workspace) return (int)hipErrorInvalidValue;
+    const long n = (long)B * heads * T;
+    AttnArgs a{qkv, dout, out, nullptr, dqkv, nullptr, workspace, workspace + n, mask, T, heads, scale};
+    return dispatch(a, B, 1, stream);
+}

@@ -1,0 +1,104 @@
+"""Data-parallel gradient exchange for the EDITOR hot path (kernel row C1).
+
+One process per GPU; the only collective per step is a SUM all-reduce of the trainable gradients
+(reference: DistributedDataParallel(..., find_unused_parameters=True), engine/processor.py:47-50).
+MI355X-first: xGMI is point-to-point, so the payload (475.7 MB fp32) is sent as a few LARGE flat buckets
+(default 64 MiB, far above NCCL-on-NVSwitch's 25 MB habit) launched on RCCL's own stream the moment the
+last gradient of a bucket is produced - the block-granular autograd nodes of editor_amd.functional make
+gradients ready block by block, so the exchange overlaps the remaining backward.
+
+Unused parameters (BACKBONE.base.fc, the head not selected by cfg.MODEL.AL) never produce a gradient; the
+first step discovers the set and order of live parameters instead of traversing the graph every step.
+Works with any backend (`nccl` == RCCL on ROCm, `gloo` in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, module, bucket_bytes=64 << 20, process_group=None):
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.bucket_bytes = bucket_bytes
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self._order = []                 # discovery: params in the order their grads became ready
+        self._seen = set()
+        self._buckets = None             # list of dict(params, flat, pending, handle)
+        self._slot = {}                  # id(param) -> (bucket index)
+        self._handles = []
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    # ------------------------------------------------------------------------------------------
+    def _hook(self, p):
+        if self.world == 1:
+            return
+        if self._buckets is None:
+            if id(p) not in self._seen:
+                self._seen.add(id(p))
+                self._order.append(p)
+            return
+        bi = self._slot.get(id(p))
+        if bi is None:
+            return
+        b = self._buckets[bi]
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        torch._foreach_copy_(b["views"], [p.grad for p in b["params"]])
+        b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._handles.append(b)
+
+    def _build(self):
+        buckets, cur, size = [], [], 0
+        for p in self._order:
+            nbytes = p.numel() * p.element_size()
+            if cur and size + nbytes > self.bucket_bytes:
+                buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            buckets.append(cur)
+        self._buckets = []
+        for bi, ps in enumerate(buckets):
+            flat = torch.empty(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
+            views, off = [], 0
+            for p in ps:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+                self._slot[id(p)] = bi
+            self._buckets.append(dict(params=ps, flat=flat, views=views, pending=len(ps), handle=None))
+
+    # ------------------------------------------------------------------------------------------
+    def finalize(self):
+        """Call after loss.backward(): waits for the in-flight buckets and leaves AVERAGED grads in .grad."""
+        if self.world == 1:
+            return
+        if self._buckets is None:
+            # discovery step: nothing was overlapped; build the buckets and reduce them now
+            self._build()
+            for b in self._buckets:
+                self._launch(b)
+        else:
+            for b in self._buckets:            # a bucket whose params did not all fire (should not happen)
+                if b["pending"] != 0 and b["handle"] is None and b["pending"] < len(b["params"]):
+                    raise RuntimeError("GradReducer: a bucket received only part of its gradients")
+        inv = 1.0 / self.world
+        for b in self._handles:
+            b["handle"].wait()
+            torch._foreach_mul_(b["views"], inv)
+            torch._foreach_copy_([p.grad for p in b["params"]], b["views"])
+            b["handle"] = None
+            b["pending"] = len(b["params"])
+        self._handles = []
+
+    def broadcast_parameters(self, src=0):
+        """Initial sync of parameters and buffers (what DDP's constructor does)."""
+        if self.world == 1:
+            return
+        for t in list(self.module.parameters()) + list(self.module.buffers()):
+            dist.broadcast(t.data, src=src, group=self.group)

@@ -233,5 +233,6 @@ def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, probs=None, out=None):
         ws = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
         call("editor_attention_bwd_f32", qkv, dout, probs, b, t, heads, hd, scale, dqkv, ws)
     else:
-        call("editor_attention_bwd_bf16", qkv, dout, out, b, t, heads, hd, scale, mask, dqkv)
+        ws = torch.empty(2 * b * heads * t, dtype=torch.float32, device=qkv.device)
+        call("editor_attention_bwd_bf16", qkv, dout, out, b, t, heads, hd, scale, mask, dqkv, ws)
     return dqkv

@@ -121,6 +121,14 @@ int editor_attention_fwd_f32(const float* qkv, int B, int T, int heads, int hd, 
 int editor_attention_bwd_f32(const float* qkv, const float* dout, const float* probs, int B, int T, int heads, int hd,
                              float scale, float* dqkv, float* workspace, editor_stream_t stream);
 
+/* Fused bf16 form (hd must be 64; T <= 416).  probs optional (NULL skips the write).  Backward recomputes the
+ * probabilities; `out` is the forward output (for delta = rowsum(dO*O)); workspace: 2*B*heads*T floats. */
+int editor_attention_fwd_bf16(const uint16_t* qkv, int B, int T, int heads, int hd, float scale, const uint8_t* mask,
+                              uint16_t* out, float* probs, editor_stream_t stream);
+int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, int B, int T, int heads,
+                              int hd, float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace,
+                              editor_stream_t stream);
+
 /* ---- bring-up probes (tests only) ------------------------------------------------------------- */
 int editor_probe_tr16(const int* addr, uint16_t* out, editor_stream_t stream);
 int editor_probe_mfma16(const float* A, const float* B, float* D, editor_stream_t stream);

@@ -191,3 +191,39 @@ def test_sfts_apply_and_pool(oracle):
     assert torch.equal(n_.cpu().long(), num.view(-1))
     assert rel_err(out.cpu(), ref.detach()) < 1e-5
     assert rel_err(xg.grad.cpu(), xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (1000, 384, 192), (387 * 4, 768, 768), (129, 128, 64)])
+def test_gemm_bf16_layouts(ops, ta, tb, m, n, k):
+    if ta and m % 8:
+        m = (m // 8) * 8
+    a = torch.randn((k, m) if ta else (m, k), generator=_g(1)).bfloat16()
+    b = torch.randn((k, n) if tb else (n, k), generator=_g(2)).bfloat16()
+    bias = torch.randn(n, generator=_g(3))
+    ref = (a.float().t() if ta else a.float()).double() @ (b.float() if tb else b.float().t()).double()
+    # bf16 output with bias
+    c = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(a.cuda(), b.cuda(), c, m, n, k, a.shape[1], b.shape[1], n, ta, tb, bias=bias.cuda())
+    assert rel_err(c.float().cpu(), ref + bias.double()) < 4e-3
+    # fp32 output, residual accumulate with per-row scale
+    c0 = torch.randn(m, n, generator=_g(4))
+    rs = torch.rand(m, generator=_g(5))
+    c = c0.clone().cuda()
+    ops.gemm(a.cuda(), b.cuda(), c, m, n, k, a.shape[1], b.shape[1], n, ta, tb, alpha=0.5, beta=1.0, bias=bias.cuda(),
+             rowscale=rs.cuda())
+    assert rel_err(c.cpu(), rs.view(-1, 1).double() * (0.5 * ref + bias.double()) + c0.double()) < 1e-5
+    # split-K atomics into fp32
+    c = torch.empty(m, n, device="cuda")
+    ops.gemm(a.cuda(), b.cuda(), c, m, n, k, a.shape[1], b.shape[1], n, ta, tb, splitk=3)
+    assert rel_err(c.cpu(), ref) < 1e-5
+
+
+def test_gemm_bf16_wgrad_shape(ops):
+    """dW = dy^T x at the backbone's real reduction length (M = 3*128*129 token rows)."""
+    m, n, k = 49536, 256, 384
+    dy = (torch.randn(m, n, generator=_g(1)) * 0.1).bfloat16()
+    x = torch.randn(m, k, generator=_g(2)).bfloat16()
+    dw = torch.empty(n, k, device="cuda")
+    ops.gemm(dy.cuda(), x.cuda(), dw, n, k, m, n, k, k, 1, 1, splitk=24)
+    assert rel_err(dw.cpu(), dy.float().t().double() @ x.float().double()) < 1e-4

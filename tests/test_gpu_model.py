@@ -102,3 +102,65 @@ def test_forward_rejects_cpu():
     img, label, cam, view = synth.make_batch(1, 2, 256, 128, cams)
     with pytest.raises(RuntimeError):
         m(img, cam_label=cam)
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16 performance mode: protocol of SURVEY.md 7 - selection agreement is REPORTED (bf16 scores cannot be
+# bit-identical to fp32 ones), features / grads are checked with the reference's selection teacher-forced.
+# Measured bf16-vs-fp32 feature error is ~5e-3 relative (bf16 operand rounding, same as torch's own bf16
+# autocast: 7e-3); the north-star's 1e-3 is met by the f32 parity mode above.
+# ---------------------------------------------------------------------------------------------------
+def test_eval_bf16_teacher_forced():
+    g = load_golden("f3_eval_vitb_256x128")
+    seed, batch = int(g["seed"]), int(g["batch"])
+    m, cfg, c, cams = _model("RGBNT201", seed, "bf16", drop_path=0.0)
+    m.eval()
+    img, label, cam, view = _cuda_batch(*synth.make_batch(seed + 1, batch, 256, 128, cams))
+    with torch.no_grad():
+        m(img, cam_label=cam, view_label=view)
+    aux = m.last_aux
+    assert torch.equal(aux["mask_fre"].cpu().bool(), t(g["mask_fre"]))          # integer path: exact in any mode
+    agree = [(aux["attn_masks"][i].cpu().bool() == t(g["mask_" + n])).float().mean().item()
+             for i, n in enumerate(("rgb", "nir", "tir"))]
+    print("bf16 per-modality attention-mask agreement:", agree)
+    assert min(agree) > 0.95
+    m.teacher_index = t(g["index"])
+    with torch.no_grad():
+        cls4t = m(img, cam_label=cam, view_label=view)
+    err = rel_err(cls4t.cpu(), g["cls4t"])
+    print("bf16 cls4t rel err (teacher-forced):", err)
+    assert err < 2e-2
+
+
+def test_train_bf16_teacher_forced():
+    g = load_golden("f4_train_vitb_al0")
+    seed, batch, inst = int(g["seed"]), int(g["batch"]), int(g["instances"])
+    m, cfg, c, cams = _model("RGBNT100", seed, "bf16", drop_path=0.0)
+    m.train()
+    h, w = cfg.INPUT.SIZE_TRAIN
+    img, label, cam, view = _cuda_batch(*synth.make_batch(seed + 1, batch, h, w, cams, instances=inst))
+    # the golden's selection = what the f32 parity model (== reference) selects
+    mf, _, _, _ = _model("RGBNT100", seed, "f32", drop_path=0.0)
+    mf.eval()
+    with torch.no_grad():
+        mf(img, cam_label=cam, view_label=view)
+    m.teacher_index = mf.last_aux["index"].bool()
+    del mf
+    out = m(img, label=label, cam_label=cam, view_label=view, writer=_Writer(), epoch=1)
+    errs = [rel_err(o.detach().float().cpu(), g["out%d" % i]) for i, o in enumerate(out)]
+    print("bf16 train outputs rel err:", errs)
+    assert max(errs) < 3e-2
+    total = out[-1]
+    for i, o in enumerate(out[:-1]):
+        total = total + (o * synth.uniform(5, "proj/%d" % i, tuple(o.shape)).cuda()).mean()
+    total.backward()
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for key, val in g.items():
+        if key.startswith("g:"):
+            worst = max(worst, rel_err(named[key[2:]].grad.cpu(), val))
+        elif key.startswith("gs:"):
+            gr = named[key[3:]].grad
+            worst = max(worst, rel_err(gr.reshape(gr.shape[0], -1)[:16, :16].cpu(), val))
+    print("bf16 worst gradient rel err:", worst)
+    assert worst < 8e-2
