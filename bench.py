@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""bench.py - tri-modal images/sec, forward+backward+optimizer step, of the EDITOR hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): RGBNT201 cfg, 3 modalities, ViT-B/16, 256x128, B=128 PER GPU
+(weak scaling, SURVEY.md 7 "DDP batch semantics"), bf16 MFMA with fp32 accumulation/residual/grads,
+synthetic seeded uint8-derived images, random-init weights of the real architecture.  A "step" is what
+engine/processor.py:70-107 does per batch minus the host->device copy (inputs are resident in HBM):
+zero_grad -> forward -> loss (pairs + aux) -> backward (+ gradient all-reduce) -> SGD step.
+
+One JSON line on rank 0.  `roofline`: the dominant kernel family (bf16 MFMA GEMM): algorithmic FLOPs of
+every launch in the timed region / their HIP-event durations, against the 2.5 PFLOP/s dense bf16 peak.
+`cpu_baseline`: the oracle (CPU restatement pinned to the reference) timed on this host's cores on a
+bounded sample of the same workload (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+class _Writer:                     # engine/processor.py:42 passes a SummaryWriter into forward
+    def add_scalar(self, tag, value, step=None):
+        self.last = value          # no host sync in the timed region
+
+
+class _GemmProbe:
+    """HIP-event timing of every bf16 GEMM launch (the events are recorded on the launch stream)."""
+
+    def __init__(self):
+        self.records = []
+
+    def install(self):
+        from editor_amd import ops
+        self._orig = ops.gemm
+        probe = self
+
+        def timed(a, b, c, m, n, k, *args, **kw):
+            if a.dtype != torch.bfloat16:
+                return probe._orig(a, b, c, m, n, k, *args, **kw)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            probe._orig(a, b, c, m, n, k, *args, **kw)
+            e1.record()
+            ta = args[3] if len(args) > 3 else kw.get("trans_a", 0)
+            tb = args[4] if len(args) > 4 else kw.get("trans_b", 0)
+            probe.records.append((2.0 * m * n * k, e0, e1, "fwd" if not ta and not tb else ("dgrad" if not ta else "wgrad")))
+        ops.gemm = timed
+        import editor_amd.functional as fn
+        fn.ops.gemm = timed
+
+    def remove(self):
+        from editor_amd import ops
+        ops.gemm = self._orig
+
+    def summary(self):
+        tot_f = tot_ms = 0.0
+        kinds = {}
+        for flops, e0, e1, kind in self.records:
+            ms = e0.elapsed_time(e1)
+            tot_f += flops
+            tot_ms += ms
+            kf, km, kn = kinds.get(kind, (0.0, 0.0, 0))
+            kinds[kind] = (kf + flops, km + ms, kn + 1)
+        return tot_f, tot_ms, len(self.records), kinds
+
+
+def _usable_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota (a container that
+    reports 256 logical CPUs but is throttled to a few thrashes when handed 256 threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))          # the oracle's per-op parallelism saturates well below 32 threads
+
+
+def cpu_baseline(model, cfg, cams, sample_b=4):
+    """Oracle (oracle/editor_ref.py) fwd+bwd on the host cores on a bounded sample of the workload."""
+    from oracle import editor_ref as oracle
+    from editor_amd import synth
+    cores = _usable_cores()
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "centers" not in k and "running" not in k and not k.startswith("FREQ"):
+            v.requires_grad_(True)
+    h, w = cfg.INPUT.SIZE_TRAIN
+
+    def run(b):
+        img, label, cam, view = synth.make_batch(1111, b, h, w, cams, instances=min(16, b // 2))
+        t0 = time.perf_counter()
+        out = oracle.editor_forward(sd, img, cam, label=label, training=True, al=cfg.MODEL.AL)
+        oracle.projection_loss(out).backward()
+        return time.perf_counter() - t0
+
+    run(2)                                          # allocator / page-fault warm-up, untimed
+    dt = run(sample_b)
+    return {"value": round(sample_b / dt, 4), "unit": "tri-modal images/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle fwd+bwd, fp32, B={sample_b} tri-modal 256x128 ViT-B/16, 1 timed iteration "
+                      f"({dt:.1f} s) after a B=2 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE: 128)")
+    ap.add_argument("--preset", default="RGBNT201")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+
+    from editor_amd import config, losses, synth
+    from editor_amd.ddp import GradReducer
+    from editor_amd.modeling import make_model
+
+    cfg, num_class, cams = config.preset(args.preset, compute_dtype=args.dtype, drop_path=0.1)
+    torch.manual_seed(1111)                                       # SOLVER.SEED (config/defaults.py:138)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = make_model(cfg, num_class, cams)
+    synth.fill_state_dict_(model.state_dict(), 1111)
+    model = model.to(dev).train()
+    reducer = GradReducer(model)
+    reducer.broadcast_parameters()
+
+    # solver/make_optimizer.py:4-29: SGD, momentum 0.9, wd 1e-4, bias lr x2 (BASE_LR 0.001)
+    groups = []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        lr, wd = 1e-3, 1e-4
+        if "bias" in name:
+            lr, wd = 2e-3, 1e-4
+        groups.append({"params": [p], "lr": lr, "weight_decay": wd})
+    opt = torch.optim.SGD(groups, momentum=0.9, foreach=True)
+
+    h, w = cfg.INPUT.SIZE_TRAIN
+    b = args.batch
+    img, label, cam, view = synth.make_batch(1111 + rank, b, h, w, cams, instances=16)
+    img = {k: v.to(dev) for k, v in img.items()}
+    label, cam, view = label.to(dev), cam.to(dev), view.to(dev)
+    writer = _Writer()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(img, label=label, cam_label=cam, view_label=view, img_path=None, writer=writer, epoch=1)
+        loss = losses.loss_pairs(out, label)
+        loss.backward()
+        reducer.finalize()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    probe = _GemmProbe()
+    probe.install()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    probe.remove()
+    lossv = float(loss.detach())
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        flops, ms, launches, kinds = probe.summary()
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        ms_step = 1e3 * elapsed / args.steps
+        out = {
+            "metric": "tri-modal images/sec fwd+bwd @ B=128 ViT-B",
+            "value": round(world * b * args.steps / elapsed, 2),
+            "unit": "tri-modal images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.preset} 3-modal ViT-B/16 {h}x{w}, batch {b}/GPU, fwd+bwd+SGD step, "
+                                   f"drop_path 0.1, SFTS+HMA HIP kernels",
+                       "global_batch": world * b, "parallelism": f"dp{world}", "loss": round(lossv, 4)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "kernel": "gemm_bf16_kernel (128x128x64, v_mfma_f32_16x16x32_bf16)",
+                         "launches_per_step": launches // max(args.steps, 1),
+                         "gemm_ms_per_step": round(ms / max(args.steps, 1), 3),
+                         "by_kind": {k: {"tflops": round(f / (m_ * 1e-3) / 1e12, 1), "ms_per_step": round(m_ / args.steps, 3),
+                                         "launches": n // args.steps}
+                                     for k, (f, m_, n) in kinds.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, cfg, cams)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

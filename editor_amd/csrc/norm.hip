@@ -212,6 +212,20 @@ __global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, lon
         Vec4<TO>::st(out + i * 4, Vec4<TI>::ld(in + i * 4));
 }
 
+// out[m,:] = in[m,:] * rowscale[m]  (fp32 -> activation dtype): gradient of a drop-path-scaled branch
+template <typename TO>
+__global__ void cast_rows_kernel(const float* __restrict__ in, const float* __restrict__ rowscale, long M, int D,
+                                 TO* __restrict__ out)
+{
+    const int d4 = D >> 2;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < M * d4; e += (long)gridDim.x * blockDim.x) {
+        const float r = rowscale ? rowscale[e / d4] : 1.f;
+        float4 v = *reinterpret_cast<const float4*>(in + e * 4);
+        v.x *= r; v.y *= r; v.z *= r; v.w *= r;
+        Vec4<TO>::st(out + e * 4, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Patch embedding glue.  im2col of non-overlapping 16x16 patches: row (b*N+p), col (c*256 + i*16 + j)
 // == Conv2d(k=16,s=16) weight layout (768,3,16,16) flattened (vit_pytorch.py:438,455-457).
@@ -287,19 +301,37 @@ __global__ void embed_bwd_pos_kernel(const float* __restrict__ dx, long Btot, in
     }
     *reinterpret_cast<float4*>(dpos + (long)tk * D + c0) = a;
 }
-// dsie[c,:] = coef * sum_{b: cam[b%Bcam]==c} sum_t dx[b,t,:]    grid (ncam, ceil(D/1024))
-__global__ void embed_bwd_sie_kernel(const float* __restrict__ dx, const long* __restrict__ cam, int Bcam, long Btot,
-                                     int Tn, int D, float coef, float* __restrict__ dsie)
+// rowsum[b,:] = sum_t dx[b,t,:]      grid (Btot, ceil(D/1024))
+__global__ void embed_bwd_rowsum_kernel(const float* __restrict__ dx, int Tn, int D, float* __restrict__ rowsum)
+{
+    const long b = blockIdx.x;
+    const int c0 = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (c0 >= D) return;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a;
+    int tk = 0;
+    for (; tk + 1 < Tn; tk += 2) {
+        const float4 v = *reinterpret_cast<const float4*>(dx + (b * Tn + tk) * D + c0);
+        const float4 u = *reinterpret_cast<const float4*>(dx + (b * Tn + tk + 1) * D + c0);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        a2.x += u.x; a2.y += u.y; a2.z += u.z; a2.w += u.w;
+    }
+    if (tk < Tn) {
+        const float4 v = *reinterpret_cast<const float4*>(dx + (b * Tn + tk) * D + c0);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(rowsum + b * D + c0) = make_float4(a.x + a2.x, a.y + a2.y, a.z + a2.z, a.w + a2.w);
+}
+// dsie[c,:] = coef * sum_{b: cam[b%Bcam]==c} rowsum[b,:]    grid (ncam, ceil(D/1024))
+__global__ void embed_bwd_sie_kernel(const float* __restrict__ rowsum, const long* __restrict__ cam, int Bcam, long Btot,
+                                     int D, float coef, float* __restrict__ dsie)
 {
     const int c = blockIdx.x, c0 = (blockIdx.y * 256 + threadIdx.x) * 4;
     if (c0 >= D) return;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long b = 0; b < Btot; ++b) {
         if (cam[b % Bcam] != c) continue;
-        for (int tk = 0; tk < Tn; ++tk) {
-            const float4 v = *reinterpret_cast<const float4*>(dx + (b * Tn + tk) * D + c0);
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-        }
+        const float4 v = *reinterpret_cast<const float4*>(rowsum + b * D + c0);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
     *reinterpret_cast<float4*>(dsie + (long)c * D + c0) = make_float4(coef * a.x, coef * a.y, coef * a.z, coef * a.w);
 }
@@ -532,6 +564,16 @@ extern "C" int editor_cast_bf16_to_f32(const uint16_t* in, float* out, long n, h
     return 0;
 }
 
+extern "C" int editor_cast_rows(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16,
+                                hipStream_t stream)
+{
+    if (D % 4) return (int)hipErrorInvalidValue;
+    DISPATCH_T(out_bf16, hipLaunchKernelGGL(cast_rows_kernel<TT>, dim3(grid_for(M * (D / 4))), dim3(256), 0, stream,
+               in, rowscale, M, D, (TT*)out));
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int editor_im2col16(const float* img, int B, int C, int H, int W, void* out, int out_bf16, hipStream_t stream)
 {
     if ((H & 15) || (W & 15)) return (int)hipErrorInvalidValue;
@@ -553,7 +595,7 @@ extern "C" int editor_embed_assemble(const void* patch, int patch_bf16, const fl
 }
 
 extern "C" int editor_embed_assemble_bwd(const float* dx, const long* cam, int Bcam, int ncam, float coef, long Btot,
-    int T, int D, void* dpatch, int dpatch_bf16, float* dpos, float* dsie, hipStream_t stream)
+    int T, int D, void* dpatch, int dpatch_bf16, float* dpos, float* dsie, float* workspace, hipStream_t stream)
 {
     if (D % 4) return (int)hipErrorInvalidValue;
     const long total = Btot * (T - 1) * (D / 4);
@@ -563,8 +605,12 @@ extern "C" int editor_embed_assemble_bwd(const float* dx, const long* cam, int B
     hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(T, (D + 1023) / 1024), dim3(256), 0, stream, dx, Btot, T, D, dpos);
     EDITOR_LAUNCH_CHECK();
     if (dsie) {
-        hipLaunchKernelGGL(embed_bwd_sie_kernel, dim3(ncam, (D + 1023) / 1024), dim3(256), 0, stream, dx, cam, Bcam, Btot,
-                           T, D, coef, dsie);
+        if (!workspace) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL(embed_bwd_rowsum_kernel, dim3((unsigned)Btot, (D + 1023) / 1024), dim3(256), 0, stream, dx, T, D,
+                           workspace);
+        EDITOR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(embed_bwd_sie_kernel, dim3(ncam, (D + 1023) / 1024), dim3(256), 0, stream, workspace, cam, Bcam,
+                           Btot, D, coef, dsie);
         EDITOR_LAUNCH_CHECK();
     }
     return 0;

@@ -115,9 +115,9 @@ class TransformerBlockFn(torch.autograd.Function):
 
 
 def _scaled_cast(dx, rowscale, dtype):
-    if rowscale is not None:
-        dx = dx * rowscale.view(-1, 1)        # rare path (DROP_PATH > 0): plain elementwise scale
-    return ops.cast(dx, dtype)
+    if rowscale is None and dx.dtype == dtype:
+        return dx
+    return ops.cast_rows(dx, rowscale, dtype)
 
 
 class PatchEmbedFn(torch.autograd.Function):

@@ -138,6 +138,14 @@ def cast(x, dtype):
     return out
 
 
+def cast_rows(x2d, rowscale, dtype):
+    """x * rowscale[:, None] cast to `dtype` (one pass)."""
+    m, d = x2d.shape
+    out = torch.empty(m, d, dtype=dtype, device=x2d.device)
+    call("editor_cast_rows", x2d, rowscale, m, d, out, _is_bf16(out))
+    return out
+
+
 def im2col16(img, dtype):
     b, c, h, w = img.shape
     out = torch.empty(b * (h // 16) * (w // 16), c * 256, dtype=dtype, device=img.device)
@@ -157,8 +165,9 @@ def embed_assemble_bwd(dx, cam, ncam, coef, dtype):
     dpatch = torch.empty(btot * (t - 1), d, dtype=dtype, device=dx.device)
     dpos = torch.empty(t, d, dtype=torch.float32, device=dx.device)
     dsie = torch.empty(ncam, d, dtype=torch.float32, device=dx.device) if ncam else None
+    ws = workspace(dx.device, btot * d) if ncam else None
     call("editor_embed_assemble_bwd", dx, cam, 0 if cam is None else cam.numel(), int(ncam), float(coef), btot, t, d,
-         dpatch, _is_bf16(dpatch), dpos, dsie)
+         dpatch, _is_bf16(dpatch), dpos, dsie, ws)
     return dpatch, dpos, dsie
 
 

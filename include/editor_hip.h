@@ -70,6 +70,10 @@ int editor_reduce_rows(const float* partials, int P, long ncol, float* out, int 
 int editor_gelu_fwd(const void* a, void* g, long n, int bf16, editor_stream_t stream);
 int editor_gelu_bwd(const void* a, const void* dg, void* da, long n, int bf16, editor_stream_t stream);
 int editor_cast_f32_to_bf16(const float* in, uint16_t* out, long n, editor_stream_t stream);
+/* out[m,:] = in[m,:] * rowscale[m] (rowscale may be NULL): fp32 gradient -> GEMM operand dtype, with the
+ * per-sample drop-path factor keep/keep_prob of vit_pytorch.py:52-69 folded in. */
+int editor_cast_rows(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16,
+                     editor_stream_t stream);
 int editor_cast_bf16_to_f32(const uint16_t* in, float* out, long n, editor_stream_t stream);
 
 /* PatchEmbed_overlap with stride == patch == 16 (vit_pytorch.py:449-458): im2col rows (b*N+p), cols (c,i,j). */
@@ -80,7 +84,8 @@ int editor_embed_assemble(const void* patch, int patch_bf16, const float* cls, c
                           const long* cam, int Bcam, float coef, long Btot, int T, int D, float* x,
                           editor_stream_t stream);
 int editor_embed_assemble_bwd(const float* dx, const long* cam, int Bcam, int ncam, float coef, long Btot, int T, int D,
-                              void* dpatch, int dpatch_bf16, float* dpos, float* dsie, editor_stream_t stream);
+                              void* dpatch, int dpatch_bf16, float* dpos, float* dsie, float* workspace /* Btot*D */,
+                              editor_stream_t stream);
 
 /* SFTS.forward mask application + BCC loss (SFTS.py:208-225).  feat/out: (nmod,B,T,D) fp32; index (B,T-1) uint8;
  * loss (1) fp32 or NULL (eval); workspace: ws_len floats. */

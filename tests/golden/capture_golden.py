@@ -167,3 +167,20 @@ if __name__ == "__main__":
         f4_f5_train("RGBNT100", 33, 16, 8, "vitb_al0")
     if "f6" in which:
         f6_blocks()
+
+
+def state_dict_keys():
+    """tests/golden/state_dict_keys.json: the reference's state-dict keys/shapes + trainable names
+    (the checkpoint / optimizer-group compatibility contract)."""
+    import json
+    out = {}
+    for preset in ("RGBNT201", "RGBNT100", "MSVR310"):
+        cfg, c, cams = config.preset(preset)
+        m = ref_shims.build_reference_model(cfg, c, cams)
+        out[preset] = {k: list(v.shape) for k, v in m.state_dict().items()}
+        out[preset + ":trainable"] = sorted(n for n, p in m.named_parameters() if p.requires_grad)
+    json.dump(out, open(os.path.join(OUT, "state_dict_keys.json"), "w"), indent=0)
+
+
+if __name__ == "__main__" and "keys" in sys.argv[1:]:
+    state_dict_keys()
