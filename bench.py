@@ -157,14 +157,11 @@ def main():
     reducer.broadcast_parameters()
 
     # solver/make_optimizer.py:4-29: SGD, momentum 0.9, wd 1e-4, bias lr x2 (BASE_LR 0.001)
-    groups = []
+    decay, bias = [], []
     for name, p in model.named_parameters():
-        if not p.requires_grad:
-            continue
-        lr, wd = 1e-3, 1e-4
-        if "bias" in name:
-            lr, wd = 2e-3, 1e-4
-        groups.append({"params": [p], "lr": lr, "weight_decay": wd})
+        if p.requires_grad:
+            (bias if "bias" in name else decay).append(p)
+    groups = [{"params": decay, "lr": 1e-3, "weight_decay": 1e-4}, {"params": bias, "lr": 2e-3, "weight_decay": 1e-4}]
     opt = torch.optim.SGD(groups, momentum=0.9, foreach=True)
 
     h, w = cfg.INPUT.SIZE_TRAIN

@@ -85,7 +85,7 @@ extern "C" int editor_attention_fwd_f32(const float* qkv, int B, int T, int head
     // S[b,h] = scale * Q K^T       Q rows at qkv + h*hd, K rows at qkv + D + h*hd, row stride 3D
     int rc = editor_gemm_f32(qkv, qkv + D, probs, T, T, hd, 3L * D, 3L * D, T, 0, 0,
                              B, (long)T * 3 * D, (long)T * 3 * D, heads * TT, heads, hd, hd, TT,
-                             scale, 0.f, nullptr, nullptr, 1, stream);
+                             scale, 0.f, nullptr, nullptr, 1, EDITOR_EPI_NONE, nullptr, 0, stream);
     if (rc) return rc;
     const long rows = (long)B * heads * T;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, probs, rows, T, heads, mask);
@@ -93,7 +93,7 @@ extern "C" int editor_attention_fwd_f32(const float* qkv, int B, int T, int head
     // O[b,:,h] = P V               V stored [key][hd] -> transB = 1
     return editor_gemm_f32(probs, qkv + 2 * D, out, T, hd, T, T, 3L * D, D, 0, 1,
                            B, heads * TT, (long)T * 3 * D, (long)T * D, heads, TT, hd, hd,
-                           1.f, 0.f, nullptr, nullptr, 1, stream);
+                           1.f, 0.f, nullptr, nullptr, 1, EDITOR_EPI_NONE, nullptr, 0, stream);
 }
 
 extern "C" int editor_attention_bwd_f32(const float* qkv, const float* dout, const float* probs, int B, int T, int heads,
@@ -104,20 +104,20 @@ extern "C" int editor_attention_bwd_f32(const float* qkv, const float* dout, con
     const long sq = (long)T * 3 * D;
     // dV = P^T dO
     int rc = editor_gemm_f32(probs, dout, dqkv + 2 * D, T, hd, T, T, D, 3L * D, 1, 1,
-                             B, heads * TT, (long)T * D, sq, heads, TT, hd, hd, 1.f, 0.f, nullptr, nullptr, 1, stream);
+                             B, heads * TT, (long)T * D, sq, heads, TT, hd, hd, 1.f, 0.f, nullptr, nullptr, 1, EDITOR_EPI_NONE, nullptr, 0, stream);
     if (rc) return rc;
     // dP = dO V^T   (V stored [key][hd] = [N][K] -> transB = 0)
     rc = editor_gemm_f32(dout, qkv + 2 * D, workspace, T, T, hd, D, 3L * D, T, 0, 0,
-                         B, (long)T * D, sq, heads * TT, heads, hd, hd, TT, 1.f, 0.f, nullptr, nullptr, 1, stream);
+                         B, (long)T * D, sq, heads * TT, heads, hd, hd, TT, 1.f, 0.f, nullptr, nullptr, 1, EDITOR_EPI_NONE, nullptr, 0, stream);
     if (rc) return rc;
     const long rows = (long)B * heads * T;
     hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, probs, workspace, rows, T);
     EDITOR_LAUNCH_CHECK();
     // dQ = scale * dS K     (K stored [key][hd] = [K][N] -> transB = 1)
     rc = editor_gemm_f32(workspace, qkv + D, dqkv, T, hd, T, T, 3L * D, 3L * D, 0, 1,
-                         B, heads * TT, sq, sq, heads, TT, hd, hd, scale, 0.f, nullptr, nullptr, 1, stream);
+                         B, heads * TT, sq, sq, heads, TT, hd, hd, scale, 0.f, nullptr, nullptr, 1, EDITOR_EPI_NONE, nullptr, 0, stream);
     if (rc) return rc;
     // dK = scale * dS^T Q
     return editor_gemm_f32(workspace, qkv, dqkv + D, T, hd, T, T, 3L * D, 3L * D, 1, 1,
-                           B, heads * TT, sq, sq, heads, TT, hd, hd, scale, 0.f, nullptr, nullptr, 1, stream);
+                           B, heads * TT, sq, sq, heads, TT, hd, hd, scale, 0.f, nullptr, nullptr, 1, EDITOR_EPI_NONE, nullptr, 0, stream);
 }

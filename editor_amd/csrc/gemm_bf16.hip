@@ -34,7 +34,13 @@ struct GemmB16Args {
     float alpha, beta;
     const float* bias; const float* rowscale;
     int splitk, tiles_m, tiles_n;
+    int epilogue; void* aux; long ldaux;     // EDITOR_EPI_* (editor_hip.h)
 };
+
+__device__ __forceinline__ float gelu_f(float a) { return 0.5f * a * (1.f + erff(a * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float a) {
+    return 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.3989422804014327f * __expf(-0.5f * a * a);
+}
 
 // ---- LDS images -------------------------------------------------------------------------------------
 // k-major tile  [128 rows][64 k]  : byte = row*128 + ((chunk ^ (row&7)) * 16), chunk = k/8
@@ -185,6 +191,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB16Args g)
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             }
             v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
+            if (g.epilogue == EDITOR_EPI_RESIDUAL) {          // C = v + aux (fp32 residual stream)
+                const float4 o = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + (long)m * g.ldaux + n);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            } else if (g.epilogue == EDITOR_EPI_GELU) {       // aux = v (pre-activation, bf16), C = gelu(v)
+                uint2 pre; pre.x = pack_bf16x2(v.x, v.y); pre.y = pack_bf16x2(v.z, v.w);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = pre;
+                v.x = gelu_f(__uint_as_float(pre.x << 16)); v.y = gelu_f(__uint_as_float(pre.x & 0xffff0000u));
+                v.z = gelu_f(__uint_as_float(pre.y << 16)); v.w = gelu_f(__uint_as_float(pre.y & 0xffff0000u));
+            } else if (g.epilogue == EDITOR_EPI_GELU_BWD) {   // C = v * gelu'(aux), aux = saved pre-activation
+                const uint2 pre = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ldaux + n);
+                v.x *= gelu_grad_f(__uint_as_float(pre.x << 16)); v.y *= gelu_grad_f(__uint_as_float(pre.x & 0xffff0000u));
+                v.z *= gelu_grad_f(__uint_as_float(pre.y << 16)); v.w *= gelu_grad_f(__uint_as_float(pre.y & 0xffff0000u));
+            }
             if (C_F32) {
                 float* c = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n;
                 if (g.splitk > 1) {
@@ -237,8 +256,9 @@ int launch(const GemmB16Args& g, hipStream_t stream)
 
 extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda,
     long ldb, long ldc, int transA, int transB, float alpha, float beta, const float* bias, const float* rowscale,
-    int splitk, hipStream_t stream)
+    int splitk, int epilogue, void* aux, long ldaux, hipStream_t stream)
 {
+    if (epilogue != EDITOR_EPI_NONE && (!aux || (ldaux & 3) || splitk > 1)) return (int)hipErrorInvalidValue;
     if (M <= 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
     // 16-byte vector accesses: leading dimensions and the contiguous extents must be multiples of 8 bf16
     if ((lda & 7) || (ldb & 7) || (N & 3) || (ldc & 3)) return (int)hipErrorInvalidValue;
@@ -260,7 +280,7 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
         }
     }
     GemmB16Args g{(const bf16_t*)A, (const bf16_t*)B, C, M, N, K, lda, ldb, ldc, alpha, beta, bias, rowscale, splitk,
-                  (M + BM - 1) / BM, (N + BN - 1) / BN};
+                  (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux};
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
     switch (sel) {
         case 7: return launch<true, true, true>(g, stream);

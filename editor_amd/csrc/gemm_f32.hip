@@ -22,7 +22,13 @@ struct GemmArgs {
     float alpha, beta;
     const float* bias; const float* rowscale;
     int splitk;
+    int epilogue; float* aux; long ldaux;
 };
+
+__device__ __forceinline__ float gelu_f(float a) { return 0.5f * a * (1.f + erff(a * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float a) {
+    return 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.3989422804014327f * __expf(-0.5f * a * a);
+}
 
 // stage a (rows x BK) tile of a row-major operand P[r][k] (ld) or its transpose P[k][r] into S[k][r]
 __device__ __forceinline__ void stage_tile(const float* __restrict__ P, long ld, int trans, int r0, int k0, int R, int K,
@@ -127,6 +133,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
                 float v = g.alpha * acc[i][j][r];
                 if (g.bias && split == 0) v += g.bias[n];
                 if (g.rowscale) v *= g.rowscale[m];
+                if (g.epilogue == EDITOR_EPI_RESIDUAL) v += g.aux[(long)m * g.ldaux + n];
+                else if (g.epilogue == EDITOR_EPI_GELU) { g.aux[(long)m * g.ldaux + n] = v; v = gelu_f(v); }
+                else if (g.epilogue == EDITOR_EPI_GELU_BWD) v *= gelu_grad_f(g.aux[(long)m * g.ldaux + n]);
                 float* c = C + (long)m * g.ldc + n;
                 if (g.splitk > 1) atomicAdd(c, v);
                 else *c = g.beta != 0.f ? v + g.beta * *c : v;
@@ -145,8 +154,10 @@ __global__ void scale_inplace_kernel(float* C, long rows, int cols, long ld, flo
 
 extern "C" int editor_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb,
     long ldc, int transA, int transB, int batch1, long sA1, long sB1, long sC1, int batch2, long sA2, long sB2, long sC2,
-    float alpha, float beta, const float* bias, const float* rowscale, int splitk, hipStream_t stream)
+    float alpha, float beta, const float* bias, const float* rowscale, int splitk, int epilogue, float* aux, long ldaux,
+    hipStream_t stream)
 {
+    if (epilogue != EDITOR_EPI_NONE && (!aux || splitk > 1 || batch1 * batch2 != 1)) return (int)hipErrorInvalidValue;
     if (M <= 0 || N <= 0 || K <= 0 || batch1 < 1 || batch2 < 1) return (int)hipErrorInvalidValue;
     if (splitk < 1) splitk = 1;
     const int ktiles = (K + BK - 1) / BK;
@@ -165,7 +176,7 @@ extern "C" int editor_gemm_f32(const float* A, const float* B, float* C, int M, 
             }
     }
     GemmArgs g{A, B, C, M, N, K, lda, ldb, ldc, transA, transB, batch2, sA1, sB1, sC1, sA2, sB2, sC2,
-               alpha, beta, bias, rowscale, splitk};
+               alpha, beta, bias, rowscale, splitk, epilogue, aux, ldaux};
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch1 * batch2 * splitk);
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, g);
     EDITOR_LAUNCH_CHECK();

@@ -144,38 +144,57 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
 }
 
-// out[c] (+)= sum_p partials[p][c]
-__global__ void reduce_rows_kernel(const float* __restrict__ partials, int P, long ncol, float* __restrict__ out,
-                                   int accumulate, float scale)
+// out[c] (+)= scale * sum_p partials[p][c].   Block = 64 columns x 4 row-groups (deterministic order).
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partials, int P, long ncol,
+                                                          float* __restrict__ out, int accumulate, float scale)
 {
-    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncol) return;
-    float s0 = 0.f, s1 = 0.f;
-    int p = 0;
-    for (; p + 1 < P; p += 2) { s0 += partials[(long)p * ncol + c]; s1 += partials[(long)(p + 1) * ncol + c]; }
-    if (p < P) s0 += partials[(long)p * ncol + c];
-    const float s = (s0 + s1) * scale;
-    out[c] = accumulate ? out[c] + s : s;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const long c = (long)blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < ncol) {
+        int p = rg;
+        for (; p + 12 < P; p += 16) {
+            s0 += partials[(long)p * ncol + c];        s1 += partials[(long)(p + 4) * ncol + c];
+            s2 += partials[(long)(p + 8) * ncol + c];  s3 += partials[(long)(p + 12) * ncol + c];
+        }
+        for (; p < P; p += 4) s0 += partials[(long)p * ncol + c];
+    }
+    red[rg][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && c < ncol) {
+        const float s = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * scale;
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
-// column sums of a (M,N) activation-gradient matrix -> partials [gridDim.y][N]  (bias gradients)
+// column sums of a (M,N) activation-gradient matrix -> partials [gridDim.y][N]  (bias gradients).
+// Block = 256 columns (64 lanes x 4) x 4 row-groups; grid.y row chunks of `rows_per` rows.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, long M, int N, long ld,
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, long M, int N, long ld, int rows_per,
                                                      float* __restrict__ partials)
 {
-    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c0 >= N) return;
-    const long rows_per = (M + gridDim.y - 1) / gridDim.y;
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + lane) * 4;
     const long r0 = (long)blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    long r = r0;
-    for (; r + 1 < r1; r += 2) {
-        const float4 u = Vec4<T>::ld(dy + r * ld + c0), v = Vec4<T>::ld(dy + (r + 1) * ld + c0);
-        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
-        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    if (c0 < N) {
+        long r = r0 + rg;
+        for (; r + 4 < r1; r += 8) {
+            const float4 u = Vec4<T>::ld(dy + r * ld + c0), v = Vec4<T>::ld(dy + (r + 4) * ld + c0);
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+        }
+        if (r < r1) { const float4 u = Vec4<T>::ld(dy + r * ld + c0); a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
     }
-    if (r < r1) { const float4 u = Vec4<T>::ld(dy + r * ld + c0); a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
-    *reinterpret_cast<float4*>(partials + (long)blockIdx.y * N + c0) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    red[rg][lane] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    __syncthreads();
+    if (rg == 0 && c0 < N) {
+        const float4 p = red[0][lane], q = red[1][lane], r = red[2][lane], t = red[3][lane];
+        *reinterpret_cast<float4*>(partials + (long)blockIdx.y * N + c0) =
+            make_float4((p.x + q.x) + (r.x + t.x), (p.y + q.y) + (r.y + t.y), (p.z + q.z) + (r.z + t.z), (p.w + q.w) + (r.w + t.w));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -498,7 +517,7 @@ extern "C" int editor_layernorm_bwd(const void* dy, int dy_bf16, const float* x,
     EDITOR_LAUNCH_CHECK();
     if (dgamma) {
         // workspace rows are [block][2][D]: treat as P rows of 2D columns, then split
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, stream, workspace, (int)blocks,
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, stream, workspace, (int)blocks,
                            (long)2 * D, workspace + (long)ws_rows * 2 * D, 0, 1.f);
         EDITOR_LAUNCH_CHECK();
         hipError_t e = hipMemcpyAsync(dgamma, workspace + (long)ws_rows * 2 * D, sizeof(float) * D, hipMemcpyDeviceToDevice, stream);
@@ -513,13 +532,13 @@ extern "C" int editor_colsum(const void* dy, int dy_bf16, long M, int N, long ld
                              int ws_rows, hipStream_t stream)
 {
     if (N % 4 || ws_rows < 1) return (int)hipErrorInvalidValue;
-    int gy = (int)((M + 255) / 256);
-    if (gy > ws_rows) gy = ws_rows;
-    if (gy < 1) gy = 1;
-    DISPATCH_T(dy_bf16, hipLaunchKernelGGL(colsum_kernel<TT>, dim3((N / 4 + 255) / 256, gy), dim3(256), 0, stream,
-               (const TT*)dy, M, N, ld, workspace));
+    int rows_per = 64;                                   // 16 rows per wave-group pass x 4
+    while ((M + rows_per - 1) / rows_per > ws_rows) rows_per *= 2;
+    const int gy = (int)((M + rows_per - 1) / rows_per);
+    DISPATCH_T(dy_bf16, hipLaunchKernelGGL(colsum_kernel<TT>, dim3((N / 4 + 63) / 64, gy), dim3(256), 0, stream,
+               (const TT*)dy, M, N, ld, rows_per, workspace));
     EDITOR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, workspace, gy, (long)N, out, 0, 1.f);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, workspace, gy, (long)N, out, 0, 1.f);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }
@@ -527,7 +546,7 @@ extern "C" int editor_colsum(const void* dy, int dy_bf16, long M, int N, long ld
 extern "C" int editor_reduce_rows(const float* partials, int P, long ncol, float* out, int accumulate, float scale,
                                   hipStream_t stream)
 {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, stream, partials, P, ncol,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((ncol + 63) / 64)), dim3(256), 0, stream, partials, P, ncol,
                        out, accumulate, scale);
     EDITOR_LAUNCH_CHECK();
     return 0;
@@ -627,7 +646,7 @@ extern "C" int editor_sfts_apply(const float* feat, const uint8_t* index, int nm
                        loss ? workspace : nullptr);
     EDITOR_LAUNCH_CHECK();
     if (loss) {   // MSELoss mean over B*(T-1)*D elements, summed over modality pairs (SFTS.py:221)
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, stream, workspace, (int)g, 1L, loss, 0,
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, workspace, (int)g, 1L, loss, 0,
                            1.f / ((float)B * (T - 1) * D));
         EDITOR_LAUNCH_CHECK();
     }

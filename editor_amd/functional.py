@@ -38,20 +38,26 @@ def _linear_fwd(x2d, w_act, bias, out_dtype):
     return y
 
 
-def _linear_bwd(dy, x2d, w_act, need_bias, splitk):
-    """dx = dy W ; dW = dy^T x (fp32) ; db = colsum(dy)."""
+def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None):
+    """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy)."""
     m, n = dy.shape
     k = x2d.shape[1]
     dx = torch.empty(m, k, dtype=x2d.dtype, device=dy.device)
-    ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1)                       # B stored (Kred=n, Nout=k)
+    if gelu_pre is None:
+        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1)                   # B stored (Kred=n, Nout=k)
+    else:
+        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=gelu_pre)
     dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
-    ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, splitk=splitk)          # both stored (Kred=m, .)
+    ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, splitk=_splitk_for(n, k, m))   # both stored (Kred=m, .)
     db = ops.colsum(dy) if need_bias else None
     return dx, dw, db
 
 
-def _splitk_for(m):
-    return max(1, min(64, m // 2048))
+def _splitk_for(n_out, k_out, m_red):
+    """wgrad has few output tiles and a long reduction: split the reduction so that about one full wave of
+    workgroups (2 per CU x 256 CUs) is resident, and no more (every split adds a pass of fp32 atomics)."""
+    tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
+    return max(1, min(512 // max(tiles, 1), m_red // 512))
 
 
 class TransformerBlockFn(torch.autograd.Function):
@@ -74,14 +80,17 @@ class TransformerBlockFn(torch.autograd.Function):
         h1, mean1, rstd1 = ops.layernorm_fwd(x2d, n1w, n1b, eps, act_dtype, mask, 0)
         qkv = _linear_fwd(h1, wq, qkvb, act_dtype)
         ao, probs = ops.attention_fwd(qkv, b, t, heads, hd, mask, probs_out)
-        x1 = x2d.clone()
-        ops.gemm(ao, wp, x1, m, d, d, d, d, d, 0, 0, beta=1.0, bias=projb, rowscale=rowscale_attn)
+        x1 = torch.empty_like(x2d)                  # x1 = x + rs * (ao Wp^T + b): residual add in the GEMM epilogue
+        ops.gemm(ao, wp, x1, m, d, d, d, d, d, 0, 0, bias=projb, rowscale=rowscale_attn,
+                 epilogue=ops.EPI_RESIDUAL, aux=x2d)
         h2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, eps, act_dtype, mask, 0)
-        a = _linear_fwd(h2, w1, fc1b, act_dtype)
-        g = ops.gelu_fwd(a)
-        x2 = x1.clone()
-        hidden = w2.shape[1]
-        ops.gemm(g, w2, x2, m, d, hidden, hidden, hidden, d, 0, 0, beta=1.0, bias=fc2b, rowscale=rowscale_mlp)
+        hidden = w1.shape[0]
+        a = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
+        g = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
+        ops.gemm(h2, w1, g, m, hidden, d, d, d, hidden, 0, 0, bias=fc1b, epilogue=ops.EPI_GELU, aux=a)
+        x2 = torch.empty_like(x2d)
+        ops.gemm(g, w2, x2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b, rowscale=rowscale_mlp,
+                 epilogue=ops.EPI_RESIDUAL, aux=x1)
         keep_probs = probs if act_dtype == torch.float32 else None
         ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
                               qkvw, projw, fc1w, fc2w, mask, keep_probs, rowscale_attn, rowscale_mlp)
@@ -95,20 +104,18 @@ class TransformerBlockFn(torch.autograd.Function):
         b, t, d, heads, act_dtype, hb_qkv, hb_proj, hb_fc1, hb_fc2 = ctx.meta
         m = b * t
         hd = d // heads
-        sk = _splitk_for(m)
         wq, wp, w1, w2 = (act_weight(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w))
         dx2 = dx2.contiguous().view(m, d)
         # ---- MLP branch:  x2 = x1 + rs * fc2(gelu(fc1(LN2(x1))))
         dy = _scaled_cast(dx2, rs_mlp, act_dtype)
-        dg, dw2, db2 = _linear_bwd(dy, g, w2, hb_fc2, sk)
-        da = ops.gelu_bwd(a, dg)
-        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, sk)
+        da, dw2, db2 = _linear_bwd(dy, g, w2, hb_fc2, gelu_pre=a)      # da = (dy W2) * gelu'(a)
+        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1)
         dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w, mean2, rstd2, mask, 0, dx_in=dx2)
         # ---- attention branch:  x1 = x + rs * proj(attn(qkv(LN1(x))))
         dy = _scaled_cast(dx1, rs_attn, act_dtype)
-        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, sk)
+        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj)
         dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, mask, probs, ao)
-        dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, sk)
+        dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv)
         dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1)
         return (dx.view(b, t, d), dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2,
                 None, None, None, None, None, None, None)
@@ -150,7 +157,7 @@ class PatchEmbedFn(torch.autograd.Function):
         kdim = cols.shape[1]
         mrows = cols.shape[0]
         dw = torch.empty(d, kdim, dtype=torch.float32, device=dx.device)
-        ops.gemm(dpatch, cols, dw, d, kdim, mrows, d, kdim, kdim, 1, 1, splitk=_splitk_for(mrows))
+        ops.gemm(dpatch, cols, dw, d, kdim, mrows, d, kdim, kdim, 1, 1, splitk=_splitk_for(d, kdim, mrows))
         db = ops.colsum(dpatch)
         dcls = dpos[0].clone().view(cls_shape)
         return (None, dw.view(conv_w.shape), db, dcls, dpos.view(pos_shape),
@@ -227,5 +234,5 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        dx, dw, db = _linear_bwd(dy.contiguous(), x.contiguous(), w.detach(), ctx.has_bias, 1)
+        dx, dw, db = _linear_bwd(dy.contiguous(), x.contiguous(), w.detach(), ctx.has_bias)
         return dx, dw, db

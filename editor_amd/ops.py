@@ -79,7 +79,7 @@ def _ptr(t, off=0):
     return t.data_ptr() + off * t.element_size()
 
 
-WS_ROWS = 512
+WS_ROWS = 1024
 
 
 # ---------------------------------------------------------------------------------------------
@@ -205,18 +205,23 @@ def pool_bwd(dout, num, nmod, t):
 # ---------------------------------------------------------------------------------------------
 # contractions
 # ---------------------------------------------------------------------------------------------
+EPI_NONE, EPI_RESIDUAL, EPI_GELU, EPI_GELU_BWD = 0, 1, 2, 3
+
+
 def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=0.0, bias=None, rowscale=None,
-         splitk=1, a_off=0, b_off=0, c_off=0):
+         splitk=1, a_off=0, b_off=0, c_off=0, epilogue=0, aux=None):
     """c = alpha * op(a) op(b) (+bias) (+beta*c) (*rowscale); dtype picks the kernel family
     (fp32 -> exact-f32 MFMA, bf16 -> bf16 MFMA with fp32 accumulate; c may be fp32 for bf16 inputs)."""
     if a.dtype == torch.float32:
         assert b.dtype == torch.float32 and c.dtype == torch.float32
         call("editor_gemm_f32", _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), m, n, k, lda, ldb, ldc,
-             int(trans_a), int(trans_b), 1, 0, 0, 0, 1, 0, 0, 0, float(alpha), float(beta), bias, rowscale, int(splitk))
+             int(trans_a), int(trans_b), 1, 0, 0, 0, 1, 0, 0, 0, float(alpha), float(beta), bias, rowscale, int(splitk),
+             int(epilogue), aux, n)
     elif a.dtype == torch.bfloat16:
         assert b.dtype == torch.bfloat16
         call("editor_gemm_bf16", _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), 1 if c.dtype == torch.float32 else 0,
-             m, n, k, lda, ldb, ldc, int(trans_a), int(trans_b), float(alpha), float(beta), bias, rowscale, int(splitk))
+             m, n, k, lda, ldb, ldc, int(trans_a), int(trans_b), float(alpha), float(beta), bias, rowscale, int(splitk),
+             int(epilogue), aux, n)
     else:
         raise TypeError(a.dtype)
 

@@ -23,6 +23,12 @@ extern "C" {
 
 typedef struct ihipStream_t* editor_stream_t;   /* == hipStream_t */
 
+/* GEMM epilogues (applied after alpha / bias / rowscale, before beta*C): */
+#define EDITOR_EPI_NONE 0
+#define EDITOR_EPI_RESIDUAL 1 /* C = v + aux        aux: fp32 (M,N) residual stream  (x + drop_path(branch), vit_pytorch.py:217-218) */
+#define EDITOR_EPI_GELU 2     /* aux = v ; C = gelu(v)   aux: pre-activation in the activation dtype (Mlp.fc1 -> act, :140-141) */
+#define EDITOR_EPI_GELU_BWD 3 /* C = v * gelu'(aux)      aux: saved pre-activation (backward of the above) */
+
 /* ---- token selection (non-differentiable) ---------------------------------------------------- */
 
 /* Frequency.py:65-84 + :42-56 - 4-level Haar DWT of each modality (pytorch_wavelets AFB2D, lowlevel.py:336-347),
@@ -108,7 +114,7 @@ int editor_rowmask_mul(float* x, const uint8_t* rowmask, int period, long M, int
 int editor_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
                     int transA, int transB, int batch1, long sA1, long sB1, long sC1, int batch2, long sA2, long sB2,
                     long sC2, float alpha, float beta, const float* bias, const float* rowscale, int splitk,
-                    editor_stream_t stream);
+                    int epilogue, float* aux, long ldaux, editor_stream_t stream);
 
 /* bf16 MFMA form of the same contraction (fp32 accumulate; C bf16 or fp32 per c_f32).  No batching.
  * Requirements: 16-byte aligned pointers, lda/ldb multiples of 8, N and ldc multiples of 4, the contiguous
@@ -116,7 +122,8 @@ int editor_gemm_f32(const float* A, const float* B, float* C, int M, int N, int 
  * (ds_read_b64_tr_b16) so dgrad / wgrad need no materialised transposes.  splitk>1 requires c_f32. */
 int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda, long ldb,
                      long ldc, int transA, int transB, float alpha, float beta, const float* bias,
-                     const float* rowscale, int splitk, editor_stream_t stream);
+                     const float* rowscale, int splitk, int epilogue, void* aux, long ldaux,
+                     editor_stream_t stream);
 
 /* Attention.forward / AttentionMask.forward on packed qkv rows (B*T, 3*heads*hd) (vit_pytorch.py:184-198,240-258).
  * mask (B,T) uint8 or NULL.  out (B*T, heads*hd).  probs (B,heads,T,T) fp32: the softmax output the backbone

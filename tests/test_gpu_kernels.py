@@ -227,3 +227,34 @@ def test_gemm_bf16_wgrad_shape(ops):
     dw = torch.empty(n, k, device="cuda")
     ops.gemm(dy.cuda(), x.cuda(), dw, n, k, m, n, k, k, 1, 1, splitk=24)
     assert rel_err(dw.cpu(), dy.float().t().double() @ x.float().double()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(ops, dtype):
+    m, n, k = 520, 384, 256
+    a = torch.randn(m, k, generator=_g(1)).to(dtype)
+    w = (torch.randn(n, k, generator=_g(2)) * 0.1).to(dtype)
+    bias = torch.randn(n, generator=_g(3)) * 0.1
+    ref = a.float() @ w.float().t() + bias
+    tol = 1e-5 if dtype == torch.float32 else 6e-3
+    # residual: C = rowscale * (A W^T + b) + R
+    res = torch.randn(m, n, generator=_g(4))
+    rs = torch.rand(m, generator=_g(5))
+    c = torch.empty(m, n, device="cuda")
+    ops.gemm(a.cuda(), w.cuda(), c, m, n, k, k, k, n, 0, 0, bias=bias.cuda(), rowscale=rs.cuda(),
+             epilogue=ops.EPI_RESIDUAL, aux=res.cuda())
+    assert rel_err(c.cpu(), rs.view(-1, 1) * ref + res) < tol
+    # GELU forward: aux <- pre-activation, C <- gelu
+    pre = torch.empty(m, n, dtype=dtype, device="cuda")
+    act = torch.empty(m, n, dtype=dtype, device="cuda")
+    ops.gemm(a.cuda(), w.cuda(), act, m, n, k, k, k, n, 0, 0, bias=bias.cuda(), epilogue=ops.EPI_GELU, aux=pre)
+    assert rel_err(pre.float().cpu(), ref) < tol
+    assert rel_err(act.float().cpu(), F.gelu(pre.float().cpu())) < tol
+    # GELU backward on a dgrad: C = (dy W) * gelu'(pre)
+    dy = torch.randn(m, n, generator=_g(6)).to(dtype)
+    pre2 = (torch.randn(m, k, generator=_g(7))).to(dtype)
+    pr = pre2.float().requires_grad_(True)
+    F.gelu(pr).backward(dy.float() @ w.float())
+    out = torch.empty(m, k, dtype=dtype, device="cuda")
+    ops.gemm(dy.cuda(), w.cuda(), out, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=pre2.cuda())
+    assert rel_err(out.float().cpu(), pr.grad) < tol
