@@ -17,6 +17,8 @@
 // 8/16-byte epilogue stores and float4 bias loads.
 #include "common.h"
 #include "../../include/editor_hip.h"
+#include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((ext_vector_type(8))) short short8_t;
@@ -87,6 +89,35 @@ struct Stage {
     }
 };
 
+// Direct HBM->LDS staging (global_load_lds_dwordx4: LDS address = wave-uniform base + lane*16, so the image is
+// written linearly and the XOR swizzle is applied to the per-lane SOURCE address; the read side applies the same
+// involution).  Each wave issues 4 x 1 KiB pieces per operand tile.  Requires the reduction extent to be a multiple of
+// BK (no zero fill possible); free-dimension tails are clamped to a valid address (their outputs are never stored).
+template <bool KMAJOR>
+__device__ __forceinline__ void stage_glds(const bf16_t* __restrict__ P, long ld, int r0, int k0, int R, char* lds,
+                                           int wave, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int piece = wave * 4 + j;                       // 1 KiB piece of the 16 KiB tile
+        long off;
+        if (KMAJOR) {
+            const int row = piece * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);
+            const int gr = min(r0 + row, R - 1);
+            off = (long)gr * ld + k0 + c * 8;
+        } else {
+            const int kr = piece * 4 + (lane >> 4);
+            const int p = lane & 15;
+            const int col = ((((p >> 1) ^ swz_rowk(kr)) << 4) | ((p & 1) << 3));
+            const int gc = min(r0 + col, R - 8);
+            off = (long)(k0 + kr) * ld + gc;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(P + off),
+                                         (__attribute__((address_space(3))) void*)(lds + piece * 1024), 16, 0, 0);
+    }
+}
+
 // fragment of sub-tile `sub` (16 rows / cols starting at base16) for k-step s: lane (i = l&15, g = l>>4) gets
 // element (base16 + i, k = s*32 + g*8 + e), e = 0..7
 template <bool KMAJOR>
@@ -111,78 +142,20 @@ __device__ __forceinline__ short8_t load_frag(const char* lds, int base16, int s
     }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool C_F32>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB16Args g)
+template <bool C_F32, int MT>
+__device__ __forceinline__ void epilogue_store(const GemmB16Args& g, float4_t (&acc)[MT][4], int mbase, int nbase, int lane,
+                                               bool first_split)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile | B tile]
-    // ---- XCD-aware tile order: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles --------
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tile_n = wgid % g.tiles_n, tile_m = wgid / g.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    // ---- K range of this split ------------------------------------------------------------------------------
-    const int ktiles = (g.K + BK - 1) / BK;
-    const int per = (ktiles + g.splitk - 1) / g.splitk;
-    const int kt0 = blockIdx.y * per, kt1 = min(ktiles, kt0 + per);
-    if (kt0 >= kt1) return;
-
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
-    float4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
-
-    Stage<A_KMAJOR> sa;
-    Stage<B_KMAJOR> sb;
-    sa.load(g.A, g.lda, m0, kt0 * BK, g.M, g.K);
-    sb.load(g.B, g.ldb, n0, kt0 * BK, g.N, g.K);
-    sa.store(smem);
-    sb.store(smem + TILE_BYTES);
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        const char* la = smem + cur * 2 * TILE_BYTES;
-        const char* lb = la + TILE_BYTES;
-        const bool more = kt + 1 < kt1;
-        if (more) {                                   // issue next tile's HBM loads under this tile's MFMAs
-            sa.load(g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K);
-            sb.load(g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K);
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            short8_t fa[4], fb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = load_frag<A_KMAJOR>(la, wm + i * 16, s, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = load_frag<B_KMAJOR>(lb, wn + j * 16, s, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)   // operands swapped: D^T tile, lane owns 4 consecutive n
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            sa.store(na);
-            sb.store(na + TILE_BYTES);
-        }
-        __syncthreads();
-    }
-    // ---- epilogue: lane (i = l&15, g = l>>4): row m = .. + i, cols n = .. + g*4 + {0..3} -----------------------
+    // lane (i = l&15, g = l>>4): row m = mbase + 16*i' + i, cols n = nbase + 16*j + g*4 + {0..3}
     const int li = lane & 15, lg = lane >> 4;
-    const bool first_split = blockIdx.y == 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm + i * 16 + li;
+    for (int i = 0; i < MT; ++i) {
+        const int m = mbase + i * 16 + li;
         if (m >= g.M) continue;
         const float rs = g.rowscale ? g.rowscale[m] : 1.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn + j * 16 + lg * 4;
+            const int n = nbase + j * 16 + lg * 4;
             if (n >= g.N) continue;                    // N is a multiple of 4 (checked on the host)
             float4 v = make_float4(g.alpha * acc[i][j][0], g.alpha * acc[i][j][1], g.alpha * acc[i][j][2],
                                    g.alpha * acc[i][j][3]);
@@ -229,6 +202,289 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB16Args g)
     }
 }
 
+template <bool A_KMAJOR, bool B_KMAJOR, bool C_F32, bool GLDS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB16Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile | B tile]
+    // ---- XCD-aware tile order: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles --------
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tile_n = wgid % g.tiles_n, tile_m = wgid / g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // ---- K range of this split ------------------------------------------------------------------------------
+    const int ktiles = (g.K + BK - 1) / BK;
+    const int per = (ktiles + g.splitk - 1) / g.splitk;
+    const int kt0 = blockIdx.y * per, kt1 = min(ktiles, kt0 + per);
+    if (kt0 >= kt1) return;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    float4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    Stage<A_KMAJOR> sa;
+    Stage<B_KMAJOR> sb;
+    if (GLDS) {
+        stage_glds<A_KMAJOR>(g.A, g.lda, m0, kt0 * BK, g.M, smem, wu, lane);
+        stage_glds<B_KMAJOR>(g.B, g.ldb, n0, kt0 * BK, g.N, smem + TILE_BYTES, wu, lane);
+    } else {
+        sa.load(g.A, g.lda, m0, kt0 * BK, g.M, g.K);
+        sb.load(g.B, g.ldb, n0, kt0 * BK, g.N, g.K);
+        sa.store(smem);
+        sb.store(smem + TILE_BYTES);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const char* la = smem + cur * 2 * TILE_BYTES;
+        const char* lb = la + TILE_BYTES;
+        const bool more = kt + 1 < kt1;
+        if (more) {                                   // issue next tile's HBM loads under this tile's MFMAs
+            if (GLDS) {
+                char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
+                stage_glds<A_KMAJOR>(g.A, g.lda, m0, (kt + 1) * BK, g.M, na, wu, lane);
+                stage_glds<B_KMAJOR>(g.B, g.ldb, n0, (kt + 1) * BK, g.N, na + TILE_BYTES, wu, lane);
+            } else {
+                sa.load(g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K);
+                sb.load(g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            short8_t fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = load_frag<A_KMAJOR>(la, wm + i * 16, s, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = load_frag<B_KMAJOR>(lb, wn + j * 16, s, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)   // operands swapped: D^T tile, lane owns 4 consecutive n
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        if (more && !GLDS) {
+            char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            sa.store(na);
+            sb.store(na + TILE_BYTES);
+        }
+        __syncthreads();                               // (GLDS: also drains the in-flight LDS-DMA, vmcnt(0))
+    }
+    epilogue_store<C_F32, 4>(g, acc, m0 + wm, n0 + wn, lane, blockIdx.y == 0);
+}
+
+// =====================================================================================================
+// Pipelined large-tile variant (the performance path).  A 128x128 tile moves 64 FLOP per byte staged into LDS and is
+// bound by L2->CU bandwidth at ~25 % of the MFMA peak (measured: 49 % of wave cycles in s_waitcnt/barrier, 0 LDS bank
+// conflicts); this kernel uses 256 x BN tiles, BN = 256 (128 FLOP/B) or 128 (85 FLOP/B, for N = 768 problems whose
+// 256-wide tiling would leave the last wave of workgroups a quarter full):
+//   * 8 wavefronts, one workgroup per CU; BN=256: waves 2(M) x 4(N), 128x64 each; BN=128: 4 x 2, 64x64 each
+//   * LDS stages filled by global_load_lds (LDS-DMA) D = STAGES-1 K-tiles ahead; ONE raw s_barrier per K-tile and a
+//     COUNTED s_waitcnt vmcnt, so the DMA of later tiles stays in flight across the barrier
+//   * grouped tile order inside each XCD's tile range (GM tile-rows x all tile-columns, column-major) so the resident
+//     workgroups of an XCD share few A and B panels (both fit its 4 MiB L2)
+// =====================================================================================================
+constexpr int PBM = 256;
+
+template <bool KMAJOR, int ROWS_OR_COLS>
+__device__ __forceinline__ void pstage_glds(const bf16_t* __restrict__ P, long ld, int r0, int k0, int R, char* lds,
+                                            int piece0, int npieces, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < npieces; ++j) {
+        const int piece = piece0 + j;
+        long off;
+        if (KMAJOR) {
+            const int row = piece * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);
+            off = (long)min(r0 + row, R - 1) * ld + k0 + c * 8;
+        } else {
+            constexpr int LPR = ROWS_OR_COLS / 8;              // lanes (16-byte units) per k-row
+            constexpr int RPP = 64 / LPR;                      // k-rows per 1 KiB piece
+            const int kr = piece * RPP + lane / LPR;
+            const int p = lane % LPR;
+            const int col = ((((p >> 1) ^ swz_rowk(kr)) << 4) | ((p & 1) << 3));
+            off = (long)(k0 + kr) * ld + min(r0 + col, R - 8);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(P + off),
+                                         (__attribute__((address_space(3))) void*)(lds + piece * 1024), 16, 0, 0);
+    }
+}
+
+template <bool KMAJOR, int COLS>
+__device__ __forceinline__ short8_t pload_frag(const char* lds, int base16, int s, int lane)
+{
+    const int i = lane & 15, g = lane >> 4;
+    if (KMAJOR) {
+        const int row = base16 + i, c = s * 4 + g;
+        return *reinterpret_cast<const short8_t*>(lds + row * 128 + ((c ^ (row & 7)) << 4));
+    } else {
+        const int blk = base16 >> 4;
+        const int k0 = s * 32 + g * 8 + (i >> 2);
+        const int k1 = k0 + 4;
+        const int a0 = k0 * (COLS * 2) + ((blk ^ swz_rowk(k0)) << 5) + ((i & 3) << 3);
+        const int a1 = k1 * (COLS * 2) + ((blk ^ swz_rowk(k1)) << 5) + ((i & 3) << 3);
+        typedef __attribute__((address_space(3))) short4_t* lds_p;
+        const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + a0));
+        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + a1));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR, bool C_F32, int PBN, int STAGES>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pipe_kernel(GemmB16Args g)
+{
+    constexpr int PA_BYTES = PBM * BK * 2, PB_BYTES = PBN * BK * 2, PSTAGE = PA_BYTES + PB_BYTES;
+    constexpr int WAVES_N = PBN / 64, WAVES_M = 8 / WAVES_N, WM = PBM / WAVES_M, MT = WM / 16;
+    constexpr int A_PIECES = PA_BYTES / 1024 / 8, B_PIECES = PB_BYTES / 1024 / 8, PIECES = A_PIECES + B_PIECES;
+    constexpr int GM = PBN == 256 ? 4 : 4;                     // tile-rows per group
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // ---- tile order: XCD-contiguous ranges, grouped (GM rows x all columns, column-major) inside --------------
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int grp = GM * g.tiles_n;
+    const int gm0 = (wgid / grp) * GM, rem = wgid % grp;
+    const int gsz = min(GM, g.tiles_m - gm0);
+    const int tile_m = gm0 + rem % gsz, tile_n = rem / gsz;
+    const int m0 = tile_m * PBM, n0 = tile_n * PBN;
+    const int ktiles = g.K / BK;
+    const int per = (ktiles + g.splitk - 1) / g.splitk;
+    const int kt0 = blockIdx.y * per, kt1 = min(ktiles, kt0 + per);
+    if (kt0 >= kt1) return;
+    const int nk = kt1 - kt0;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int wm = (w / WAVES_N) * WM, wn = (w % WAVES_N) * 64;
+    float4_t acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int t) {
+        char* st = smem + (t % STAGES) * PSTAGE;
+        const int k0 = (kt0 + t) * BK;
+        pstage_glds<A_KMAJOR, PBM>(g.A, g.lda, m0, k0, g.M, st, wu * A_PIECES, A_PIECES, lane);
+        pstage_glds<B_KMAJOR, PBN>(g.B, g.ldb, n0, k0, g.N, st + PA_BYTES, wu * B_PIECES, B_PIECES, lane);
+    };
+    // Software pipeline.  All STAGES buffers are kept full (tile t+STAGES is issued as soon as tile t's buffer is
+    // released), and the MFMA operands are double-buffered in REGISTERS across the barrier: while the matrix core
+    // works on k-half s, the ds_reads of the next k-half (possibly of the next tile) are already in flight, so a
+    // wave never sits between "barrier released" and "first MFMA" waiting for LDS.
+    //   step 2t  : read F1(t)            | MFMA F0(t)
+    //   step 2t+1: wait tile t+1, barrier, DMA tile t+STAGES -> buffer of tile t, read F0(t+1) | MFMA F1(t)
+    // Fragment reads are issued as inline asm so that hipcc does not track them: its own bookkeeping inserts a
+    // conservative s_waitcnt lgkmcnt(0) at the loop header (it cannot count reads that are in flight across the
+    // back edge), which would serialise "read F1 -> MFMA F0".  The waits below are placed by hand instead:
+    //   lgkmcnt(NF): the NF reads just issued may stay in flight, everything older (the operands of the next MFMA
+    //                group) has landed;   lgkmcnt(0) before the barrier.
+    // Every wait is followed by sched_barrier(0) (an MFMA is register-only and would otherwise be hoisted above it).
+    short8_t fa0[MT], fb0[4], fa1[MT], fb1[4];
+    // loop-invariant per-lane byte offsets inside a stage, for k-half 0; k-half 1 = XOR 64 (k-major: chunk index bit 2)
+    // or + 32 k-rows (row-k image)
+    uint32_t offA[MT], offB[4];
+    {
+        const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if (A_KMAJOR) { const int row = wm + i * 16 + li; offA[i] = row * 128 + ((lg ^ (row & 7)) << 4); }
+            else { const int k0 = lg * 8 + (li >> 2); offA[i] = k0 * (PBM * 2) + ((((wm >> 4) + i) ^ swz_rowk(k0)) << 5) + ((li & 3) << 3); }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (B_KMAJOR) { const int row = wn + j * 16 + li; offB[j] = PA_BYTES + row * 128 + ((lg ^ (row & 7)) << 4); }
+            else { const int k0 = lg * 8 + (li >> 2); offB[j] = PA_BYTES + k0 * (PBN * 2) + ((((wn >> 4) + j) ^ swz_rowk(k0)) << 5) + ((li & 3) << 3); }
+        }
+    }
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    constexpr int NF = (A_KMAJOR ? MT : 2 * MT) + (B_KMAJOR ? 4 : 8);     // LDS reads per fragment set
+    constexpr int NFW = NF > 15 ? 15 : NF;
+    auto rd128 = [](uint32_t addr) {
+        short8_t v;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+        return v;
+    };
+    auto rdtr = [](uint32_t addr, auto rowskip) {
+        short4_t lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "i"(decltype(rowskip)::value));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto load_frags = [&](short8_t (&fa)[MT], short8_t (&fb)[4], int t, int s) {
+        const uint32_t st = smem_base + (t % STAGES) * PSTAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (B_KMAJOR) fb[j] = rd128(st + (offB[j] ^ (s << 6)));
+            else fb[j] = rdtr(st + offB[j] + s * 32 * (PBN * 2), std::integral_constant<int, 4 * PBN * 2>{});
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if (A_KMAJOR) fa[i] = rd128(st + (offA[i] ^ (s << 6)));
+            else fa[i] = rdtr(st + offA[i] + s * 32 * (PBM * 2), std::integral_constant<int, 4 * PBM * 2>{});
+        }
+    };
+    auto mma = [&](short8_t (&fa)[MT], short8_t (&fb)[4]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+#define WAIT_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#pragma unroll
+    for (int d = 0; d < STAGES; ++d)
+        if (d < nk) issue(d);
+    {   // tile 0 landed (later tiles may still be in flight)
+        const int later = min(nk - 1, STAGES - 1);
+        if (later >= 2)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    load_frags(fa0, fb0, 0, 0);
+    int t = 0;
+    // steady state (tile t+STAGES exists)
+    for (; t + STAGES < nk; ++t) {
+        load_frags(fa1, fb1, t, 1);
+        WAIT_LGKM(NFW);                                               // F0(t) landed, F1(t) in flight
+        mma(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);                            // the waits below stay BEHIND these MFMAs
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PIECES) : "memory");   // tile t+1 landed
+        WAIT_LGKM(0);                                                 // my reads of tile t's buffer are done
+        __builtin_amdgcn_s_barrier();                                 // ... everyone's: the buffer can be refilled
+        issue(t + STAGES);
+        load_frags(fa0, fb0, t + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // drain: no more tiles to request
+    for (; t < nk; ++t) {
+        load_frags(fa1, fb1, t, 1);
+        WAIT_LGKM(NFW);
+        mma(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WAIT_LGKM(0);
+        if (t + 1 < nk) {
+            __builtin_amdgcn_s_barrier();
+            load_frags(fa0, fb0, t + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mma(fa1, fb1);
+    }
+#undef WAIT_LGKM
+    epilogue_store<C_F32, MT>(g, acc, m0 + wm, n0 + wn, lane, blockIdx.y == 0);
+}
+
 __global__ void scale_c_kernel(float* C, long rows, int cols, long ld, float beta)
 {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -237,10 +493,10 @@ __global__ void scale_c_kernel(float* C, long rows, int cols, long ld, float bet
     *c = beta == 0.f ? 0.f : *c * beta;
 }
 
-template <bool AK, bool BK_, bool CF>
+template <bool AK, bool BK_, bool CF, bool GL>
 int launch(const GemmB16Args& g, hipStream_t stream)
 {
-    auto kern = gemm_bf16_kernel<AK, BK_, CF>;
+    auto kern = gemm_bf16_kernel<AK, BK_, CF, GL>;
     static bool attr_done = false;                       // per-instantiation; idempotent
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
@@ -250,6 +506,35 @@ int launch(const GemmB16Args& g, hipStream_t stream)
     hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(256), 4 * TILE_BYTES, stream, g);
     EDITOR_LAUNCH_CHECK();
     return 0;
+}
+
+template <bool AK, bool BK_, bool CF, int PBN, int STAGES>
+int launch_pipe_t(GemmB16Args g, hipStream_t stream)
+{
+    constexpr int LDS = STAGES * (PBM + PBN) * BK * 2;
+    auto kern = gemm_bf16_pipe_kernel<AK, BK_, CF, PBN, STAGES>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    g.tiles_m = (g.M + PBM - 1) / PBM;
+    g.tiles_n = (g.N + PBN - 1) / PBN;
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(512), LDS, stream, g);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool AK, bool BK_, bool CF>
+int launch_pipe(const GemmB16Args& g, hipStream_t stream)
+{
+    // 256-wide tiles unless they would leave the machine badly filled (N = 768: 3 tile columns)
+    const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.splitk;
+    const bool wide = g.N >= 256 && (g.N % 256 == 0 || g.N >= 1024) &&
+                      (t256 >= 1024 || (t256 % 256 == 0) || (t256 % 256) >= 160) && !getenv("EDITOR_GEMM_NO_WIDE");
+    if (wide) return launch_pipe_t<AK, BK_, CF, 256, 2>(g, stream);
+    return launch_pipe_t<AK, BK_, CF, 128, 3>(g, stream);
 }
 
 }  // namespace
@@ -281,15 +566,33 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
     }
     GemmB16Args g{(const bf16_t*)A, (const bf16_t*)B, C, M, N, K, lda, ldb, ldc, alpha, beta, bias, rowscale, splitk,
                   (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux};
+    // direct-to-LDS staging needs whole BK tiles along the reduction and >= 8 valid elements to clamp to
+    const bool glds = (K % BK == 0) && M >= 8 && N >= 8 && !getenv("EDITOR_GEMM_NO_GLDS");
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
-    switch (sel) {
-        case 7: return launch<true, true, true>(g, stream);
-        case 6: return launch<true, true, false>(g, stream);
-        case 5: return launch<true, false, true>(g, stream);
-        case 4: return launch<true, false, false>(g, stream);
-        case 3: return launch<false, true, true>(g, stream);
-        case 2: return launch<false, true, false>(g, stream);
-        case 1: return launch<false, false, true>(g, stream);
-        default: return launch<false, false, false>(g, stream);
+    // large problems: 3-stage LDS-DMA pipeline (256x128 tiles)
+    const bool pipe = glds && M >= 256 && N >= 128 && !getenv("EDITOR_GEMM_NO_PIPE");
+    if (pipe) {
+        switch (sel) {
+            case 7: return launch_pipe<true, true, true>(g, stream);
+            case 6: return launch_pipe<true, true, false>(g, stream);
+            case 5: return launch_pipe<true, false, true>(g, stream);
+            case 4: return launch_pipe<true, false, false>(g, stream);
+            case 3: return launch_pipe<false, true, true>(g, stream);
+            case 2: return launch_pipe<false, true, false>(g, stream);
+            case 1: return launch_pipe<false, false, true>(g, stream);
+            default: return launch_pipe<false, false, false>(g, stream);
+        }
     }
+#define GEMM_CASE(n, a, b, c) case n: return glds ? launch<a, b, c, true>(g, stream) : launch<a, b, c, false>(g, stream)
+    switch (sel) {
+        GEMM_CASE(7, true, true, true);
+        GEMM_CASE(6, true, true, false);
+        GEMM_CASE(5, true, false, true);
+        GEMM_CASE(4, true, false, false);
+        GEMM_CASE(3, false, true, true);
+        GEMM_CASE(2, false, true, false);
+        GEMM_CASE(1, false, false, true);
+        default: return glds ? launch<false, false, false, true>(g, stream) : launch<false, false, false, false>(g, stream);
+    }
+#undef GEMM_CASE
 }

@@ -1,0 +1,61 @@
+"""Micro-benchmark of the bf16 GEMM kernel family on the hot path's real shapes (M = 3*128*129 token rows).
+    python tools/gemm_bench.py            # prints TFLOP/s per (layout, shape)
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from editor_amd import ops  # noqa: E402
+from editor_amd.functional import _splitk_for  # noqa: E402
+
+
+def bench(fn, iters=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    m = int(os.environ.get("GEMM_M", 3 * 128 * 129))
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    rows = []
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]
+    only = os.environ.get("GEMM_ONLY")          # e.g. "fwd:3072x768"
+    if only:
+        kind_only, sh = only.split(":")
+        shapes = [tuple(int(v) for v in sh.split("x"))]
+    iters = int(os.environ.get("GEMM_ITERS", "20"))
+    for (n, k) in shapes:
+        x = torch.randn(m, k, device=dev, generator=g).bfloat16()
+        w = (torch.randn(n, k, device=dev, generator=g) * 0.05).bfloat16()
+        dy = torch.randn(m, n, device=dev, generator=g).bfloat16()
+        y = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+        dx = torch.empty(m, k, device=dev, dtype=torch.bfloat16)
+        dw = torch.empty(n, k, device=dev)
+        fl = 2.0 * m * n * k
+        if not only or kind_only == "fwd":
+            t = bench(lambda: ops.gemm(x, w, y, m, n, k, k, k, n, 0, 0), iters)
+            rows.append(("fwd", n, k, fl / t / 1e9))
+        if not only or kind_only == "dgrad":
+            t = bench(lambda: ops.gemm(dy, w, dx, m, k, n, n, k, k, 0, 1), iters)
+            rows.append(("dgrad", n, k, fl / t / 1e9))
+        sk = _splitk_for(n, k, m)
+        if not only or kind_only == "wgrad":
+            t = bench(lambda: ops.gemm(dy, x, dw, n, k, m, n, k, k, 1, 1, splitk=sk), iters)
+            rows.append((f"wgrad(sk={sk})", n, k, fl / t / 1e9))
+    for r in rows:
+        print("%-14s N=%-5d K=%-5d %8.1f TFLOP/s" % r)
+
+
+if __name__ == "__main__":
+    main()
