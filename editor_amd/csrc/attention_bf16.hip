@@ -1,13 +1,13 @@
 // Fused bf16 multi-head attention (forward + backward) for the EDITOR hot path, gfx950 / CDNA4.
 // Restates Attention.forward (vit_pytorch.py:184-198) and AttentionMask.forward (:240-258) on packed
 // qkv rows (B*T, 3*heads*64); sequences are short (T = 129 / 193 backbone, 387 joint HMA block), so the
-// whole key range of one (sample, head) lives in LDS and a wavefront keeps a FULL score row block in registers:
-// no online-softmax rescaling, and the softmax output can be emitted (the backbone returns it,
-// vit_pytorch.py:638-644; the rollout consumes it).
+// whole key range of one (sample, head) lives in LDS, every pass streams over 16x16 score tiles with the row
+// log-sum-exp known in advance (no running rescale of the output), and the softmax output can be emitted
+// (the backbone returns it, vit_pytorch.py:638-644; the rollout consumes it).
 //
 // One workgroup per (sample, head); each wavefront owns 16-row "own" tiles and sweeps all "other" rows:
 //   FWD   own = queries, LDS = K,V      S^T = K Q^T -> softmax over keys -> O^T = V^T P^T
-//   DQ    own = queries, LDS = K,V      recompute P^T, dP^T = V dO^T, dS^T, dQ^T = K^T dS^T ; writes lse, delta
+//   DQ    own = queries, LDS = K,V      P^T = exp(S^T - lse), dP^T = V dO^T, dS^T, dQ^T = K^T dS^T ; writes delta
 //   DKV   own = keys,    LDS = Q,dO     P = exp(S - lse), dP = dO V^T, dS ; dV^T = dO^T P, dK^T = Q^T dS
 // Every product is a v_mfma_f32_16x16x32_bf16 whose accumulator layout (lane = own column, 4 consecutive
 // other-rows) is directly the next product's B operand after a bf16 pack - no cross-lane movement - using a
@@ -88,11 +88,20 @@ struct AttnArgs {
     bf16_t* out; bf16_t* dqkv; float* probs; float* lse; float* delta;
     const uint8_t* mask;
     int T, heads; float scale;
+    int ldp;                              // row stride (floats) of the probability output, multiple of 4
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// FWD and DQ passes (own = queries; LDS holds the K and V images)
+// FWD and DQ passes (own = queries; LDS holds the K and V images).  Both STREAM over key tiles with the row
+// log-sum-exp known in advance (FWD computes it in a first sweep over the score tiles - an online max/sum that
+// costs 2 extra MFMAs per tile but no registers; DQ reads the value FWD saved), so a wave holds one score tile at
+// a time: ~64-90 VGPRs, 4+ waves/SIMD, instead of a full 16xT score block (256 VGPRs, one workgroup per CU).
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool bit_of(unsigned long long lo, unsigned long long hi, int bit)
+{
+    return bit < 64 ? (lo >> bit) & 1ull : (hi >> (bit - 64)) & 1ull;
+}
+
 template <int NT, bool BWD>
 __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
 {
@@ -123,78 +132,46 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
             if (ok) { if (bit < 64) kv0 |= 1ull << bit; else kv1 |= 1ull << (bit - 64); }
         }
     const float sc = a.scale * kLog2e;
+    const long row_idx0 = ((long)b * a.heads + hh) * T;
 
     for (int q0 = w * 16; q0 < T; q0 += nw * 16) {
         const int q = q0 + li;
         const bool qok = q < T && (!mk || mk[q]);
-        short8_t qf[2], dof[2];
+        short8_t qf[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) qf[s] = frag_own(qbase, ld, q0, T, s, lane);
-        // ---- S^T tiles: lane holds column q, rows keys 16t + 4g + r -----------------------------------------
-        float4_t p[NT];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            float4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(kimg, t * 16, s, lane), qf[s], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int bit = t * 4 + r;
-                const bool ok = bit < 64 ? (kv0 >> bit) & 1ull : (kv1 >> (bit - 64)) & 1ull;
-                acc[r] = ok ? acc[r] * sc : -INFINITY;
-                mx = fmaxf(mx, acc[r]);
-            }
-            p[t] = acc;
-        }
-        mx = group_max(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { p[t][r] = exp2f(p[t][r] - mx); sum += p[t][r]; }
-        sum = group_sum(sum);
-        const float inv = (qok && sum > 0.f) ? 1.f / sum : 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p[t][r] *= inv;
-
+        float lse;                                        // log2-sum-exp2 of the scaled scores of row q
         if (!BWD) {
-            if (a.probs && q < T) {                 // softmax output (B,h,T,T) fp32 for the rollout
-                float* pr = a.probs + (((long)b * a.heads + hh) * T + q) * T;
+            // ---- sweep 1: online max / sum over this lane's keys, then across the 4 lane groups ------------------
+            float m = -INFINITY, l = 0.f;
+#pragma unroll 2
+            for (int t = 0; t < NT; ++t) {
+                float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int s = 0; s < 2; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(kimg, t * 16, s, lane), qf[s], acc, 0, 0, 0);
+                float sv[4], tm = -INFINITY;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = 16 * t + 4 * lg + r;
-                        if (key < T) pr[key] = p[t][r];
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    sv[r] = bit_of(kv0, kv1, t * 4 + r) ? acc[r] * sc : -INFINITY;
+                    tm = fmaxf(tm, sv[r]);
+                }
+                if (tm > m) { l *= exp2f(m - tm); m = tm; }              // (m == -inf: l == 0, stays 0)
+                if (m > -INFINITY) l += (exp2f(sv[0] - m) + exp2f(sv[1] - m)) + (exp2f(sv[2] - m) + exp2f(sv[3] - m));
             }
-            // ---- O^T = V^T P^T -------------------------------------------------------------------------------
-            float4_t o[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s2 = 0; s2 < NT / 2; ++s2) {
-                const short8_t pf = join(pack4(p[2 * s2][0], p[2 * s2][1], p[2 * s2][2], p[2 * s2][3]),
-                                         pack4(p[2 * s2 + 1][0], p[2 * s2 + 1][1], p[2 * s2 + 1][2], p[2 * s2 + 1][3]));
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(vimg, s2, dt, lane), pf, o[dt], 0, 0, 0);
-            }
-            if (q < T) {
-                bf16_t* orow = a.out + ((long)b * T + q) * D + hh * HD + 4 * lg;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    *reinterpret_cast<uint2*>(orow + dt * 16) = pack4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
-            }
+            const float M = group_max(m);
+            const float L = group_sum(m > -INFINITY ? l * exp2f(m - M) : 0.f);
+            lse = (qok && L > 0.f) ? M + log2f(L) : INFINITY;          // +inf -> P == 0 (masked query)
+            if (a.lse && lg == 0 && q < T) a.lse[row_idx0 + q] = lse;
         } else {
-            // ---- delta[q] = sum_d dO[q,d] * O[q,d] ; lse[q] ------------------------------------------------------
+            lse = q < T ? a.lse[row_idx0 + q] : INFINITY;
+        }
+
+        float dl = 0.f;
+        short8_t dof[2];
+        if (BWD) {   // delta[q] = sum_d dO[q,d] * O[q,d]
             const bf16_t* dobase = a.dout + (long)b * T * D + hh * HD;
             const bf16_t* obase = a.out_fwd + (long)b * T * D + hh * HD;
-            float dl = 0.f;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 dof[s] = frag_own(dobase, D, q0, T, s, lane);
@@ -203,40 +180,52 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
                 for (int e = 0; e < 8; ++e) dl += bf16_to_f32((bf16_t)dof[s][e]) * bf16_to_f32((bf16_t)of[e]);
             }
             dl = group_sum(dl);
-            if (lg == 0 && q < T) {
-                const long idx = ((long)b * a.heads + hh) * T + q;
-                a.delta[idx] = dl;
-                // lse in log2 units of the scaled scores; +inf for masked queries so that P == 0 downstream
-                a.lse[idx] = (qok && sum > 0.f) ? mx + log2f(sum) : INFINITY;
+            if (lg == 0 && q < T) a.delta[row_idx0 + q] = dl;
+        }
+        // probability rows are padded to a multiple of 4 floats so that each lane's 4 consecutive keys are ONE 16-byte store
+        float* pr = (!BWD && a.probs && q < T) ? a.probs + (row_idx0 + q) * a.ldp : nullptr;
+
+        // ---- sweep 2: P^T tiles from lse; FWD: O^T += V^T P^T ; BWD: dS^T, dQ^T += K^T dS^T ----------------------
+        float4_t o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int s2 = 0; s2 < NT / 2; ++s2) {
+            uint2 pk[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int t = 2 * s2 + half;
+                float4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(kimg, t * 16, s, lane), qf[s], acc, 0, 0, 0);
+                    if (BWD) dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(vimg, t * 16, s, lane), dof[s], dp, 0, 0, 0);
+                }
+                float pv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pv[r] = bit_of(kv0, kv1, t * 4 + r) ? exp2f(acc[r] * sc - lse) : 0.f;
+                if (!BWD) {
+                    if (pr && 16 * t + 4 * lg < a.ldp)
+                        *reinterpret_cast<float4*>(pr + 16 * t + 4 * lg) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                    pk[half] = pack4(pv[0], pv[1], pv[2], pv[3]);
+                } else {
+                    pk[half] = pack4(pv[0] * (dp[0] - dl) * a.scale, pv[1] * (dp[1] - dl) * a.scale,
+                                     pv[2] * (dp[2] - dl) * a.scale, pv[3] * (dp[3] - dl) * a.scale);
+                }
             }
-            // ---- dS^T = P^T * (dP^T - delta) * scale, packed per tile ------------------------------------------
-            uint2 ds[NT];
+            const short8_t pf = join(pk[0], pk[1]);
+            const char* timg = BWD ? kimg : vimg;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                float4_t dp = {0.f, 0.f, 0.f, 0.f};
+            for (int dt = 0; dt < 4; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(timg, s2, dt, lane), pf, o[dt], 0, 0, 0);
+        }
+        if (q < T) {
+            bf16_t* orow = BWD ? a.dqkv + ((long)b * T + q) * ld + hh * HD + 4 * lg
+                               : a.out + ((long)b * T + q) * D + hh * HD + 4 * lg;
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(vimg, t * 16, s, lane), dof[s], dp, 0, 0, 0);
-                ds[t] = pack4(p[t][0] * (dp[0] - dl) * a.scale, p[t][1] * (dp[1] - dl) * a.scale,
-                              p[t][2] * (dp[2] - dl) * a.scale, p[t][3] * (dp[3] - dl) * a.scale);
-            }
-            // ---- dQ^T = K^T dS^T ----------------------------------------------------------------------------------
-            float4_t dq[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dq[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s2 = 0; s2 < NT / 2; ++s2) {
-                const short8_t df = join(ds[2 * s2], ds[2 * s2 + 1]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(kimg, s2, dt, lane), df, dq[dt], 0, 0, 0);
-            }
-            if (q < T) {
-                bf16_t* drow = a.dqkv + ((long)b * T + q) * ld + hh * HD + 4 * lg;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    *reinterpret_cast<uint2*>(drow + dt * 16) = pack4(dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]);
-            }
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<uint2*>(orow + dt * 16) = pack4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
         }
     }
 }
@@ -378,18 +367,19 @@ int dispatch(const AttnArgs& a, int B, int mode, hipStream_t stream)
 }  // namespace
 
 extern "C" int editor_attention_fwd_bf16(const uint16_t* qkv, int B, int T, int heads, int hd, float scale,
-                                         const uint8_t* mask, uint16_t* out, float* probs, hipStream_t stream)
+                                         const uint8_t* mask, uint16_t* out, float* probs, int ldp, float* lse,
+                                         hipStream_t stream)
 {
     if (hd != HD || T < 1 || B < 1) return (int)hipErrorInvalidValue;
-    AttnArgs a{qkv, nullptr, nullptr, out, nullptr, probs, nullptr, nullptr, mask, T, heads, scale};
+    if (probs && (ldp < T || (ldp & 3) || (reinterpret_cast<uintptr_t>(probs) & 15))) return (int)hipErrorInvalidValue;
+    AttnArgs a{qkv, nullptr, nullptr, out, nullptr, probs, lse, nullptr, mask, T, heads, scale, ldp};
     return dispatch(a, B, 0, stream);
 }
 
-extern "C" int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, int B, int T,
-    int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace, hipStream_t stream)
+extern "C" int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse,
+    int B, int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace, hipStream_t stream)
 {
-    if (hd != HD || T < 1 || B < 1 || !workspace) return (int)hipErrorInvalidValue;
-    const long n = (long)B * heads * T;
-    AttnArgs a{qkv, dout, out, nullptr, dqkv, nullptr, workspace, workspace + n, mask, T, heads, scale};
+    if (hd != HD || T < 1 || B < 1 || !workspace || !lse) return (int)hipErrorInvalidValue;
+    AttnArgs a{qkv, dout, out, nullptr, dqkv, nullptr, const_cast<float*>(lse), workspace, mask, T, heads, scale, 0};
     return dispatch(a, B, 1, stream);
 }

@@ -531,8 +531,10 @@ int launch_pipe(const GemmB16Args& g, hipStream_t stream)
 {
     // 256-wide tiles unless they would leave the machine badly filled (N = 768: 3 tile columns)
     const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.splitk;
-    const bool wide = g.N >= 256 && (g.N % 256 == 0 || g.N >= 1024) &&
-                      (t256 >= 1024 || (t256 % 256 == 0) || (t256 % 256) >= 160) && !getenv("EDITOR_GEMM_NO_WIDE");
+    // measured (tools/gemm_bench.py): the 256x128 3-stage form is >= the 256x256 2-stage form on every hot-path
+    // shape (the 2-stage pipeline exposes DMA latency); keep 256x256 opt-in until it gets a half-tile schedule.
+    const bool wide = getenv("EDITOR_GEMM_WIDE") && g.N >= 256 && (g.N % 256 == 0 || g.N >= 1024) &&
+                      (t256 >= 1024 || (t256 % 256 == 0) || (t256 % 256) >= 160);
     if (wide) return launch_pipe_t<AK, BK_, CF, 256, 2>(g, stream);
     return launch_pipe_t<AK, BK_, CF, 128, 3>(g, stream);
 }

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64) void topk_mask_kernel(const V* __restrict__ val
 //     probs layout [L][Bp][heads][T][T] fp32 (softmax outputs of the backbone, vit_pytorch.py:190)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void rollout_kernel(const float* __restrict__ probs, int L, long layer_stride,
-                                                      int T, float* __restrict__ scores)
+                                                      int T, int ldp, float* __restrict__ scores)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* r = reinterpret_cast<float*>(smem);          // [T]
@@ -263,21 +263,21 @@ __global__ __launch_bounds__(512) void rollout_kernel(const float* __restrict__ 
     const int G = blockDim.x / T;                        // row groups
     const int g = threadIdx.x / T, j = threadIdx.x % T;
     const bool active = g < G;
-    const float* A = probs + (long)(L - 1) * layer_stride + bh * (long)T * T;
+    const float* A = probs + (long)(L - 1) * layer_stride + bh * (long)T * ldp;
     for (int t = threadIdx.x; t < T; t += blockDim.x) r[t] = A[t];           // CLS row of the last layer
     __syncthreads();
     for (int l = L - 2; l >= 0; --l) {
-        A = probs + (long)l * layer_stride + bh * (long)T * T;
+        A = probs + (long)l * layer_stride + bh * (long)T * ldp;
         if (active) {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             int i = g;
             for (; i + 3 * G < T; i += 4 * G) {
-                a0 += r[i] * A[(long)i * T + j];
-                a1 += r[i + G] * A[(long)(i + G) * T + j];
-                a2 += r[i + 2 * G] * A[(long)(i + 2 * G) * T + j];
-                a3 += r[i + 3 * G] * A[(long)(i + 3 * G) * T + j];
+                a0 += r[i] * A[(long)i * ldp + j];
+                a1 += r[i + G] * A[(long)(i + G) * ldp + j];
+                a2 += r[i + 2 * G] * A[(long)(i + 2 * G) * ldp + j];
+                a3 += r[i + 3 * G] * A[(long)(i + 3 * G) * ldp + j];
             }
-            for (; i < T; i += G) a0 += r[i] * A[(long)i * T + j];
+            for (; i < T; i += G) a0 += r[i] * A[(long)i * ldp + j];
             part[g * T + j] = (a0 + a1) + (a2 + a3);
         }
         __syncthreads();
@@ -342,15 +342,15 @@ extern "C" int editor_topk_mask_f32(const float* vals, int rows, int n, int k, i
                                     hipStream_t stream)
 { return topk_mask_launch<float>(vals, rows, n, k, group, mask, stream); }
 
-extern "C" int editor_attn_rollout_f32(const float* probs, int L, int BH, int T, long layer_stride, float* scores,
+extern "C" int editor_attn_rollout_f32(const float* probs, int L, int BH, int T, int ldp, long layer_stride, float* scores,
                                        hipStream_t stream)
 {
-    if (L < 1 || T < 2 || T > 512) return (int)hipErrorInvalidValue;
+    if (L < 1 || T < 2 || T > 512 || ldp < T) return (int)hipErrorInvalidValue;
     int threads = (512 / T) * T;                       // G full row-groups of T threads
     if (threads < 64) threads = T;
     const int G = threads / T;
     const size_t lds = (size_t)(((T + 3) & ~3) + (size_t)G * T) * sizeof(float);
-    hipLaunchKernelGGL(rollout_kernel, dim3(BH), dim3(threads), lds, stream, probs, L, layer_stride, T, scores);
+    hipLaunchKernelGGL(rollout_kernel, dim3(BH), dim3(threads), lds, stream, probs, L, layer_stride, T, ldp, scores);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

@@ -79,7 +79,7 @@ class TransformerBlockFn(torch.autograd.Function):
         wq, wp, w1, w2 = (act_weight(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w))
         h1, mean1, rstd1 = ops.layernorm_fwd(x2d, n1w, n1b, eps, act_dtype, mask, 0)
         qkv = _linear_fwd(h1, wq, qkvb, act_dtype)
-        ao, probs = ops.attention_fwd(qkv, b, t, heads, hd, mask, probs_out)
+        ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, mask, probs_out)
         x1 = torch.empty_like(x2d)                  # x1 = x + rs * (ao Wp^T + b): residual add in the GEMM epilogue
         ops.gemm(ao, wp, x1, m, d, d, d, d, d, 0, 0, bias=projb, rowscale=rowscale_attn,
                  epilogue=ops.EPI_RESIDUAL, aux=x2d)
@@ -91,16 +91,15 @@ class TransformerBlockFn(torch.autograd.Function):
         x2 = torch.empty_like(x2d)
         ops.gemm(g, w2, x2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b, rowscale=rowscale_mlp,
                  epilogue=ops.EPI_RESIDUAL, aux=x1)
-        keep_probs = probs if act_dtype == torch.float32 else None
         ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
-                              qkvw, projw, fc1w, fc2w, mask, keep_probs, rowscale_attn, rowscale_mlp)
+                              qkvw, projw, fc1w, fc2w, mask, attn_saved, rowscale_attn, rowscale_mlp)
         ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None)
         return x2.view(b, t, d)
 
     @staticmethod
     def backward(ctx, dx2):
         (x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w, qkvw, projw, fc1w, fc2w, mask,
-         probs, rs_attn, rs_mlp) = ctx.saved_tensors
+         attn_saved, rs_attn, rs_mlp) = ctx.saved_tensors
         b, t, d, heads, act_dtype, hb_qkv, hb_proj, hb_fc1, hb_fc2 = ctx.meta
         m = b * t
         hd = d // heads
@@ -114,7 +113,7 @@ class TransformerBlockFn(torch.autograd.Function):
         # ---- attention branch:  x1 = x + rs * proj(attn(qkv(LN1(x))))
         dy = _scaled_cast(dx1, rs_attn, act_dtype)
         dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj)
-        dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, mask, probs, ao)
+        dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, mask, attn_saved, ao)
         dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv)
         dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1)
         return (dx.view(b, t, d), dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2,

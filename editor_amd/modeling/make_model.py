@@ -285,7 +285,9 @@ class EDITOR(nn.Module):
         x = fn.PatchEmbedFn.apply(imgs, base.patch_embed.proj.weight, base.patch_embed.proj.bias, base.cls_token,
                                   base.pos_embed, sie, cam if sie is not None else None, float(base.sie_xishu),
                                   self.act_dtype)
-        probs = torch.empty(base.depth, btot, base.heads, t, t, dtype=torch.float32, device=imgs.device)
+        # softmax outputs of every layer; rows padded to a multiple of 4 floats in bf16 mode (16-byte stores)
+        ldp = t if self.act_dtype == torch.float32 else (t + 3) // 4 * 4
+        probs = torch.empty(base.depth, btot, base.heads, t, ldp, dtype=torch.float32, device=imgs.device)
         for i, blk in enumerate(base.blocks):
             rs_a = rs_m = None
             p = base.drop_rates[i]
@@ -305,7 +307,7 @@ class EDITOR(nn.Module):
 
     def _select(self, probs, mask_fre, b):
         """Part_Attention x3 + union with the frequency mask (SFTS.py:145-164,183-187) -> (B,N) uint8."""
-        l, btot, h, t, _ = probs.shape
+        l, btot, h, t = probs.shape[:4]
         scores = ops.attn_rollout(probs)                                        # (3B, h, N)
         m = ops.topk_mask(scores.view(btot * h, t - 1), self.head_k, group=h)    # (3B, N)
         nmod = btot // b

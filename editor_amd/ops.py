@@ -39,10 +39,11 @@ def frequency_mask(rgb, nir, tir, keep):
 
 
 def attn_rollout(probs):
-    """probs: (L, B, H, T, T) fp32 contiguous -> (B, H, T-1) CLS-row rollout scores (SFTS.py:150-153)."""
-    l, b, h, t, _ = probs.shape
+    """probs: (L, B, H, T, ldp) fp32 contiguous (ldp >= T: padded rows) -> (B, H, T-1) CLS-row rollout scores
+    (SFTS.py:150-153)."""
+    l, b, h, t, ldp = probs.shape
     scores = torch.empty(b, h, t - 1, dtype=torch.float32, device=probs.device)
-    call("editor_attn_rollout_f32", probs, l, b * h, t, b * h * t * t, scores)
+    call("editor_attn_rollout_f32", probs, l, b * h, t, ldp, b * h * t * ldp, scores)
     return scores
 
 
@@ -226,8 +227,10 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
         raise TypeError(a.dtype)
 
 
-def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None):
-    """Attention / AttentionMask core on packed qkv (b*t, 3*heads*hd) -> (b*t, heads*hd)."""
+def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True):
+    """Attention / AttentionMask core on packed qkv (b*t, 3*heads*hd) -> (b*t, heads*hd).
+    Returns (out, saved): `saved` is what the backward needs besides qkv/out - the probabilities in fp32 mode,
+    the per-row log-sum-exp in bf16 mode."""
     d = heads * hd
     out = torch.empty(b * t, d, dtype=qkv.dtype, device=qkv.device)
     scale = hd ** -0.5
@@ -235,18 +238,20 @@ def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None):
         if probs is None:
             probs = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
         call("editor_attention_fwd_f32", qkv, b, t, heads, hd, scale, mask, out, probs)
-    else:
-        call("editor_attention_fwd_bf16", qkv, b, t, heads, hd, scale, mask, out, probs)
-    return out, probs
+        return out, probs
+    lse = torch.empty(b * heads * t, dtype=torch.float32, device=qkv.device) if want_lse else None
+    call("editor_attention_fwd_bf16", qkv, b, t, heads, hd, scale, mask, out, probs,
+         0 if probs is None else probs.shape[-1], lse)
+    return out, lse
 
 
-def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, probs=None, out=None):
+def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None):
     dqkv = torch.empty_like(qkv)
     scale = hd ** -0.5
     if qkv.dtype == torch.float32:
         ws = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
-        call("editor_attention_bwd_f32", qkv, dout, probs, b, t, heads, hd, scale, dqkv, ws)
+        call("editor_attention_bwd_f32", qkv, dout, saved, b, t, heads, hd, scale, dqkv, ws)
     else:
-        ws = torch.empty(2 * b * heads * t, dtype=torch.float32, device=qkv.device)
-        call("editor_attention_bwd_bf16", qkv, dout, out, b, t, heads, hd, scale, mask, dqkv, ws)
+        ws = torch.empty(b * heads * t, dtype=torch.float32, device=qkv.device)
+        call("editor_attention_bwd_bf16", qkv, dout, out, saved, b, t, heads, hd, scale, mask, dqkv, ws)
     return dqkv

@@ -45,8 +45,9 @@ int editor_topk_mask_i32(const int32_t* vals, int rows, int n, int k, int group,
 int editor_topk_mask_f32(const float* vals, int rows, int n, int k, int group, uint8_t* mask, editor_stream_t stream);
 
 /* Part_Attention rollout (SFTS.py:150-153): CLS row of A_{L-1} @ ... @ A_0 without the CLS column.
- * probs: L tensors of (BH,T,T) fp32 spaced `layer_stride` floats apart; scores: (BH, T-1) fp32. */
-int editor_attn_rollout_f32(const float* probs, int L, int BH, int T, long layer_stride, float* scores,
+ * probs: L tensors of (BH,T,ldp) fp32 (rows padded to ldp >= T floats) spaced `layer_stride` floats apart;
+ * scores: (BH, T-1) fp32. */
+int editor_attn_rollout_f32(const float* probs, int L, int BH, int T, int ldp, long layer_stride, float* scores,
                             editor_stream_t stream);
 
 /* index = a | b | c | d (SFTS.py:185-187); b, c, d may be NULL. */
@@ -133,13 +134,16 @@ int editor_attention_fwd_f32(const float* qkv, int B, int T, int heads, int hd, 
 int editor_attention_bwd_f32(const float* qkv, const float* dout, const float* probs, int B, int T, int heads, int hd,
                              float scale, float* dqkv, float* workspace, editor_stream_t stream);
 
-/* Fused bf16 form (hd must be 64; T <= 416).  probs optional (NULL skips the write).  Backward recomputes the
- * probabilities; `out` is the forward output (for delta = rowsum(dO*O)); workspace: 2*B*heads*T floats. */
+/* Fused bf16 form (hd must be 64; T <= 416).  probs optional (NULL skips the write).  lse (B*heads*T fp32, log2 units
+ * of the scaled scores, +inf for masked queries) is written by the forward (NULL to skip) and consumed by the backward,
+ * which recomputes the probabilities from it; `out` is the forward output (delta = rowsum(dO*O));
+ * workspace: B*heads*T floats. */
 int editor_attention_fwd_bf16(const uint16_t* qkv, int B, int T, int heads, int hd, float scale, const uint8_t* mask,
-                              uint16_t* out, float* probs, editor_stream_t stream);
-int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, int B, int T, int heads,
-                              int hd, float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace,
+                              uint16_t* out, float* probs, int ldp /* row stride of probs, multiple of 4 */, float* lse,
                               editor_stream_t stream);
+int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, int B,
+                              int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv,
+                              float* workspace, editor_stream_t stream);
 
 /* ---- bring-up probes (tests only) ------------------------------------------------------------- */
 int editor_probe_tr16(const int* addr, uint16_t* out, editor_stream_t stream);
