@@ -9,6 +9,8 @@ Activation dtype: torch.bfloat16 (performance mode, bf16 MFMA with fp32 accumula
 (parity mode, exact-f32 MFMA).  The residual stream, LayerNorm statistics, losses and every parameter
 gradient are fp32 in both modes.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -17,16 +19,22 @@ _BF16_CACHE = {}
 
 
 def act_weight(w, dtype):
-    """fp32 master parameter -> GEMM operand dtype (bf16 copies are cached per parameter version)."""
+    """fp32 master parameter -> GEMM operand dtype.  bf16 copies are cached per parameter OBJECT and re-cast when
+    the parameter's version counter moves (optimizer step, load_state_dict).  The entry holds a weak reference so
+    that a recycled id()/address of a freed parameter can never serve stale weights."""
     if dtype == torch.float32:
         return w.detach()
     key = id(w)
     ent = _BF16_CACHE.get(key)
     ver = w._version
-    if ent is None or ent[0] != ver or ent[1].data_ptr() == 0 or ent[2] != w.data_ptr():
-        ent = (ver, ops.cast(w.detach().contiguous().view(-1), torch.bfloat16).view(w.shape), w.data_ptr())
+    if ent is None or ent[0]() is not w or ent[1] != ver or ent[3] != w.data_ptr():
+        if len(_BF16_CACHE) > 4096:                       # drop entries of dead parameters
+            for k in [k for k, e in _BF16_CACHE.items() if e[0]() is None]:
+                del _BF16_CACHE[k]
+        ent = (weakref.ref(w), ver, ops.cast(w.detach().contiguous().view(-1), torch.bfloat16).view(w.shape),
+               w.data_ptr())
         _BF16_CACHE[key] = ent
-    return ent[1]
+    return ent[2]
 
 
 def _linear_fwd(x2d, w_act, bias, out_dtype):
