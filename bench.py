@@ -145,8 +145,10 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("EDITOR_FORCE_DDP") == "1"      # the flag exercises the RCCL path on 1 GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
 
@@ -162,7 +164,7 @@ def main():
         model = make_model(cfg, num_class, cams)
     synth.fill_state_dict_(model.state_dict(), 1111)
     model = model.to(dev).train()
-    reducer = GradReducer(model)
+    reducer = GradReducer(model, force=use_dist)
     reducer.broadcast_parameters()
 
     # solver/make_optimizer.py:4-29: SGD, momentum 0.9, wd 1e-4, bias lr x2 (BASE_LR 0.001)
@@ -193,14 +195,14 @@ def main():
         step()
     probe = _GemmProbe()
     probe.install()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         probe.recording = rank == 0 and i == args.steps - 1
         loss = step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -208,7 +210,7 @@ def main():
     probe.remove()
     lossv = float(loss.detach())
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
@@ -241,7 +243,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, cfg, cams)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

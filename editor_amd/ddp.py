@@ -16,10 +16,11 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, module, bucket_bytes=64 << 20, process_group=None):
+    def __init__(self, module, bucket_bytes=64 << 20, process_group=None, force=False):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())   # force: run the exchange on 1 rank too
         self.bucket_bytes = bucket_bytes
         self.params = [p for p in module.parameters() if p.requires_grad]
         self._order = []                 # discovery: params in the order their grads became ready
@@ -27,12 +28,14 @@ class GradReducer:
         self._buckets = None             # list of dict(params, flat, pending, handle)
         self._slot = {}                  # id(param) -> (bucket index)
         self._handles = []
+        # RCCL averages in the collective itself; gloo (CPU tests) only sums
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
 
     # ------------------------------------------------------------------------------------------
     def _hook(self, p):
-        if self.world == 1:
+        if not self.active:
             return
         if self._buckets is None:
             if id(p) not in self._seen:
@@ -49,7 +52,8 @@ class GradReducer:
 
     def _launch(self, b):
         torch._foreach_copy_(b["views"], [p.grad for p in b["params"]])
-        b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
         self._handles.append(b)
 
     def _build(self):
@@ -76,7 +80,7 @@ class GradReducer:
     # ------------------------------------------------------------------------------------------
     def finalize(self):
         """Call after loss.backward(): waits for the in-flight buckets and leaves AVERAGED grads in .grad."""
-        if self.world == 1:
+        if not self.active:
             return
         if self._buckets is None:
             # discovery step: nothing was overlapped; build the buckets and reduce them now
@@ -90,7 +94,8 @@ class GradReducer:
         inv = 1.0 / self.world
         for b in self._handles:
             b["handle"].wait()
-            torch._foreach_mul_(b["views"], inv)
+            if not self._avg:
+                torch._foreach_mul_(b["views"], inv)
             torch._foreach_copy_([p.grad for p in b["params"]], b["views"])
             b["handle"] = None
             b["pending"] = len(b["params"])
@@ -98,7 +103,7 @@ class GradReducer:
 
     def broadcast_parameters(self, src=0):
         """Initial sync of parameters and buffers (what DDP's constructor does)."""
-        if self.world == 1:
+        if not self.active:
             return
         for t in list(self.module.parameters()) + list(self.module.buffers()):
             dist.broadcast(t.data, src=src, group=self.group)

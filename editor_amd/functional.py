@@ -243,3 +243,45 @@ class LinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dx, dw, db = _linear_bwd(dy.contiguous(), x.contiguous(), w.detach(), ctx.has_bias)
         return dx, dw, db
+
+
+class BatchNorm1dFn(torch.autograd.Function):
+    """nn.BatchNorm1d (FUSE_BN / BACKBONE_BN / AL_BN, make_model.py:115,120,140); running stats updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, momentum, eps, training):
+        y, sm, si = ops.bn1d_fwd(x, gamma, beta, rmean, rvar, momentum, eps, training)
+        ctx.save_for_backward(x, gamma, sm, si)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, sm, si = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("BatchNorm1dFn.backward in eval mode is not part of the hot path")
+        dx, dg, db = ops.bn1d_bwd(dy.contiguous(), x, gamma, sm, si)
+        return dx, dg, db, None, None, None, None, None
+
+
+class OCFRFn(torch.autograd.Function):
+    """OCFR.forward (OCFR.py:44-84) over the three modalities: returns the summed intra loss and updates the centre
+    tables (non-grad Parameters) in place."""
+
+    @staticmethod
+    def forward(ctx, f_r, f_n, f_t, c_r, c_n, c_t, label, momentum):
+        loss = torch.empty(1, dtype=torch.float32, device=f_r.device)
+        saved = []
+        for i, (f, c) in enumerate(((f_r, c_r), (f_n, c_n), (f_t, c_t))):
+            fn, inv = ops.ocfr_fwd(f, label, c.data, momentum, loss, accumulate=i > 0)
+            saved += [fn, inv, c.data.clone()]      # centres are overwritten by later steps: keep this step's copy
+        ctx.save_for_backward(label, *saved)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        label = ctx.saved_tensors[0]
+        sv = ctx.saved_tensors[1:]
+        dl = dloss.contiguous().view(1).float()
+        grads = [ops.ocfr_bwd(sv[3 * i], sv[3 * i + 1], sv[3 * i + 2], label, dl) for i in range(3)]
+        return grads[0], grads[1], grads[2], None, None, None, None, None

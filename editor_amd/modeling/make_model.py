@@ -337,21 +337,10 @@ class EDITOR(nn.Module):
         return x, loss_ocfr
 
     def _ocfr(self, cls_feats, label):
-        """OCFR.forward (OCFR.py:44-84).  Tiny (3 x (B,D)); host-side tensor ops on device for now."""
+        """OCFR.forward (OCFR.py:44-84): normalise, per-label centre update (momentum 0.8), MSE to own-class centre."""
         mc = self.FUSE_block.memory_cls
-        mom = torch.tensor(self.FUSE_block.momentum, dtype=torch.float32, device=label.device)
-        uniq, inv = torch.unique(label, return_inverse=True)
-        cnt = torch.bincount(inv, minlength=uniq.numel()).clamp_min(1).unsqueeze(1).float()
-        loss = 0.0
-        for f, name in zip(cls_feats, ("RGB", "NIR", "TIR")):
-            centers = getattr(mc, name + "_centers")
-            fnorm = F.normalize(f, dim=1)
-            with torch.no_grad():
-                batch_c = torch.zeros(uniq.numel(), f.shape[1], device=f.device).index_add_(0, inv, fnorm) / cnt
-                centers[uniq] = mom * batch_c + (1 - mom) * centers[uniq]
-                target = centers[uniq][inv]
-            loss = loss + F.mse_loss(target, fnorm)
-        return loss
+        return fn.OCFRFn.apply(cls_feats[0], cls_feats[1], cls_feats[2], mc.RGB_centers, mc.NIR_centers, mc.TIR_centers,
+                               label.contiguous(), float(self.FUSE_block.momentum))
 
     # -- forward (make_model.py:150-258) ----------------------------------------------------------
     def forward(self, x, cam_label=None, label=None, view_label=None, img_path=None, mode=1, writer=None, epoch=None):
@@ -400,7 +389,10 @@ class EDITOR(nn.Module):
                 aux_loss)
 
     def _bn(self, bn, x):
-        return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, self.training, bn.momentum, bn.eps)
+        if self.training:
+            bn.num_batches_tracked += 1
+        return fn.BatchNorm1dFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                      self.training)
 
 
 def make_model(cfg, num_class, camera_num):

@@ -255,3 +255,51 @@ def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None):
         ws = torch.empty(b * heads * t, dtype=torch.float32, device=qkv.device)
         call("editor_attention_bwd_bf16", qkv, dout, out, saved, b, t, heads, hd, scale, mask, dqkv, ws)
     return dqkv
+
+
+# ---------------------------------------------------------------------------------------------
+# head kernels
+# ---------------------------------------------------------------------------------------------
+def _rows_view(x):
+    """(B, C) view with unit column stride -> (tensor, row stride)."""
+    assert x.dim() == 2 and x.stride(1) == 1, "head kernels need unit column stride"
+    return x, x.stride(0)
+
+
+def bn1d_fwd(x, gamma, beta, rmean, rvar, momentum, eps, training):
+    x, ldx = _rows_view(x)
+    b, c = x.shape
+    y = torch.empty(b, c, dtype=torch.float32, device=x.device)
+    sm = torch.empty(c, dtype=torch.float32, device=x.device) if training else None
+    si = torch.empty(c, dtype=torch.float32, device=x.device) if training else None
+    call("editor_bn1d_fwd", _ptr(x), ldx, b, c, gamma, beta, rmean, rvar, float(momentum), float(eps),
+         1 if training else 0, y, sm, si)
+    return y, sm, si
+
+
+def bn1d_bwd(dy, x, gamma, sm, si):
+    x, ldx = _rows_view(x)
+    b, c = x.shape
+    dx = torch.empty(b, c, dtype=torch.float32, device=x.device)
+    dg = torch.empty(c, dtype=torch.float32, device=x.device)
+    db = torch.empty(c, dtype=torch.float32, device=x.device)
+    call("editor_bn1d_bwd", dy, _ptr(x), ldx, b, c, gamma, sm, si, dx, dg, db)
+    return dx, dg, db
+
+
+def ocfr_fwd(feat, label, centers, momentum, loss, accumulate):
+    feat, ldf = _rows_view(feat)
+    b, d = feat.shape
+    fn = torch.empty(b, d, dtype=torch.float32, device=feat.device)
+    inv = torch.empty(b, dtype=torch.float32, device=feat.device)
+    ws = workspace(feat.device, b)
+    call("editor_ocfr_fwd", _ptr(feat), ldf, label, b, d, centers.shape[0], centers, float(momentum), fn, inv, ws, loss,
+         1 if accumulate else 0)
+    return fn, inv
+
+
+def ocfr_bwd(fn, inv, centers, label, dloss):
+    b, d = fn.shape
+    df = torch.empty(b, d, dtype=torch.float32, device=fn.device)
+    call("editor_ocfr_bwd", fn, inv, centers, label, dloss, b, d, df)
+    return df

@@ -145,6 +145,23 @@ int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const u
                               int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv,
                               float* workspace, editor_stream_t stream);
 
+/* ---- head kernels ------------------------------------------------------------------------------------ */
+
+/* nn.BatchNorm1d on (B,C) rows with row stride ldx (make_model.py:115,120,140).  training: batch statistics, running
+ * stats updated in place (momentum, unbiased variance); eval: running stats.  save_mean/save_invstd: (C), training only. */
+int editor_bn1d_fwd(const float* x, long ldx, int B, int C, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, int training, float* y, float* save_mean,
+                    float* save_invstd, editor_stream_t stream);
+int editor_bn1d_bwd(const float* dy, const float* x, long ldx, int B, int C, const float* gamma, const float* save_mean,
+                    const float* save_invstd, float* dx, float* dgamma, float* dbeta, editor_stream_t stream);
+/* OCFR.forward for ONE modality (OCFR.py:44-84): L2-normalise feat rows (row stride ldf), per-label batch mean,
+ * centers[label] = momentum*mean + (1-momentum)*centers[label] in place, loss (+)= MSE(centers[label_b], fnorm_b).
+ * fnorm (B,D), inv_norm (B): saved for backward.  workspace: B floats. */
+int editor_ocfr_fwd(const float* feat, long ldf, const long* label, int B, int D, int C, float* centers, float momentum,
+                    float* fnorm, float* inv_norm, float* workspace, float* loss, int accumulate, editor_stream_t stream);
+int editor_ocfr_bwd(const float* fnorm, const float* inv_norm, const float* centers, const long* label,
+                    const float* dloss, int B, int D, float* dfeat, editor_stream_t stream);
+
 /* ---- bring-up probes (tests only) ------------------------------------------------------------- */
 int editor_probe_tr16(const int* addr, uint16_t* out, editor_stream_t stream);
 int editor_probe_mfma16(const float* A, const float* B, float* D, editor_stream_t stream);
