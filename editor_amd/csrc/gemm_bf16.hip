@@ -37,6 +37,8 @@ struct GemmB16Args {
     const float* bias; const float* rowscale;
     int splitk, tiles_m, tiles_n;
     int epilogue; void* aux; long ldaux;     // EDITOR_EPI_* (editor_hip.h)
+    int slabs;                               // split-K partial tiles go to per-split slabs of C (= workspace)
+    int stagger;                             // experiment: start delay (x 8k cycles) of every second workgroup
 };
 
 __device__ __forceinline__ float gelu_f(float a) { return 0.5f * a * (1.f + erff(a * 0.70710678118654752f)); }
@@ -278,6 +280,88 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB16Args g)
     epilogue_store<C_F32, 4>(g, acc, m0 + wm, n0 + wn, lane, blockIdx.y == 0);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// LDS-staged epilogue.  Measured (tools/gemm_bench.py with the stores removed): the direct epilogue above - every
+// lane storing its own 8 / 16 bytes, i.e. 32-byte pieces of 16 different rows per wave instruction - costs 30-45 % of
+// the kernel (590 -> 890-1040 TFLOP/s without it): the store path is issue bound on partial lines.  Here the finished
+// tile is written to LDS in the output dtype (padded rows, conflict-free) and leaves as 16 bytes per lane with the
+// 16/32 lanes of a row covering 256/512 CONTIGUOUS bytes: full 128-byte lines, 4x fewer store instructions.
+// Split-K partial tiles go to per-split slabs of a workspace (plain stores, reduced by a second tiny kernel) instead
+// of fp32 atomics.
+// ---------------------------------------------------------------------------------------------------------
+// The accumulators are parked in LDS as raw fp32 (padded rows), then a ROLLED loop - 8 output columns per lane per
+// trip - applies alpha / bias / row scale / residual / GELU and stores 16 bytes (bf16) or 2 x 16 bytes (fp32) per lane,
+// the 16 lanes of a tile row covering 256 / 512 contiguous bytes.  Keeping the math in a rolled loop matters: the fully
+// unrolled per-fragment epilogue is ~10k straight-line instructions executed once per tile, i.e. always instruction-cache
+// cold (measured: ~5.5 us per tile even with the global stores removed).
+template <bool C_F32, int MT, int PBM, int PBN, int NTHREADS>
+__device__ __forceinline__ void epilogue_staged(const GemmB16Args& g, float4_t (&acc)[MT][4], char* lds, int m0, int n0,
+                                                int wm, int wn, int lane, int split)
+{
+    constexpr int RBP = PBN * 4 + 16;                          // padded fp32 row: consecutive rows shift by 4 banks
+    const int li = lane & 15, lg = lane >> 4;
+    __syncthreads();                                            // every wave is done with the operand stages
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4_t*>(lds + (wm + i * 16 + li) * RBP + (wn + j * 16 + lg * 4) * 4) = acc[i][j];
+    __syncthreads();
+    constexpr int GPR = PBN / 8;                                // 8-column groups per tile row
+    constexpr int TOTAL = PBM * GPR;
+    const bool add_bias = g.bias && split == 0;
+    float* Cf = C_F32 ? reinterpret_cast<float*>(g.C) + (g.splitk > 1 ? (long)split * g.M * g.ldc : 0L) : nullptr;
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll 4
+    for (int c = threadIdx.x; c < TOTAL; c += NTHREADS) {
+        const int row = c / GPR, cg = c % GPR;
+        const int m = m0 + row, n = n0 + cg * 8;
+        if (m >= g.M || n >= g.N) continue;                      // N is a multiple of 8 on this path (checked on the host)
+        const float4 lo = *reinterpret_cast<const float4*>(lds + row * RBP + cg * 32);
+        const float4 hi = *reinterpret_cast<const float4*>(lds + row * RBP + cg * 32 + 16);
+        float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const float rs = g.rowscale ? g.rowscale[m] : 1.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            x[e] *= g.alpha;
+            if (add_bias) x[e] += g.bias[n + e];
+            x[e] *= rs;
+        }
+        if (g.epilogue == EDITOR_EPI_RESIDUAL) {
+            const float* r = reinterpret_cast<const float*>(g.aux) + (long)m * g.ldaux + n;
+            const float4 r0 = *reinterpret_cast<const float4*>(r), r1 = *reinterpret_cast<const float4*>(r + 4);
+            x[0] += r0.x; x[1] += r0.y; x[2] += r0.z; x[3] += r0.w; x[4] += r1.x; x[5] += r1.y; x[6] += r1.z; x[7] += r1.w;
+        } else if (g.epilogue == EDITOR_EPI_GELU) {             // aux <- pre-activation (bf16), C <- gelu(rounded pre-activation)
+            uint4 p;
+            p.x = pack_bf16x2(x[0], x[1]); p.y = pack_bf16x2(x[2], x[3]); p.z = pack_bf16x2(x[4], x[5]); p.w = pack_bf16x2(x[6], x[7]);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = p;
+            const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[2 * e] = gelu_f(__uint_as_float(pw[e] << 16));
+                x[2 * e + 1] = gelu_f(__uint_as_float(pw[e] & 0xffff0000u));
+            }
+        } else if (g.epilogue == EDITOR_EPI_GELU_BWD) {
+            const uint4 p = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ldaux + n);
+            const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[2 * e] *= gelu_grad_f(__uint_as_float(pw[e] << 16));
+                x[2 * e + 1] *= gelu_grad_f(__uint_as_float(pw[e] & 0xffff0000u));
+            }
+        }
+        if (C_F32) {
+            float* o = Cf + (long)m * g.ldc + n;
+            *reinterpret_cast<float4*>(o) = make_float4(x[0], x[1], x[2], x[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(x[4], x[5], x[6], x[7]);
+        } else {
+            uint4 o;
+            o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]); o.z = pack_bf16x2(x[4], x[5]); o.w = pack_bf16x2(x[6], x[7]);
+            *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = o;
+        }
+    }
+}
+
 // =====================================================================================================
 // Pipelined large-tile variant (the performance path).  A 128x128 tile moves 64 FLOP per byte staged into LDS and is
 // bound by L2->CU bandwidth at ~25 % of the MFMA peak (measured: 49 % of wave cycles in s_waitcnt/barrier, 0 LDS bank
@@ -289,7 +373,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB16Args g)
 //   * grouped tile order inside each XCD's tile range (GM tile-rows x all tile-columns, column-major) so the resident
 //     workgroups of an XCD share few A and B panels (both fit its 4 MiB L2)
 // =====================================================================================================
-constexpr int PBM = 256;
 
 template <bool KMAJOR, int ROWS_OR_COLS>
 __device__ __forceinline__ void pstage_glds(const bf16_t* __restrict__ P, long ld, int r0, int k0, int R, char* lds,
@@ -336,12 +419,12 @@ __device__ __forceinline__ short8_t pload_frag(const char* lds, int base16, int 
     }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool C_F32, int PBN, int STAGES>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_pipe_kernel(GemmB16Args g)
+template <bool A_KMAJOR, bool B_KMAJOR, bool C_F32, int PBM, int PBN, int STAGES, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64, 2) void gemm_bf16_pipe_kernel(GemmB16Args g)
 {
     constexpr int PA_BYTES = PBM * BK * 2, PB_BYTES = PBN * BK * 2, PSTAGE = PA_BYTES + PB_BYTES;
-    constexpr int WAVES_N = PBN / 64, WAVES_M = 8 / WAVES_N, WM = PBM / WAVES_M, MT = WM / 16;
-    constexpr int A_PIECES = PA_BYTES / 1024 / 8, B_PIECES = PB_BYTES / 1024 / 8, PIECES = A_PIECES + B_PIECES;
+    constexpr int WAVES_N = PBN / 64, WAVES_M = NWAVES / WAVES_N, WM = PBM / WAVES_M, MT = WM / 16;
+    constexpr int A_PIECES = PA_BYTES / 1024 / NWAVES, B_PIECES = PB_BYTES / 1024 / NWAVES, PIECES = A_PIECES + B_PIECES;
     constexpr int GM = PBN == 256 ? 4 : 4;                     // tile-rows per group
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- tile order: XCD-contiguous ranges, grouped (GM rows x all columns, column-major) inside --------------
@@ -363,6 +446,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pipe_kernel(GemmB16Args g)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const int wm = (w / WAVES_N) * WM, wn = (w % WAVES_N) * 64;
+    // Two co-resident workgroups of a CU start half a tile period apart, so that one drains its output tile to HBM
+    // while the other feeds the matrix core (identical tiles otherwise keep every CU of the chip in lockstep and the
+    // chip alternates between an MFMA phase and an HBM-write-bound store phase).
+    if (g.stagger && g.stagger != 99 && ((bid >> 8) & 1) && bid < 512) {
+        for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     float4_t acc[MT][4];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -506,7 +595,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pipe_kernel(GemmB16Args g)
         mma(fa1, fb1);
     }
 #undef WAIT_LGKM
-    epilogue_store<C_F32, MT>(g, acc, m0 + wm, n0 + wn, lane, blockIdx.y == 0);
+    constexpr bool kStaged = PBM * (PBN * 4 + 16) <= STAGES * PSTAGE;
+    // (the erf-heavy GELU forward epilogue is faster fully unrolled in registers: measured 372 vs 437 us per launch)
+    if (kStaged && g.beta == 0.f && (g.splitk == 1 || g.slabs) && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (g.ldaux & 7) == 0 &&
+        g.epilogue != EDITOR_EPI_GELU)
+        epilogue_staged<C_F32, MT, PBM, PBN, NWAVES * 64>(g, acc, smem, m0, n0, wm, wn, lane, blockIdx.y);
+    else
+        epilogue_store<C_F32, MT>(g, acc, m0 + wm, n0 + wn, lane, blockIdx.y == 0);
 }
 
 __global__ void scale_c_kernel(float* C, long rows, int cols, long ld, float beta)
@@ -532,11 +627,28 @@ int launch(const GemmB16Args& g, hipStream_t stream)
     return 0;
 }
 
-template <bool AK, bool BK_, bool CF, int PBN, int STAGES>
+// out[e] = beta*out[e] + sum_s slab[s][e]   (split-K reduction, deterministic order)
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, long n4, float* __restrict__ out, float beta)
+{
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4*>(slabs)[e];
+        for (int s = 1; s < nsplit; ++s) {
+            const float4 b = reinterpret_cast<const float4*>(slabs)[(long)s * n4 + e];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (beta != 0.f) {
+            const float4 o = reinterpret_cast<float4*>(out)[e];
+            a.x += beta * o.x; a.y += beta * o.y; a.z += beta * o.z; a.w += beta * o.w;
+        }
+        reinterpret_cast<float4*>(out)[e] = a;
+    }
+}
+
+template <bool AK, bool BK_, bool CF, int PBM, int PBN, int STAGES, int NWAVES>
 int launch_pipe_t(GemmB16Args g, hipStream_t stream)
 {
     constexpr int LDS = STAGES * (PBM + PBN) * BK * 2;
-    auto kern = gemm_bf16_pipe_kernel<AK, BK_, CF, PBN, STAGES>;
+    auto kern = gemm_bf16_pipe_kernel<AK, BK_, CF, PBM, PBN, STAGES, NWAVES>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -545,7 +657,7 @@ int launch_pipe_t(GemmB16Args g, hipStream_t stream)
     }
     g.tiles_m = (g.M + PBM - 1) / PBM;
     g.tiles_n = (g.N + PBN - 1) / PBN;
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(512), LDS, stream, g);
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(NWAVES * 64), LDS, stream, g);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }
@@ -559,17 +671,18 @@ int launch_pipe(const GemmB16Args& g, hipStream_t stream)
     // shape (the 2-stage pipeline exposes DMA latency); keep 256x256 opt-in until it gets a half-tile schedule.
     const bool wide = getenv("EDITOR_GEMM_WIDE") && g.N >= 256 && (g.N % 256 == 0 || g.N >= 1024) &&
                       (t256 >= 1024 || (t256 % 256 == 0) || (t256 % 256) >= 160);
-    if (wide) return launch_pipe_t<AK, BK_, CF, 256, 2>(g, stream);
-    return launch_pipe_t<AK, BK_, CF, 128, 3>(g, stream);
+    if (wide) return launch_pipe_t<AK, BK_, CF, 256, 256, 2, 8>(g, stream);
+    // 128x128, 2 stages, 4 waves: 64 KiB -> two workgroups per CU, one's prologue/epilogue under the other's main loop
+    if (getenv("EDITOR_GEMM_SMALL")) return launch_pipe_t<AK, BK_, CF, 128, 128, 2, 4>(g, stream);
+    return launch_pipe_t<AK, BK_, CF, 256, 128, 3, 8>(g, stream);
 }
 
 }  // namespace
 
 extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda,
     long ldb, long ldc, int transA, int transB, float alpha, float beta, const float* bias, const float* rowscale,
-    int splitk, int epilogue, void* aux, long ldaux, hipStream_t stream)
+    int splitk, int epilogue, void* aux, long ldaux, float* splitk_ws, hipStream_t stream)
 {
-    if (epilogue != EDITOR_EPI_NONE && (!aux || (ldaux & 3) || splitk > 1)) return (int)hipErrorInvalidValue;
     if (M <= 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
     // 16-byte vector accesses: leading dimensions and the contiguous extents must be multiples of 8 bf16
     if ((lda & 7) || (ldb & 7) || (N & 3) || (ldc & 3)) return (int)hipErrorInvalidValue;
@@ -579,35 +692,49 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
     if (transB && (N & 7)) return (int)hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15)
         return (int)hipErrorInvalidValue;
+    if (epilogue != EDITOR_EPI_NONE && (!aux || (ldaux & 3) || splitk > 1)) return (int)hipErrorInvalidValue;
     if (splitk < 1) splitk = 1;
     const int ktiles = (K + BK - 1) / BK;
     if (splitk > ktiles) splitk = ktiles;
-    if (splitk > 1) {
-        if (!c_f32) return (int)hipErrorInvalidValue;
-        if (beta != 1.f) {
-            hipLaunchKernelGGL(scale_c_kernel, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, stream,
-                               (float*)C, (long)M, N, ldc, beta);
-            EDITOR_LAUNCH_CHECK();
-        }
-    }
-    GemmB16Args g{(const bf16_t*)A, (const bf16_t*)B, C, M, N, K, lda, ldb, ldc, alpha, beta, bias, rowscale, splitk,
-                  (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux};
+    if (splitk > 1 && !c_f32) return (int)hipErrorInvalidValue;
     // direct-to-LDS staging needs whole BK tiles along the reduction and >= 8 valid elements to clamp to
     const bool glds = (K % BK == 0) && M >= 8 && N >= 8 && !getenv("EDITOR_GEMM_NO_GLDS");
-    const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
     // large problems: 3-stage LDS-DMA pipeline (256x128 tiles)
     const bool pipe = glds && M >= 256 && N >= 128 && !getenv("EDITOR_GEMM_NO_PIPE");
+    // split-K: per-split slabs in the workspace + a reduction kernel (pipelined path), else fp32 atomics into C
+    const bool slabs = splitk > 1 && pipe && splitk_ws && ldc == N && (((long)M * N) & 3) == 0 &&
+                       (reinterpret_cast<uintptr_t>(splitk_ws) & 15) == 0;
+    if (splitk > 1 && !slabs && beta != 1.f) {
+        hipLaunchKernelGGL(scale_c_kernel, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, stream,
+                           (float*)C, (long)M, N, ldc, beta);
+        EDITOR_LAUNCH_CHECK();
+    }
+    GemmB16Args g{(const bf16_t*)A, (const bf16_t*)B, slabs ? (void*)splitk_ws : C, M, N, K, lda, ldb, ldc, alpha,
+                  slabs ? 0.f : beta, bias, rowscale, splitk, (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux,
+                  slabs ? 1 : 0, getenv("EDITOR_GEMM_STAGGER") ? atoi(getenv("EDITOR_GEMM_STAGGER")) : 0};
+    const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
+    int rc;
     if (pipe) {
         switch (sel) {
-            case 7: return launch_pipe<true, true, true>(g, stream);
-            case 6: return launch_pipe<true, true, false>(g, stream);
-            case 5: return launch_pipe<true, false, true>(g, stream);
-            case 4: return launch_pipe<true, false, false>(g, stream);
-            case 3: return launch_pipe<false, true, true>(g, stream);
-            case 2: return launch_pipe<false, true, false>(g, stream);
-            case 1: return launch_pipe<false, false, true>(g, stream);
-            default: return launch_pipe<false, false, false>(g, stream);
+            case 7: rc = launch_pipe<true, true, true>(g, stream); break;
+            case 6: rc = launch_pipe<true, true, false>(g, stream); break;
+            case 5: rc = launch_pipe<true, false, true>(g, stream); break;
+            case 4: rc = launch_pipe<true, false, false>(g, stream); break;
+            case 3: rc = launch_pipe<false, true, true>(g, stream); break;
+            case 2: rc = launch_pipe<false, true, false>(g, stream); break;
+            case 1: rc = launch_pipe<false, false, true>(g, stream); break;
+            default: rc = launch_pipe<false, false, false>(g, stream); break;
         }
+        if (rc) return rc;
+        if (slabs) {
+            const long n4 = (long)M * N / 4;
+            long blocks = (n4 + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, splitk_ws, splitk, n4,
+                               (float*)C, beta);
+            EDITOR_LAUNCH_CHECK();
+        }
+        return 0;
     }
 #define GEMM_CASE(n, a, b, c) case n: return glds ? launch<a, b, c, true>(g, stream) : launch<a, b, c, false>(g, stream)
     switch (sel) {

@@ -222,7 +222,7 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
         assert b.dtype == torch.bfloat16
         call("editor_gemm_bf16", _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), 1 if c.dtype == torch.float32 else 0,
              m, n, k, lda, ldb, ldc, int(trans_a), int(trans_b), float(alpha), float(beta), bias, rowscale, int(splitk),
-             int(epilogue), aux, n)
+             int(epilogue), aux, n, workspace(a.device, int(splitk) * m * n) if splitk > 1 else None)
     else:
         raise TypeError(a.dtype)
 

@@ -124,6 +124,7 @@ int editor_gemm_f32(const float* A, const float* B, float* C, int M, int N, int 
 int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda, long ldb,
                      long ldc, int transA, int transB, float alpha, float beta, const float* bias,
                      const float* rowscale, int splitk, int epilogue, void* aux, long ldaux,
+                     float* splitk_ws /* splitk*M*N floats or NULL (then split-K uses fp32 atomics) */,
                      editor_stream_t stream);
 
 /* Attention.forward / AttentionMask.forward on packed qkv rows (B*T, 3*heads*hd) (vit_pytorch.py:184-198,240-258).
