@@ -89,6 +89,8 @@ struct AttnArgs {
     const uint8_t* mask;
     int T, heads; float scale;
     int ldp;                              // row stride (floats) of the probability output, multiple of 4
+    const int* cu;                        // varlen: sequence b owns packed rows [cu[b], cu[b+1]); NULL = dense (b*T)
+    long Mtot;                            // total packed rows (lse / delta are laid out [heads][Mtot])
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -109,12 +111,15 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
     constexpr int Tp = NT * 16;
     char* kimg = smem;
     char* vimg = smem + Tp * ROWB;
-    const int T = a.T, D = a.heads * HD;
+    const int D = a.heads * HD;
     const int b = blockIdx.x / a.heads, hh = blockIdx.x % a.heads;
     const long ld = 3L * D;
-    const bf16_t* qbase = a.qkv + (long)b * T * ld + hh * HD;
-    load_image(kimg, qbase + D, ld, T, Tp);
-    load_image(vimg, qbase + 2 * D, ld, T, Tp);
+    const long row0 = a.cu ? (long)a.cu[b] : (long)b * a.T;         // first packed row of this sequence
+    const int T = a.cu ? a.cu[b + 1] - a.cu[b] : a.T;               // its length
+    const int nt = min(NT, ((T + 31) >> 5) << 1);                   // key tiles actually populated (even count)
+    const bf16_t* qbase = a.qkv + row0 * ld + hh * HD;
+    load_image(kimg, qbase + D, ld, T, nt * 16);
+    load_image(vimg, qbase + 2 * D, ld, T, nt * 16);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -132,7 +137,8 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
             if (ok) { if (bit < 64) kv0 |= 1ull << bit; else kv1 |= 1ull << (bit - 64); }
         }
     const float sc = a.scale * kLog2e;
-    const long row_idx0 = ((long)b * a.heads + hh) * T;
+    const long row_idx0 = (long)hh * a.Mtot + row0;                // lse / delta index of row 0
+    const long prow0 = ((long)b * a.heads + hh) * a.T;             // probability rows (dense mode only)
 
     for (int q0 = w * 16; q0 < T; q0 += nw * 16) {
         const int q = q0 + li;
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
             // ---- sweep 1: online max / sum over this lane's keys, then across the 4 lane groups ------------------
             float m = -INFINITY, l = 0.f;
 #pragma unroll 2
-            for (int t = 0; t < NT; ++t) {
+            for (int t = 0; t < nt; ++t) {
                 float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
@@ -170,8 +176,8 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
         float dl = 0.f;
         short8_t dof[2];
         if (BWD) {   // delta[q] = sum_d dO[q,d] * O[q,d]
-            const bf16_t* dobase = a.dout + (long)b * T * D + hh * HD;
-            const bf16_t* obase = a.out_fwd + (long)b * T * D + hh * HD;
+            const bf16_t* dobase = a.dout + row0 * D + hh * HD;
+            const bf16_t* obase = a.out_fwd + row0 * D + hh * HD;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 dof[s] = frag_own(dobase, D, q0, T, s, lane);
@@ -183,14 +189,14 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
             if (lg == 0 && q < T) a.delta[row_idx0 + q] = dl;
         }
         // probability rows are padded to a multiple of 4 floats so that each lane's 4 consecutive keys are ONE 16-byte store
-        float* pr = (!BWD && a.probs && q < T) ? a.probs + (row_idx0 + q) * a.ldp : nullptr;
+        float* pr = (!BWD && a.probs && q < T) ? a.probs + (prow0 + q) * a.ldp : nullptr;
 
         // ---- sweep 2: P^T tiles from lse; FWD: O^T += V^T P^T ; BWD: dS^T, dQ^T += K^T dS^T ----------------------
         float4_t o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-        for (int s2 = 0; s2 < NT / 2; ++s2) {
+        for (int s2 = 0; s2 < nt / 2; ++s2) {
             uint2 pk[2];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -221,8 +227,8 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(timg, s2, dt, lane), pf, o[dt], 0, 0, 0);
         }
         if (q < T) {
-            bf16_t* orow = BWD ? a.dqkv + ((long)b * T + q) * ld + hh * HD + 4 * lg
-                               : a.out + ((long)b * T + q) * D + hh * HD + 4 * lg;
+            bf16_t* orow = BWD ? a.dqkv + (row0 + q) * ld + hh * HD + 4 * lg
+                               : a.out + (row0 + q) * D + hh * HD + 4 * lg;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 *reinterpret_cast<uint2*>(orow + dt * 16) = pack4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
@@ -242,15 +248,18 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
     char* doimg = smem + Tp * ROWB;
     float* lse_s = reinterpret_cast<float*>(smem + 2 * Tp * ROWB);
     float* dl_s = lse_s + Tp;
-    const int T = a.T, D = a.heads * HD;
+    const int D = a.heads * HD;
     const int b = blockIdx.x / a.heads, hh = blockIdx.x % a.heads;
     const long ld = 3L * D;
-    const bf16_t* qbase = a.qkv + (long)b * T * ld + hh * HD;
-    load_image(qimg, qbase, ld, T, Tp);
-    load_image(doimg, a.dout + (long)b * T * D + hh * HD, D, T, Tp);
+    const long row0 = a.cu ? (long)a.cu[b] : (long)b * a.T;
+    const int T = a.cu ? a.cu[b + 1] - a.cu[b] : a.T;
+    const int nt = min(NT, ((T + 31) >> 5) << 1);
+    const bf16_t* qbase = a.qkv + row0 * ld + hh * HD;
+    load_image(qimg, qbase, ld, T, nt * 16);
+    load_image(doimg, a.dout + row0 * D + hh * HD, D, T, nt * 16);
     const uint8_t* mk = a.mask ? a.mask + (long)b * T : nullptr;
     for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
-        const long idx = ((long)b * a.heads + hh) * T + t;
+        const long idx = (long)hh * a.Mtot + row0 + t;
         const bool ok = t < T && (!mk || mk[t]);
         lse_s[t] = ok ? a.lse[idx] : INFINITY;
         dl_s[t] = ok ? a.delta[idx] : 0.f;
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dv[dt] = float4_t{0.f, 0.f, 0.f, 0.f}; dk[dt] = dv[dt]; }
 #pragma unroll 1
-        for (int u2 = 0; u2 < NT / 2; ++u2) {
+        for (int u2 = 0; u2 < nt / 2; ++u2) {
             uint2 pk[2], dsk[2];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
             }
         }
         if (key < T) {
-            bf16_t* krow = a.dqkv + ((long)b * T + key) * ld + D + hh * HD + 4 * lg;
+            bf16_t* krow = a.dqkv + (row0 + key) * ld + D + hh * HD + 4 * lg;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 *reinterpret_cast<uint2*>(krow + dt * 16) = pack4(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
@@ -368,18 +377,22 @@ int dispatch(const AttnArgs& a, int B, int mode, hipStream_t stream)
 
 extern "C" int editor_attention_fwd_bf16(const uint16_t* qkv, int B, int T, int heads, int hd, float scale,
                                          const uint8_t* mask, uint16_t* out, float* probs, int ldp, float* lse,
-                                         hipStream_t stream)
+                                         const int* cu, long Mtot, hipStream_t stream)
 {
     if (hd != HD || T < 1 || B < 1) return (int)hipErrorInvalidValue;
-    if (probs && (ldp < T || (ldp & 3) || (reinterpret_cast<uintptr_t>(probs) & 15))) return (int)hipErrorInvalidValue;
-    AttnArgs a{qkv, nullptr, nullptr, out, nullptr, probs, lse, nullptr, mask, T, heads, scale, ldp};
+    if (probs && (ldp < T || (ldp & 3) || (reinterpret_cast<uintptr_t>(probs) & 15) || cu)) return (int)hipErrorInvalidValue;
+    if (cu && mask) return (int)hipErrorInvalidValue;             // packed sequences hold only live tokens
+    if (!cu) Mtot = (long)B * T;
+    AttnArgs a{qkv, nullptr, nullptr, out, nullptr, probs, lse, nullptr, mask, T, heads, scale, ldp, cu, Mtot};
     return dispatch(a, B, 0, stream);
 }
 
 extern "C" int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse,
-    int B, int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace, hipStream_t stream)
+    int B, int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace, const int* cu,
+    long Mtot, hipStream_t stream)
 {
-    if (hd != HD || T < 1 || B < 1 || !workspace || !lse) return (int)hipErrorInvalidValue;
-    AttnArgs a{qkv, dout, out, nullptr, dqkv, nullptr, const_cast<float*>(lse), workspace, mask, T, heads, scale, 0};
+    if (hd != HD || T < 1 || B < 1 || !workspace || !lse || (cu && mask)) return (int)hipErrorInvalidValue;
+    if (!cu) Mtot = (long)B * T;
+    AttnArgs a{qkv, dout, out, nullptr, dqkv, nullptr, const_cast<float*>(lse), workspace, mask, T, heads, scale, 0, cu, Mtot};
     return dispatch(a, B, 1, stream);
 }

@@ -39,6 +39,8 @@ struct GemmB16Args {
     int epilogue; void* aux; long ldaux;     // EDITOR_EPI_* (editor_hip.h)
     int slabs;                               // split-K partial tiles go to per-split slabs of C (= workspace)
     int stagger;                             // experiment: start delay (x 8k cycles) of every second workgroup
+    const int* m_live;                       // device scalar: only the first *m_live token rows are live (NULL: all)
+    int live_is_k;                           // the token-row extent is the reduction (wgrad) instead of M
 };
 
 __device__ __forceinline__ float gelu_f(float a) { return 0.5f * a * (1.f + erff(a * 0.70710678118654752f)); }
@@ -437,11 +439,16 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void gemm_bf16_pipe_kernel(GemmB16A
     const int gsz = min(GM, g.tiles_m - gm0);
     const int tile_m = gm0 + rem % gsz, tile_n = rem / gsz;
     const int m0 = tile_m * PBM, n0 = tile_n * PBN;
-    const int ktiles = g.K / BK;
+    // compacted HMA: the host launches for the worst-case row count, the live extent is a device scalar
+    int ktiles = g.K / BK;
+    if (g.m_live) {
+        const int live = *g.m_live;
+        if (g.live_is_k) ktiles = min(ktiles, (live + BK - 1) / BK);      // rows in [live, roundup) are zero by contract
+        else if (m0 >= live) return;                                        // tile of dead rows: nobody reads them
+    }
     const int per = (ktiles + g.splitk - 1) / g.splitk;
     const int kt0 = blockIdx.y * per, kt1 = min(ktiles, kt0 + per);
-    if (kt0 >= kt1) return;
-    const int nk = kt1 - kt0;
+    const int nk = max(kt1 - kt0, 0);                                       // (an empty split still writes its zero slab)
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(w);
@@ -556,14 +563,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void gemm_bf16_pipe_kernel(GemmB16A
 #pragma unroll
     for (int d = 0; d < STAGES; ++d)
         if (d < nk) issue(d);
-    {   // tile 0 landed (later tiles may still be in flight)
+    if (nk > 0) {   // tile 0 landed (later tiles may still be in flight)
         const int later = min(nk - 1, STAGES - 1);
         if (later >= 2)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
         else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
         else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    load_frags(fa0, fb0, 0, 0);
+    if (nk > 0) load_frags(fa0, fb0, 0, 0);
     int t = 0;
     // steady state (tile t+STAGES exists)
     for (; t + STAGES < nk; ++t) {
@@ -681,7 +688,7 @@ int launch_pipe(const GemmB16Args& g, hipStream_t stream)
 
 extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda,
     long ldb, long ldc, int transA, int transB, float alpha, float beta, const float* bias, const float* rowscale,
-    int splitk, int epilogue, void* aux, long ldaux, float* splitk_ws, hipStream_t stream)
+    int splitk, int epilogue, void* aux, long ldaux, float* splitk_ws, const int* m_live, hipStream_t stream)
 {
     if (M <= 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
     // 16-byte vector accesses: leading dimensions and the contiguous extents must be multiples of 8 bf16
@@ -711,7 +718,9 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
     }
     GemmB16Args g{(const bf16_t*)A, (const bf16_t*)B, slabs ? (void*)splitk_ws : C, M, N, K, lda, ldb, ldc, alpha,
                   slabs ? 0.f : beta, bias, rowscale, splitk, (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux,
-                  slabs ? 1 : 0, getenv("EDITOR_GEMM_STAGGER") ? atoi(getenv("EDITOR_GEMM_STAGGER")) : 0};
+                  slabs ? 1 : 0, getenv("EDITOR_GEMM_STAGGER") ? atoi(getenv("EDITOR_GEMM_STAGGER")) : 0,
+                  m_live, transA ? 1 : 0};
+    if (m_live && (!pipe || (splitk > 1 && !slabs))) return (int)hipErrorInvalidValue;   // live-row form: pipelined path only
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
     int rc;
     if (pipe) {

@@ -37,10 +37,11 @@ constexpr int kMaxV = 4;   // float4 chunks per lane: D <= 64*4*4 = 1024
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, long M, int D, const uint8_t* __restrict__ rowmask, int mask_period,
-    T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out)
+    T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, const int* __restrict__ m_live)
 {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m_live) M = min(M, (long)((*m_live + 63) & ~63));      // live rows, rounded up to the GEMM reduction tile (mask = 0 there)
     if (row >= M) return;
     const int nv = D >> 8;                       // D / (64*4)
     const float* xr = x + row * D;
@@ -84,9 +85,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ mean_in, const float* __restrict__ rstd_in, long M, int D,
     const uint8_t* __restrict__ rowmask, int mask_period, const float* __restrict__ dx_in, float* __restrict__ dx_out,
-    float* __restrict__ partials)
+    float* __restrict__ partials, const int* __restrict__ m_live)
 {
     __shared__ float red[4][2][1024];
+    if (m_live) M = min(M, (long)((*m_live + 63) & ~63));
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nv = D >> 8;
     float4 g[kMaxV], dg[kMaxV], db[kMaxV];
@@ -234,9 +236,10 @@ __global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, lon
 // out[m,:] = in[m,:] * rowscale[m]  (fp32 -> activation dtype): gradient of a drop-path-scaled branch
 template <typename TO>
 __global__ void cast_rows_kernel(const float* __restrict__ in, const float* __restrict__ rowscale, long M, int D,
-                                 TO* __restrict__ out)
+                                 TO* __restrict__ out, const int* __restrict__ m_live)
 {
     const int d4 = D >> 2;
+    if (m_live) M = min(M, (long)((*m_live + 63) & ~63));
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < M * d4; e += (long)gridDim.x * blockDim.x) {
         const float r = rowscale ? rowscale[e / d4] : 1.f;
         float4 v = *reinterpret_cast<const float4*>(in + e * 4);
@@ -496,24 +499,25 @@ inline unsigned grid_for(long n, int block = 256, long cap = 256L * 16) {
 #define DISPATCH_T(is_bf16, CALL) do { if (is_bf16) { using TT = bf16_t; CALL; } else { using TT = float; CALL; } } while (0)
 
 extern "C" int editor_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, long M, int D,
-    const uint8_t* rowmask, int mask_period, void* y, int y_bf16, float* mean, float* rstd, hipStream_t stream)
+    const uint8_t* rowmask, int mask_period, void* y, int y_bf16, float* mean, float* rstd, const int* m_live,
+    hipStream_t stream)
 {
     if (D % 256 || D > 1024 || M <= 0) return (int)hipErrorInvalidValue;
     DISPATCH_T(y_bf16, hipLaunchKernelGGL(layernorm_fwd_kernel<TT>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream,
-               x, gamma, beta, eps, M, D, rowmask, mask_period, (TT*)y, mean, rstd));
+               x, gamma, beta, eps, M, D, rowmask, mask_period, (TT*)y, mean, rstd, m_live));
     EDITOR_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int editor_layernorm_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
     const float* rstd, long M, int D, const uint8_t* rowmask, int mask_period, const float* dx_in, float* dx_out,
-    float* dgamma, float* dbeta, float* workspace, int ws_rows, hipStream_t stream)
+    float* dgamma, float* dbeta, float* workspace, int ws_rows, const int* m_live, hipStream_t stream)
 {
     if (D % 256 || D > 1024 || M <= 0 || ws_rows < 1) return (int)hipErrorInvalidValue;
     long blocks = (M + 3) / 4;
     if (blocks > ws_rows) blocks = ws_rows;
     DISPATCH_T(dy_bf16, hipLaunchKernelGGL(layernorm_bwd_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, stream,
-               (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out, dgamma ? workspace : nullptr));
+               (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out, dgamma ? workspace : nullptr, m_live));
     EDITOR_LAUNCH_CHECK();
     if (dgamma) {
         // workspace rows are [block][2][D]: treat as P rows of 2D columns, then split
@@ -584,11 +588,11 @@ extern "C" int editor_cast_bf16_to_f32(const uint16_t* in, float* out, long n, h
 }
 
 extern "C" int editor_cast_rows(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16,
-                                hipStream_t stream)
+                                const int* m_live, hipStream_t stream)
 {
     if (D % 4) return (int)hipErrorInvalidValue;
     DISPATCH_T(out_bf16, hipLaunchKernelGGL(cast_rows_kernel<TT>, dim3(grid_for(M * (D / 4))), dim3(256), 0, stream,
-               in, rowscale, M, D, (TT*)out));
+               in, rowscale, M, D, (TT*)out, m_live));
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

@@ -37,26 +37,26 @@ def act_weight(w, dtype):
     return ent[2]
 
 
-def _linear_fwd(x2d, w_act, bias, out_dtype):
+def _linear_fwd(x2d, w_act, bias, out_dtype, m_live=None):
     """y = x W^T + b;  x (M,K) act dtype, W (N,K)."""
     m, k = x2d.shape
     n = w_act.shape[0]
     y = torch.empty(m, n, dtype=out_dtype, device=x2d.device)
-    ops.gemm(x2d, w_act, y, m, n, k, k, k, n, 0, 0, bias=bias)
+    ops.gemm(x2d, w_act, y, m, n, k, k, k, n, 0, 0, bias=bias, m_live=m_live)
     return y
 
 
-def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None):
+def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None):
     """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy)."""
     m, n = dy.shape
     k = x2d.shape[1]
     dx = torch.empty(m, k, dtype=x2d.dtype, device=dy.device)
     if gelu_pre is None:
-        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1)                   # B stored (Kred=n, Nout=k)
+        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, m_live=m_live)    # B stored (Kred=n, Nout=k)
     else:
-        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=gelu_pre)
+        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=gelu_pre, m_live=m_live)
     dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
-    ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, splitk=_splitk_for(n, k, m))   # both stored (Kred=m, .)
+    ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, splitk=_splitk_for(n, k, m), m_live=m_live)   # both stored (Kred=m, .)
     db = ops.colsum(dy) if need_bias else None
     return dx, dw, db
 
@@ -79,59 +79,67 @@ class TransformerBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, mask, probs_out,
-                heads, eps, act_dtype, rowscale_attn, rowscale_mlp):
-        b, t, d = x.shape
-        m = b * t
+                heads, eps, act_dtype, rowscale_attn, rowscale_mlp, cu=None, max_t=None, m_live=None):
+        # dense: x (B,T,D), mask (B,T) token mask.  packed (compacted HMA): x (M,D), cu (B+1) sequence row ranges,
+        # max_t = longest sequence, mask (M) = 1 for live rows / 0 for the padding rows at the end.
+        if cu is None:
+            b, t, d = x.shape
+        else:
+            b, t, d = cu.numel() - 1, int(max_t), x.shape[1]
+        m = x.numel() // d
         hd = d // heads
         x2d = x.reshape(m, d)
+        amask = None if cu is not None else mask           # packed sequences hold only live tokens
         wq, wp, w1, w2 = (act_weight(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w))
-        h1, mean1, rstd1 = ops.layernorm_fwd(x2d, n1w, n1b, eps, act_dtype, mask, 0)
-        qkv = _linear_fwd(h1, wq, qkvb, act_dtype)
-        ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, mask, probs_out)
+        h1, mean1, rstd1 = ops.layernorm_fwd(x2d, n1w, n1b, eps, act_dtype, mask, 0, m_live=m_live)
+        qkv = _linear_fwd(h1, wq, qkvb, act_dtype, m_live)
+        ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, probs_out, cu=cu)
         x1 = torch.empty_like(x2d)                  # x1 = x + rs * (ao Wp^T + b): residual add in the GEMM epilogue
         ops.gemm(ao, wp, x1, m, d, d, d, d, d, 0, 0, bias=projb, rowscale=rowscale_attn,
-                 epilogue=ops.EPI_RESIDUAL, aux=x2d)
-        h2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, eps, act_dtype, mask, 0)
+                 epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)
+        h2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, eps, act_dtype, mask, 0, m_live=m_live)
         hidden = w1.shape[0]
         a = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
         g = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
-        ops.gemm(h2, w1, g, m, hidden, d, d, d, hidden, 0, 0, bias=fc1b, epilogue=ops.EPI_GELU, aux=a)
+        ops.gemm(h2, w1, g, m, hidden, d, d, d, hidden, 0, 0, bias=fc1b, epilogue=ops.EPI_GELU, aux=a, m_live=m_live)
         x2 = torch.empty_like(x2d)
         ops.gemm(g, w2, x2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b, rowscale=rowscale_mlp,
-                 epilogue=ops.EPI_RESIDUAL, aux=x1)
+                 epilogue=ops.EPI_RESIDUAL, aux=x1, m_live=m_live)
         ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
-                              qkvw, projw, fc1w, fc2w, mask, attn_saved, rowscale_attn, rowscale_mlp)
-        ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None)
-        return x2.view(b, t, d)
+                              qkvw, projw, fc1w, fc2w, mask, attn_saved, rowscale_attn, rowscale_mlp, cu, m_live)
+        ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None,
+                    tuple(x.shape))
+        return x2.view(x.shape)
 
     @staticmethod
     def backward(ctx, dx2):
         (x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w, qkvw, projw, fc1w, fc2w, mask,
-         attn_saved, rs_attn, rs_mlp) = ctx.saved_tensors
-        b, t, d, heads, act_dtype, hb_qkv, hb_proj, hb_fc1, hb_fc2 = ctx.meta
-        m = b * t
+         attn_saved, rs_attn, rs_mlp, cu, m_live) = ctx.saved_tensors
+        b, t, d, heads, act_dtype, hb_qkv, hb_proj, hb_fc1, hb_fc2, xshape = ctx.meta
+        m = x2d.shape[0]
         hd = d // heads
+        amask = None if cu is not None else mask
         wq, wp, w1, w2 = (act_weight(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w))
         dx2 = dx2.contiguous().view(m, d)
         # ---- MLP branch:  x2 = x1 + rs * fc2(gelu(fc1(LN2(x1))))
-        dy = _scaled_cast(dx2, rs_mlp, act_dtype)
-        da, dw2, db2 = _linear_bwd(dy, g, w2, hb_fc2, gelu_pre=a)      # da = (dy W2) * gelu'(a)
-        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1)
-        dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w, mean2, rstd2, mask, 0, dx_in=dx2)
+        dy = _scaled_cast(dx2, rs_mlp, act_dtype, m_live)
+        da, dw2, db2 = _linear_bwd(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live)      # da = (dy W2) * gelu'(a)
+        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live)
+        dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w, mean2, rstd2, mask, 0, dx_in=dx2, m_live=m_live)
         # ---- attention branch:  x1 = x + rs * proj(attn(qkv(LN1(x))))
-        dy = _scaled_cast(dx1, rs_attn, act_dtype)
-        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj)
-        dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, mask, attn_saved, ao)
-        dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv)
-        dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1)
-        return (dx.view(b, t, d), dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2,
-                None, None, None, None, None, None, None)
+        dy = _scaled_cast(dx1, rs_attn, act_dtype, m_live)
+        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live)
+        dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, amask, attn_saved, ao, cu=cu)
+        dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live)
+        dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1, m_live=m_live)
+        return (dx.view(xshape), dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2,
+                None, None, None, None, None, None, None, None, None, None)
 
 
-def _scaled_cast(dx, rowscale, dtype):
+def _scaled_cast(dx, rowscale, dtype, m_live=None):
     if rowscale is None and dx.dtype == dtype:
         return dx
-    return ops.cast_rows(dx, rowscale, dtype)
+    return ops.cast_rows(dx, rowscale, dtype, m_live)
 
 
 class PatchEmbedFn(torch.autograd.Function):
@@ -176,18 +184,18 @@ class LayerNormFn(torch.autograd.Function):
     (out_norm + `x * mask3`, vit_pytorch.py:329-332) or the backbone's final norm (:643)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, eps, mask):
+    def forward(ctx, x, w, b, eps, mask, m_live=None):
         shape = x.shape
         x2d = x.reshape(-1, shape[-1])
-        y, mean, rstd = ops.layernorm_fwd(x2d, w, b, eps, torch.float32, mask, 0)
-        ctx.save_for_backward(x2d, w, mean, rstd, mask)
+        y, mean, rstd = ops.layernorm_fwd(x2d, w, b, eps, torch.float32, mask, 0, m_live=m_live)
+        ctx.save_for_backward(x2d, w, mean, rstd, mask, m_live)
         return y.view(shape)
 
     @staticmethod
     def backward(ctx, dy):
-        x2d, w, mean, rstd, mask = ctx.saved_tensors
-        dx, dw, db = ops.layernorm_bwd(dy.contiguous().view(x2d.shape), x2d, w, mean, rstd, mask, 0)
-        return dx.view(dy.shape), dw, db, None, None
+        x2d, w, mean, rstd, mask, m_live = ctx.saved_tensors
+        dx, dw, db = ops.layernorm_bwd(dy.contiguous().view(x2d.shape), x2d, w, mean, rstd, mask, 0, m_live=m_live)
+        return dx.view(dy.shape), dw, db, None, None, None
 
 
 class SFTSApplyFn(torch.autograd.Function):
@@ -285,3 +293,37 @@ class OCFRFn(torch.autograd.Function):
         dl = dloss.contiguous().view(1).float()
         grads = [ops.ocfr_bwd(sv[3 * i], sv[3 * i + 1], sv[3 * i + 2], label, dl) for i in range(3)]
         return grads[0], grads[1], grads[2], None, None, None, None, None
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """out[r] = x2d[src[r]] (zeros where src[r] < 0): row movement between the dense token tensor and the packed
+    layouts of the compacted HMA head.  Every source row is gathered at most once, so backward is a plain scatter."""
+
+    @staticmethod
+    def forward(ctx, x2d, src, live=None, live_mul=1, live_stride=0):
+        ctx.save_for_backward(src)
+        ctx.rows_in = x2d.shape[0]
+        return ops.gather_rows(x2d.contiguous(), src, live, live_mul, live_stride)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (src,) = ctx.saved_tensors
+        return ops.scatter_rows(dy.contiguous(), src, ctx.rows_in), None, None, None, None
+
+
+class PoolPackedFn(torch.autograd.Function):
+    """make_model.py:186-203 on the sample-major packed layout."""
+
+    @staticmethod
+    def forward(ctx, x2d, cu, b, nmod):
+        out, num = ops.pool_packed_fwd(x2d.contiguous(), cu, b, nmod)
+        ctx.save_for_backward(num, cu)
+        ctx.meta = (b, nmod, x2d.shape[0])
+        ctx.mark_non_differentiable(num)
+        return out, num
+
+    @staticmethod
+    def backward(ctx, dout, _dnum):
+        num, cu = ctx.saved_tensors
+        b, nmod, rows = ctx.meta
+        return ops.pool_packed_bwd(dout.contiguous(), num, cu, b, nmod, rows), None, None, None

@@ -260,6 +260,7 @@ class EDITOR(nn.Module):
             self.AL_BN = nn.BatchNorm1d(3 * dim)
             nn.init.normal_(self.AL_HEAD.weight, std=0.001)
         self.act_dtype = _act_dtype(cfg)
+        self.hma_compact = bool(getattr(cfg.MODEL, "HMA_COMPACT", True))
         self.teacher_index = None            # optional (B,N) bool: force the SFTS selection (bf16 protocol)
         self.last_aux = {}
 
@@ -336,6 +337,33 @@ class EDITOR(nn.Module):
         x = fn.LayerNormFn.apply(x, fb.out_norm.weight, fb.out_norm.bias, 1e-5, mask3.view(-1))
         return x, loss_ocfr
 
+    def _hma_compact(self, feats_s, index, label):
+        """BlockMask.forward on the kept tokens only (SURVEY.md 5 "HMA exact-zero invariant"): the same four blocks on
+        packed variable-length sequences.  Returns pooled (3,B,2D), num (B) and loss_ocfr."""
+        fb = self.FUSE_block
+        nmod, b, t, d = feats_s.shape
+        plan = ops.CompactPlan(index, t, nmod)
+        xa = fn.GatherRowsFn.apply(feats_s.reshape(nmod * b * t, d), plan.map_a, plan.live_a, 1, plan.ma)   # layout A
+        mods = []
+        for i, tag in enumerate(("R", "N", "T")):
+            args = _block_args(getattr(fb, "norm" + tag), getattr(fb, "attn" + tag), getattr(fb, "norm" + tag + "_"),
+                               getattr(fb, "mlp" + tag))
+            mods.append(fn.TransformerBlockFn.apply(xa[i * plan.ma:(i + 1) * plan.ma], *args, plan.mask_a, None,
+                                                    self.hma_heads, 1e-5, self.act_dtype, None, None, plan.cu, t,
+                                                    plan.live_a))
+        xa = torch.cat(mods, dim=0)
+        loss_ocfr = None
+        if self.training:
+            cls = fn.GatherRowsFn.apply(xa, plan.map_cls).view(nmod, b, d)
+            loss_ocfr = self._ocfr([cls[0], cls[1], cls[2]], label)
+        xb = fn.GatherRowsFn.apply(xa, plan.map_b, plan.live_a, nmod, plan.mb)             # layout B (MB, D)
+        xb = fn.TransformerBlockFn.apply(xb, *_block_args(fb.norm1, fb.attn1, fb.norm2, fb.mlp), plan.mask_b, None,
+                                         self.hma_heads, 1e-5, self.act_dtype, None, None, plan.cu3, nmod * t, plan.live_b)
+        xb = fn.LayerNormFn.apply(xb, fb.out_norm.weight, fb.out_norm.bias, 1e-5, plan.mask_b, plan.live_b)
+        pooled, num = fn.PoolPackedFn.apply(xb, plan.cu, b, nmod)
+        self.last_aux["plan"] = plan
+        return pooled, num, loss_ocfr
+
     def _ocfr(self, cls_feats, label):
         """OCFR.forward (OCFR.py:44-84): normalise, per-label centre update (momentum 0.8), MSE to own-class centre."""
         mc = self.FUSE_block.memory_cls
@@ -371,8 +399,11 @@ class EDITOR(nn.Module):
                 mod_scores = [fn.LinearFn.apply(self._bn(self.BACKBONE_BN, c), self.BACKBONE_HEAD.weight, None)
                               for c in cls_tri]
         feats_s, loss_bcc = fn.SFTSApplyFn.apply(feats, index, training)
-        fused, loss_ocfr = self._hma(feats_s, index, label)
-        pooled, num = fn.PoolFn.apply(fused, 3, t)
+        if self.hma_compact and self.act_dtype == torch.bfloat16 and b * t >= 256:
+            pooled, num, loss_ocfr = self._hma_compact(feats_s, index, label)
+        else:                      # dense-masked form, as the reference computes it (always used in f32 parity mode)
+            fused, loss_ocfr = self._hma(feats_s, index, label)
+            pooled, num = fn.PoolFn.apply(fused, 3, t)
         if training and writer is not None:
             writer.add_scalar("num_count", num.mean(), epoch)                      # make_model.py:199-200
         red = [fn.LinearFn.apply(pooled[i], getattr(self, tag + "_REDUCE").weight, getattr(self, tag + "_REDUCE").bias)

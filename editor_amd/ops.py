@@ -86,23 +86,25 @@ WS_ROWS = 1024
 # ---------------------------------------------------------------------------------------------
 # row kernels
 # ---------------------------------------------------------------------------------------------
-def layernorm_fwd(x2d, gamma, beta, eps, out_dtype, rowmask=None, mask_period=0, want_stats=True):
+def layernorm_fwd(x2d, gamma, beta, eps, out_dtype, rowmask=None, mask_period=0, want_stats=True, m_live=None):
     m, d = x2d.shape
     y = torch.empty(m, d, dtype=out_dtype, device=x2d.device)
     mean = torch.empty(m, dtype=torch.float32, device=x2d.device) if want_stats else None
     rstd = torch.empty(m, dtype=torch.float32, device=x2d.device) if want_stats else None
-    call("editor_layernorm_fwd", x2d, gamma, beta, float(eps), m, d, rowmask, int(mask_period), y, _is_bf16(y), mean, rstd)
+    call("editor_layernorm_fwd", x2d, gamma, beta, float(eps), m, d, rowmask, int(mask_period), y, _is_bf16(y), mean, rstd,
+         m_live)
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x2d, gamma, mean, rstd, rowmask=None, mask_period=0, dx_in=None, want_param_grads=True):
+def layernorm_bwd(dy, x2d, gamma, mean, rstd, rowmask=None, mask_period=0, dx_in=None, want_param_grads=True,
+                  m_live=None):
     m, d = x2d.shape
     dx = torch.empty(m, d, dtype=torch.float32, device=x2d.device)
     dg = torch.empty(d, dtype=torch.float32, device=x2d.device) if want_param_grads else None
     db = torch.empty(d, dtype=torch.float32, device=x2d.device) if want_param_grads else None
     ws = workspace(x2d.device, (WS_ROWS + 1) * 2 * d)
     call("editor_layernorm_bwd", dy, _is_bf16(dy), x2d, gamma, mean, rstd, m, d, rowmask, int(mask_period), dx_in, dx,
-         dg, db, ws, WS_ROWS)
+         dg, db, ws, WS_ROWS, m_live)
     return dx, dg, db
 
 
@@ -139,11 +141,11 @@ def cast(x, dtype):
     return out
 
 
-def cast_rows(x2d, rowscale, dtype):
+def cast_rows(x2d, rowscale, dtype, m_live=None):
     """x * rowscale[:, None] cast to `dtype` (one pass)."""
     m, d = x2d.shape
     out = torch.empty(m, d, dtype=dtype, device=x2d.device)
-    call("editor_cast_rows", x2d, rowscale, m, d, out, _is_bf16(out))
+    call("editor_cast_rows", x2d, rowscale, m, d, out, _is_bf16(out), m_live)
     return out
 
 
@@ -210,51 +212,125 @@ EPI_NONE, EPI_RESIDUAL, EPI_GELU, EPI_GELU_BWD = 0, 1, 2, 3
 
 
 def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=0.0, bias=None, rowscale=None,
-         splitk=1, a_off=0, b_off=0, c_off=0, epilogue=0, aux=None):
+         splitk=1, a_off=0, b_off=0, c_off=0, epilogue=0, aux=None, m_live=None):
     """c = alpha * op(a) op(b) (+bias) (+beta*c) (*rowscale); dtype picks the kernel family
     (fp32 -> exact-f32 MFMA, bf16 -> bf16 MFMA with fp32 accumulate; c may be fp32 for bf16 inputs)."""
     if a.dtype == torch.float32:
-        assert b.dtype == torch.float32 and c.dtype == torch.float32
+        assert b.dtype == torch.float32 and c.dtype == torch.float32 and m_live is None
         call("editor_gemm_f32", _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), m, n, k, lda, ldb, ldc,
              int(trans_a), int(trans_b), 1, 0, 0, 0, 1, 0, 0, 0, float(alpha), float(beta), bias, rowscale, int(splitk),
              int(epilogue), aux, n)
     elif a.dtype == torch.bfloat16:
         assert b.dtype == torch.bfloat16
+        if m_live is not None and (m < 256 or n < 128 or k % 64):
+            raise RuntimeError("live-row GEMM needs the pipelined path (M >= 256, N >= 128, K % 64 == 0)")
         call("editor_gemm_bf16", _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), 1 if c.dtype == torch.float32 else 0,
              m, n, k, lda, ldb, ldc, int(trans_a), int(trans_b), float(alpha), float(beta), bias, rowscale, int(splitk),
-             int(epilogue), aux, n, workspace(a.device, int(splitk) * m * n) if splitk > 1 else None)
+             int(epilogue), aux, n, workspace(a.device, int(splitk) * m * n) if splitk > 1 else None, m_live)
     else:
         raise TypeError(a.dtype)
 
 
-def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True):
-    """Attention / AttentionMask core on packed qkv (b*t, 3*heads*hd) -> (b*t, heads*hd).
+def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True, cu=None):
+    """Attention / AttentionMask core on packed qkv (rows, 3*heads*hd) -> (rows, heads*hd).
+    Dense: rows = b*t.  Variable length (compacted HMA): cu (b+1 int32) = packed row range of every sequence,
+    t = longest sequence; rows outside every sequence (padding) come out as zeros.
     Returns (out, saved): `saved` is what the backward needs besides qkv/out - the probabilities in fp32 mode,
     the per-row log-sum-exp in bf16 mode."""
     d = heads * hd
-    out = torch.empty(b * t, d, dtype=qkv.dtype, device=qkv.device)
+    rows = qkv.shape[0]
     scale = hd ** -0.5
     if qkv.dtype == torch.float32:
+        if cu is not None:
+            raise RuntimeError("variable-length attention exists in the bf16 kernels only (f32 = dense parity mode)")
+        out = torch.empty(rows, d, dtype=qkv.dtype, device=qkv.device)
         if probs is None:
             probs = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
         call("editor_attention_fwd_f32", qkv, b, t, heads, hd, scale, mask, out, probs)
         return out, probs
-    lse = torch.empty(b * heads * t, dtype=torch.float32, device=qkv.device) if want_lse else None
+    out = (torch.zeros if cu is not None else torch.empty)(rows, d, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(heads * rows, dtype=torch.float32, device=qkv.device) if want_lse else None
     call("editor_attention_fwd_bf16", qkv, b, t, heads, hd, scale, mask, out, probs,
-         0 if probs is None else probs.shape[-1], lse)
+         0 if probs is None else probs.shape[-1], lse, cu, rows)
     return out, lse
 
 
-def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None):
-    dqkv = torch.empty_like(qkv)
+def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None, cu=None):
     scale = hd ** -0.5
+    rows = qkv.shape[0]
     if qkv.dtype == torch.float32:
+        dqkv = torch.empty_like(qkv)
         ws = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
         call("editor_attention_bwd_f32", qkv, dout, saved, b, t, heads, hd, scale, dqkv, ws)
     else:
-        ws = torch.empty(b * heads * t, dtype=torch.float32, device=qkv.device)
-        call("editor_attention_bwd_bf16", qkv, dout, out, saved, b, t, heads, hd, scale, mask, dqkv, ws)
+        dqkv = torch.zeros_like(qkv) if cu is not None else torch.empty_like(qkv)
+        ws = torch.empty(heads * rows, dtype=torch.float32, device=qkv.device)
+        call("editor_attention_bwd_bf16", qkv, dout, out, saved, b, t, heads, hd, scale, mask, dqkv, ws, cu, rows)
     return dqkv
+
+
+# ---------------------------------------------------------------------------------------------
+# compacted (variable-length) HMA
+# ---------------------------------------------------------------------------------------------
+class CompactPlan:
+    """Packing plan of the HMA head for one batch, built ON DEVICE from the SFTS index with no host round trip:
+    buffers and launches are sized for the worst case (every token kept) and the live row counts stay in device
+    memory (`live_a` = sum_b L_b, `live_b` = nmod * that), which the kernels read through their `m_live` argument."""
+
+    def __init__(self, index, t, nmod=3, pad=64):
+        b, n = index.shape
+        dev = index.device
+        self.b, self.t, self.nmod = b, t, nmod
+        self.cu = torch.empty(b + 1, dtype=torch.int32, device=dev)
+        tok = torch.empty(b * (n + 1), dtype=torch.int32, device=dev)
+        call("editor_compact_plan", index, b, n, self.cu, tok)
+        self.ma = (b * t + pad - 1) // pad * pad                   # worst-case rows per modality (layout A)
+        self.mb = (nmod * b * t + pad - 1) // pad * pad            # worst-case rows of layout B
+        self.map_a = torch.empty(nmod * self.ma, dtype=torch.int32, device=dev)
+        self.map_b = torch.empty(self.mb, dtype=torch.int32, device=dev)
+        self.map_cls = torch.empty(nmod * b, dtype=torch.int32, device=dev)
+        self.mask_a = torch.empty(self.ma, dtype=torch.uint8, device=dev)
+        self.mask_b = torch.empty(self.mb, dtype=torch.uint8, device=dev)
+        self.cu3 = torch.empty(b + 1, dtype=torch.int32, device=dev)
+        call("editor_compact_maps", self.cu, tok, b, t, nmod, self.ma, self.mb, self.map_a, self.map_b, self.map_cls,
+             self.mask_a, self.mask_b, self.cu3)
+        self.live_a = self.cu[b:b + 1]                             # device scalars
+        self.live_b = self.cu3[b:b + 1]
+
+    @property
+    def total(self):
+        """Host copy of the kept-row count (synchronises; for tests / logging only)."""
+        return int(self.cu[-1].item())
+
+
+def gather_rows(x2d, src, live=None, live_mul=1, live_stride=0):
+    """out[r] = x2d[src[r]] (0 where src[r] < 0).  live (device int32 scalar): only rows below
+    roundup64(live_mul * live) of every `live_stride`-row segment are produced."""
+    r = src.numel()
+    out = torch.empty(r, x2d.shape[1], dtype=torch.float32, device=x2d.device)
+    call("editor_gather_rows", x2d, src, r, x2d.shape[1], out, live, int(live_mul), int(live_stride))
+    return out
+
+
+def scatter_rows(dy2d, src, rows_out):
+    dx = torch.empty(rows_out, dy2d.shape[1], dtype=torch.float32, device=dy2d.device)
+    call("editor_scatter_rows", dy2d, src, src.numel(), dy2d.shape[1], rows_out, dx)
+    return dx
+
+
+def pool_packed_fwd(x2d, cu, b, nmod):
+    d = x2d.shape[1]
+    out = torch.empty(nmod, b, 2 * d, dtype=torch.float32, device=x2d.device)
+    num = torch.empty(b, dtype=torch.float32, device=x2d.device)
+    call("editor_pool_packed_fwd", x2d, cu, b, nmod, d, out, num)
+    return out, num
+
+
+def pool_packed_bwd(dout, num, cu, b, nmod, rows):
+    d = dout.shape[2] // 2
+    dx = torch.empty(rows, d, dtype=torch.float32, device=dout.device)
+    call("editor_pool_packed_bwd", dout, num, cu, b, nmod, d, rows, dx)
+    return dx
 
 
 # ---------------------------------------------------------------------------------------------

@@ -61,13 +61,13 @@ int editor_mask_or(const uint8_t* a, const uint8_t* b, const uint8_t* c, const u
  * unselected tokens, vit_pytorch.py:245,162); mask row = row % mask_period (0 = no wrap).  mean/rstd: (M) fp32. */
 int editor_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, long M, int D,
                          const uint8_t* rowmask, int mask_period, void* y, int y_bf16, float* mean, float* rstd,
-                         editor_stream_t stream);
+                         const int* m_live, editor_stream_t stream);
 /* backward: dx_out = (dx_in ? dx_in : 0) + dLN/dx ; dgamma/dbeta (D) fp32 (NULL to skip).
  * workspace: (ws_rows+1)*2*D floats. */
 int editor_layernorm_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
                          const float* rstd, long M, int D, const uint8_t* rowmask, int mask_period,
                          const float* dx_in, float* dx_out, float* dgamma, float* dbeta, float* workspace,
-                         int ws_rows, editor_stream_t stream);
+                         int ws_rows, const int* m_live, editor_stream_t stream);
 /* out[n] = sum_m dy[m,n]  (bias gradients of every nn.Linear).  workspace: ws_rows*N floats. */
 int editor_colsum(const void* dy, int dy_bf16, long M, int N, long ld, float* out, float* workspace, int ws_rows,
                   editor_stream_t stream);
@@ -80,7 +80,7 @@ int editor_cast_f32_to_bf16(const float* in, uint16_t* out, long n, editor_strea
 /* out[m,:] = in[m,:] * rowscale[m] (rowscale may be NULL): fp32 gradient -> GEMM operand dtype, with the
  * per-sample drop-path factor keep/keep_prob of vit_pytorch.py:52-69 folded in. */
 int editor_cast_rows(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16,
-                     editor_stream_t stream);
+                     const int* m_live, editor_stream_t stream);
 int editor_cast_bf16_to_f32(const uint16_t* in, float* out, long n, editor_stream_t stream);
 
 /* PatchEmbed_overlap with stride == patch == 16 (vit_pytorch.py:449-458): im2col rows (b*N+p), cols (c,i,j). */
@@ -125,7 +125,12 @@ int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, i
                      long ldc, int transA, int transB, float alpha, float beta, const float* bias,
                      const float* rowscale, int splitk, int epilogue, void* aux, long ldaux,
                      float* splitk_ws /* splitk*M*N floats or NULL (then split-K uses fp32 atomics) */,
-                     editor_stream_t stream);
+                     const int* m_live /* see below */, editor_stream_t stream);
+
+/* m_live (device int32 scalar, may be NULL) - compacted HMA without a host round trip: buffers and launches are sized
+ * for the worst-case row count, only the first *m_live token rows are live.  Row kernels process rows below
+ * roundup64(*m_live) (rows in [*m_live, roundup64) carry mask 0 / zeros), GEMMs skip tiles of dead rows (forward, dgrad)
+ * or shorten the reduction (wgrad: transA); dead rows are never read by anyone. */
 
 /* Attention.forward / AttentionMask.forward on packed qkv rows (B*T, 3*heads*hd) (vit_pytorch.py:184-198,240-258).
  * mask (B,T) uint8 or NULL.  out (B*T, heads*hd).  probs (B,heads,T,T) fp32: the softmax output the backbone
@@ -135,16 +140,34 @@ int editor_attention_fwd_f32(const float* qkv, int B, int T, int heads, int hd, 
 int editor_attention_bwd_f32(const float* qkv, const float* dout, const float* probs, int B, int T, int heads, int hd,
                              float scale, float* dqkv, float* workspace, editor_stream_t stream);
 
-/* Fused bf16 form (hd must be 64; T <= 416).  probs optional (NULL skips the write).  lse (B*heads*T fp32, log2 units
+/* Fused bf16 form (hd must be 64; T <= 416).  probs optional (NULL skips the write).  lse (heads*Mtot fp32, log2 units
  * of the scaled scores, +inf for masked queries) is written by the forward (NULL to skip) and consumed by the backward,
  * which recomputes the probabilities from it; `out` is the forward output (delta = rowsum(dO*O));
- * workspace: B*heads*T floats. */
+ * workspace: heads*Mtot floats.  Variable-length (compacted HMA) form: cu (B+1 int32) gives each sequence's packed row
+ * range, T = the longest sequence, Mtot = total packed rows (pad rows are not touched); cu == NULL: dense, Mtot = B*T. */
 int editor_attention_fwd_bf16(const uint16_t* qkv, int B, int T, int heads, int hd, float scale, const uint8_t* mask,
                               uint16_t* out, float* probs, int ldp /* row stride of probs, multiple of 4 */, float* lse,
-                              editor_stream_t stream);
+                              const int* cu, long Mtot, editor_stream_t stream);
 int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, int B,
                               int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv,
-                              float* workspace, editor_stream_t stream);
+                              float* workspace, const int* cu, long Mtot, editor_stream_t stream);
+
+/* ---- compacted (variable-length) HMA: packing plan and row movement (csrc/compact.hip) ------------------ */
+/* index (B,N) uint8 -> cu (B+1): exclusive prefix sum of L_b = 1 + #selected; tok (>= cu[B] ints): token id (0 = cls,
+ * n+1 = patch n) of every packed row, sample-major. */
+int editor_compact_plan(const uint8_t* index, int B, int N, int* cu, int* tok, editor_stream_t stream);
+/* row maps between the dense (nmod,B,T,D) tokens, layout A (nmod x MA rows, modality-major) and layout B (MB rows,
+ * sample-major: [R rows | N rows | T rows] per sample); -1 / mask 0 mark pad rows.  cu3 = nmod * cu. */
+int editor_compact_maps(const int* cu, const int* tok, int B, int T, int nmod, long MA, long MB, int* mapA, int* mapB,
+                        int* mapCls, uint8_t* maskA, uint8_t* maskB, int* cu3, editor_stream_t stream);
+int editor_gather_rows(const float* in, const int* src, long R, int D, float* out, const int* r_live /* or NULL */,
+                       int live_mul, long live_stride, editor_stream_t stream);
+int editor_scatter_rows(const float* dy, const int* src, long R, int D, long rows_out, float* dx, editor_stream_t stream);
+/* make_model.py:186-203 on layout B */
+int editor_pool_packed_fwd(const float* x, const int* cu, long B, int nmod, int D, float* out, float* num,
+                           editor_stream_t stream);
+int editor_pool_packed_bwd(const float* dout, const float* num, const int* cu, long B, int nmod, int D, long rows,
+                           float* dx, editor_stream_t stream);
 
 /* ---- head kernels ------------------------------------------------------------------------------------ */
 

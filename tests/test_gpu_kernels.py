@@ -260,3 +260,62 @@ def test_gemm_epilogues(ops, dtype):
     out = torch.empty(m, k, dtype=dtype, device="cuda")
     ops.gemm(dy.cuda(), w.cuda(), out, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=pre2.cuda())
     assert rel_err(out.float().cpu(), pr.grad) < tol
+
+
+def test_attention_varlen_matches_dense_reference(ops):
+    """Compacted (variable-length) attention == per-sequence dense softmax attention (fp32 reference)."""
+    heads, hd = 12, 64
+    d = heads * hd
+    lens = [129, 60, 1, 77, 128]
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    total = int(cu[-1])
+    rows = (total + 63) // 64 * 64
+    g = _g(5)
+    qkv = (torch.randn(rows, 3 * d, generator=g) * 1.2).bfloat16()
+    qkv[total:] = 0
+    do = torch.randn(rows, d, generator=g).bfloat16()
+    do[total:] = 0
+    qr = qkv.float().requires_grad_(True)
+    outs = []
+    for i, n in enumerate(lens):
+        s0 = int(cu[i])
+        o, _ = _attn_ref(qr[s0:s0 + n], 1, n, heads, hd, None)
+        outs.append(o)
+    ref = torch.cat(outs + [torch.zeros(rows - total, d)])
+    ref.backward(do.float())
+    o, lse = ops.attention_fwd(qkv.cuda(), len(lens), max(lens), heads, hd, None, None, cu=cu.cuda())
+    assert rel_err(o.float().cpu(), ref.detach()) < 1.5e-2
+    assert float(o[total:].abs().max()) == 0.0
+    dqkv = ops.attention_bwd(qkv.cuda(), do.cuda(), len(lens), max(lens), heads, hd, None, lse, o, cu=cu.cuda())
+    assert rel_err(dqkv.float().cpu(), qr.grad) < 2.5e-2
+    assert float(dqkv[total:].abs().max()) == 0.0
+
+
+def test_compact_plan_and_rows(ops):
+    g = _g(11)
+    b, n, d, nmod = 7, 128, 256, 3
+    t = n + 1
+    index = (torch.rand(b, n, generator=g) > 0.55).to(torch.uint8)
+    plan = ops.CompactPlan(index.cuda(), t, nmod)
+    lens = 1 + index.sum(1)
+    assert plan.total == int(lens.sum())
+    assert plan.cu.cpu().tolist() == [0] + lens.cumsum(0).tolist()
+    dense = torch.randn(nmod * b * t, d, generator=g)
+    xa = ops.gather_rows(dense.cuda(), plan.map_a).cpu().view(nmod, plan.ma, d)
+    cu = plan.cu.cpu()
+    for m in range(nmod):
+        for bb in range(b):
+            toks = [0] + [int(i) + 1 for i in torch.nonzero(index[bb]).flatten()]
+            ref = dense.view(nmod, b, t, d)[m, bb, toks]
+            assert torch.equal(xa[m, cu[bb]:cu[bb + 1]], ref)
+        assert float(xa[m, plan.total:].abs().max()) == 0.0
+    assert plan.mask_a.cpu().sum() == plan.total and plan.mask_b.cpu().sum() == nmod * plan.total
+    xb = ops.gather_rows(xa.reshape(-1, d).cuda(), plan.map_b).cpu()
+    for bb in range(b):
+        ln = int(cu[bb + 1] - cu[bb])
+        for m in range(nmod):
+            assert torch.equal(xb[nmod * cu[bb] + m * ln: nmod * cu[bb] + (m + 1) * ln], xa[m, cu[bb]:cu[bb + 1]])
+    # scatter is the exact adjoint of gather
+    back = ops.scatter_rows(xa.reshape(-1, d).cuda(), plan.map_a, nmod * b * t).cpu().view(nmod, b, t, d)
+    keep = torch.cat([torch.ones(b, 1, dtype=torch.bool), index.bool()], 1)
+    assert torch.equal(back, dense.view(nmod, b, t, d) * keep.view(1, b, t, 1))

@@ -164,3 +164,33 @@ def test_train_bf16_teacher_forced():
             worst = max(worst, rel_err(gr.reshape(gr.shape[0], -1)[:16, :16].cpu(), val))
     print("bf16 worst gradient rel err:", worst)
     assert worst < 8e-2
+
+
+def test_hma_compact_equals_dense_bf16():
+    """The compacted (variable-length) HMA head == the reference's dense-masked form (same bf16 kernels, same weights):
+    outputs and gradients agree to bf16 rounding; the dense form itself is pinned to the reference by the tests above."""
+    seed, batch = 31, 16
+    img, label, cam, view = _cuda_batch(*synth.make_batch(seed + 1, batch, 256, 128, 4, instances=8))
+    res = {}
+    for compact in (False, True):
+        m, cfg, c, cams = _model("RGBNT201", seed, "bf16", drop_path=0.0, hma_compact=compact)
+        m.train()
+        out = m(img, label=label, cam_label=cam, view_label=view, writer=_Writer(), epoch=1)
+        total = out[-1]
+        for i, o in enumerate(out[:-1]):
+            total = total + (o * synth.uniform(5, "proj/%d" % i, tuple(o.shape)).cuda()).mean()
+        total.backward()
+        named = dict(m.named_parameters())
+        res[compact] = ([o.detach().float().cpu() for o in out],
+                        {k: named[k].grad.float().cpu() for k in ("FUSE_block.attn1.qkv.weight", "FUSE_block.mlpN.fc2.weight",
+                                                                  "FUSE_block.normR.weight", "FUSE_block.out_norm.bias",
+                                                                  "BACKBONE.base.blocks.11.mlp.fc2.weight", "RGB_REDUCE.weight",
+                                                                  "BACKBONE.base.cls_token")},
+                        m.last_aux["num"].cpu(), m.last_aux["index"].cpu())
+        if compact:
+            assert m.last_aux["plan"].total == int(m.last_aux["index"].sum()) + batch
+    assert torch.equal(res[False][3], res[True][3]) and torch.equal(res[False][2], res[True][2])
+    for a, b in zip(res[False][0], res[True][0]):
+        assert rel_err(a, b) < 1.5e-2
+    for k in res[False][1]:
+        assert rel_err(res[True][1][k], res[False][1][k]) < 4e-2, k
