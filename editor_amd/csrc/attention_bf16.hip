@@ -334,7 +334,7 @@ int set_lds(K kern, size_t bytes)
     return 0;
 }
 
-inline int pick_nt(int T) { return T <= 160 ? 10 : (T <= 224 ? 14 : (T <= 416 ? 26 : 0)); }
+inline int pick_nt(int T) { return T <= 160 ? 10 : (T <= 224 ? 14 : (T <= 416 ? 26 : (T <= 608 ? 38 : 0))); }
 inline int pick_threads(int T) { const int tiles = (T + 15) / 16; return (tiles % 3 == 0) ? 192 : 256; }
 
 template <int NT>
@@ -369,6 +369,7 @@ int dispatch(const AttnArgs& a, int B, int mode, hipStream_t stream)
         case 10: return launch_all<10>(a, B, mode, stream);
         case 14: return launch_all<14>(a, B, mode, stream);
         case 26: return launch_all<26>(a, B, mode, stream);
+        case 38: return launch_all<38>(a, B, mode, stream);      // 3 x 193 tokens: joint HMA block of the 384x128 configs
         default: return (int)hipErrorInvalidValue;
     }
 }

@@ -140,7 +140,7 @@ int editor_attention_fwd_f32(const float* qkv, int B, int T, int heads, int hd, 
 int editor_attention_bwd_f32(const float* qkv, const float* dout, const float* probs, int B, int T, int heads, int hd,
                              float scale, float* dqkv, float* workspace, editor_stream_t stream);
 
-/* Fused bf16 form (hd must be 64; T <= 416).  probs optional (NULL skips the write).  lse (heads*Mtot fp32, log2 units
+/* Fused bf16 form (hd must be 64; T <= 608).  probs optional (NULL skips the write).  lse (heads*Mtot fp32, log2 units
  * of the scaled scores, +inf for masked queries) is written by the forward (NULL to skip) and consumed by the backward,
  * which recomputes the probabilities from it; `out` is the forward output (delta = rowsum(dO*O));
  * workspace: heads*Mtot floats.  Variable-length (compacted HMA) form: cu (B+1 int32) gives each sequence's packed row

@@ -194,3 +194,20 @@ def test_hma_compact_equals_dense_bf16():
         assert rel_err(a, b) < 1.5e-2
     for k in res[False][1]:
         assert rel_err(res[True][1][k], res[False][1][k]) < 4e-2, k
+
+
+def test_eval_bf16_384x128_config4():
+    """BASELINE.json config 4 geometry (384x128 -> 192 patches, T = 193, joint HMA block of up to 579 tokens) in bf16,
+    compacted HMA, reference selection teacher-forced."""
+    g = load_golden("f3_eval_vitb_384x128")
+    seed, batch = int(g["seed"]), int(g["batch"])
+    m, cfg, c, cams = _model("MSVR310", seed, "bf16", drop_path=0.0)
+    m.eval()
+    img, label, cam, view = _cuda_batch(*synth.make_batch(seed + 1, batch, 384, 128, cams))
+    m.teacher_index = t(g["index"])
+    with torch.no_grad():
+        cls4t = m(img, cam_label=cam, view_label=view)
+    assert torch.equal(m.last_aux["mask_fre"].cpu().bool(), t(g["mask_fre"]))
+    err = rel_err(cls4t.cpu(), g["cls4t"])
+    print("bf16 384x128 cls4t rel err:", err)
+    assert err < 2e-2
