@@ -60,7 +60,9 @@ class _GemmProbe:
                 ta = args[3] if len(args) > 3 else kw.get("trans_a", 0)
                 tb = args[4] if len(args) > 4 else kw.get("trans_b", 0)
                 kind = "fwd" if not ta and not tb else ("dgrad" if not ta else "wgrad")
-                probe.calls.append((kind, 2.0 * m * n * k, (a, b, c, m, n, k) + args, dict(kw)))
+                # compacted HMA launches are sized for the worst case; count only the live rows (device scalar,
+                # read after the timed region) as algorithmic work
+                probe.calls.append([kind, (m, n, k, kw.get("m_live"), bool(ta)), (a, b, c, m, n, k) + args, dict(kw)])
             return probe._orig(a, b, c, m, n, k, *args, **kw)
         ops.gemm = recorded
 
@@ -70,6 +72,15 @@ class _GemmProbe:
 
     def replay(self, reps=3):
         by_kind = {}
+        for call in self.calls:                            # algorithmic FLOPs with the live row count
+            m, n, k, live, ta = call[1]
+            if live is not None:
+                rows = int(live.item())
+                if ta:
+                    k = min(k, rows)
+                else:
+                    m = min(m, rows)
+            call[1] = 2.0 * m * n * k
         for kind in ("fwd", "dgrad", "wgrad"):
             calls = [c for c in self.calls if c[0] == kind]
             if not calls:
@@ -136,6 +147,7 @@ def main():
     ap.add_argument("--preset", default="RGBNT201")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-replay", action="store_true", help="skip the GEMM replay (clean rocprof per-step totals)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -215,7 +227,7 @@ def main():
     elapsed = float(el.item())
 
     if rank == 0:
-        kinds = probe.replay()
+        kinds = {} if args.no_replay else probe.replay()
         flops = sum(v[0] for v in kinds.values())
         ms = sum(v[1] for v in kinds.values())
         launches = sum(v[2] for v in kinds.values())

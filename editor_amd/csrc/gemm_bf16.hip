@@ -43,10 +43,21 @@ struct GemmB16Args {
     int live_is_k;                           // the token-row extent is the reduction (wgrad) instead of M
 };
 
-__device__ __forceinline__ float gelu_f(float a) { return 0.5f * a * (1.f + erff(a * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float a) {
-    return 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.3989422804014327f * __expf(-0.5f * a * a);
+// exact-erf GELU (nn.GELU default) for bf16 outputs: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. 4
+// orders below bf16 resolution) - one v_exp + one v_rcp + 6 FMAs instead of libm's branchy erff; the SAME exponential
+// exp(-a^2/2) also gives the Gaussian term of the derivative.  (The f32 parity kernels keep erff.)
+__device__ __forceinline__ void erf_half_terms(float a, float& cdf, float& gauss)
+{
+    const float z = fabsf(a) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+    const float e = __expf(-z * z);                                   // = exp(-a^2/2)
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erf_abs = fmaf(-poly, e, 1.f);
+    cdf = 0.5f * (1.f + copysignf(erf_abs, a));                        // Phi(a)
+    gauss = e;
 }
+__device__ __forceinline__ float gelu_f(float a) { float c, g; erf_half_terms(a, c, g); return a * c; }
+__device__ __forceinline__ float gelu_grad_f(float a) { float c, g; erf_half_terms(a, c, g); return fmaf(a * 0.3989422804014327f, g, c); }
 
 // ---- LDS images -------------------------------------------------------------------------------------
 // k-major tile  [128 rows][64 k]  : byte = row*128 + ((chunk ^ (row&7)) * 16), chunk = k/8
