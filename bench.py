@@ -111,7 +111,7 @@ def _usable_cores():
     return max(1, min(n, 32))          # the oracle's per-op parallelism saturates well below 32 threads
 
 
-def cpu_baseline(model, cfg, cams, sample_b=4):
+def cpu_baseline(model, cfg, cams, sample_b=32):
     """Oracle (oracle/editor_ref.py) fwd+bwd on the host cores on a bounded sample of the workload."""
     from oracle import editor_ref as oracle
     from editor_amd import synth

@@ -307,6 +307,77 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB16Args g)
 // the 16 lanes of a tile row covering 256 / 512 contiguous bytes.  Keeping the math in a rolled loop matters: the fully
 // unrolled per-fragment epilogue is ~10k straight-line instructions executed once per tile, i.e. always instruction-cache
 // cold (measured: ~5.5 us per tile even with the global stores removed).
+template <bool C_F32, int EPI, int PBM, int PBN, int NTHREADS>
+__device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const char* lds, int m0, int n0, int split)
+{
+    constexpr int RBP = PBN * 4 + 16;
+    constexpr int GPR = PBN / 8;                                // 8-column groups per tile row
+    constexpr int ITERS = PBM * GPR / NTHREADS;                 // trips per thread (8 for 256x128 / 512 threads)
+    static_assert(PBM * GPR % NTHREADS == 0, "tile must divide evenly");
+    const bool add_bias = g.bias && split == 0;
+    float* Cf = C_F32 ? reinterpret_cast<float*>(g.C) + (g.splitk > 1 ? (long)split * g.M * g.ldc : 0L) : nullptr;
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+    // branch-free body per epilogue kind, all LDS reads of a half issued before the first use
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float4 lo[ITERS / 2], hi[ITERS / 2];
+#pragma unroll
+        for (int it = 0; it < ITERS / 2; ++it) {
+            const int c = threadIdx.x + (half * (ITERS / 2) + it) * NTHREADS;
+            const int row = c / GPR, cg = c % GPR;
+            lo[it] = *reinterpret_cast<const float4*>(lds + row * RBP + cg * 32);
+            hi[it] = *reinterpret_cast<const float4*>(lds + row * RBP + cg * 32 + 16);
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS / 2; ++it) {
+            const int c = threadIdx.x + (half * (ITERS / 2) + it) * NTHREADS;
+            const int row = c / GPR, cg = c % GPR;
+            const int m = m0 + row, n = n0 + cg * 8;
+            if (m >= g.M || n >= g.N) continue;                  // N is a multiple of 8 on this path (checked on the host)
+            float x[8] = {lo[it].x, lo[it].y, lo[it].z, lo[it].w, hi[it].x, hi[it].y, hi[it].z, hi[it].w};
+            const float rs = g.rowscale ? g.rowscale[m] : 1.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                x[e] *= g.alpha;
+                if (add_bias) x[e] += g.bias[n + e];
+                x[e] *= rs;
+            }
+            if (EPI == EDITOR_EPI_RESIDUAL) {
+                const float* r = reinterpret_cast<const float*>(g.aux) + (long)m * g.ldaux + n;
+                const float4 r0 = *reinterpret_cast<const float4*>(r), r1 = *reinterpret_cast<const float4*>(r + 4);
+                x[0] += r0.x; x[1] += r0.y; x[2] += r0.z; x[3] += r0.w; x[4] += r1.x; x[5] += r1.y; x[6] += r1.z; x[7] += r1.w;
+            } else if (EPI == EDITOR_EPI_GELU) {                 // aux <- pre-activation (bf16), C <- gelu(rounded pre-activation)
+                uint4 p;
+                p.x = pack_bf16x2(x[0], x[1]); p.y = pack_bf16x2(x[2], x[3]); p.z = pack_bf16x2(x[4], x[5]); p.w = pack_bf16x2(x[6], x[7]);
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = p;
+                const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[2 * e] = gelu_f(__uint_as_float(pw[e] << 16));
+                    x[2 * e + 1] = gelu_f(__uint_as_float(pw[e] & 0xffff0000u));
+                }
+            } else if (EPI == EDITOR_EPI_GELU_BWD) {
+                const uint4 p = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ldaux + n);
+                const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[2 * e] *= gelu_grad_f(__uint_as_float(pw[e] << 16));
+                    x[2 * e + 1] *= gelu_grad_f(__uint_as_float(pw[e] & 0xffff0000u));
+                }
+            }
+            if (C_F32) {
+                float* o = Cf + (long)m * g.ldc + n;
+                *reinterpret_cast<float4*>(o) = make_float4(x[0], x[1], x[2], x[3]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(x[4], x[5], x[6], x[7]);
+            } else {
+                uint4 o;
+                o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]); o.z = pack_bf16x2(x[4], x[5]); o.w = pack_bf16x2(x[6], x[7]);
+                *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = o;
+            }
+        }
+    }
+}
+
 template <bool C_F32, int MT, int PBM, int PBN, int NTHREADS>
 __device__ __forceinline__ void epilogue_staged(const GemmB16Args& g, float4_t (&acc)[MT][4], char* lds, int m0, int n0,
                                                 int wm, int wn, int lane, int split)
@@ -320,58 +391,11 @@ __device__ __forceinline__ void epilogue_staged(const GemmB16Args& g, float4_t (
         for (int j = 0; j < 4; ++j)
             *reinterpret_cast<float4_t*>(lds + (wm + i * 16 + li) * RBP + (wn + j * 16 + lg * 4) * 4) = acc[i][j];
     __syncthreads();
-    constexpr int GPR = PBN / 8;                                // 8-column groups per tile row
-    constexpr int TOTAL = PBM * GPR;
-    const bool add_bias = g.bias && split == 0;
-    float* Cf = C_F32 ? reinterpret_cast<float*>(g.C) + (g.splitk > 1 ? (long)split * g.M * g.ldc : 0L) : nullptr;
-    bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
-#pragma unroll 4
-    for (int c = threadIdx.x; c < TOTAL; c += NTHREADS) {
-        const int row = c / GPR, cg = c % GPR;
-        const int m = m0 + row, n = n0 + cg * 8;
-        if (m >= g.M || n >= g.N) continue;                      // N is a multiple of 8 on this path (checked on the host)
-        const float4 lo = *reinterpret_cast<const float4*>(lds + row * RBP + cg * 32);
-        const float4 hi = *reinterpret_cast<const float4*>(lds + row * RBP + cg * 32 + 16);
-        float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        const float rs = g.rowscale ? g.rowscale[m] : 1.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            x[e] *= g.alpha;
-            if (add_bias) x[e] += g.bias[n + e];
-            x[e] *= rs;
-        }
-        if (g.epilogue == EDITOR_EPI_RESIDUAL) {
-            const float* r = reinterpret_cast<const float*>(g.aux) + (long)m * g.ldaux + n;
-            const float4 r0 = *reinterpret_cast<const float4*>(r), r1 = *reinterpret_cast<const float4*>(r + 4);
-            x[0] += r0.x; x[1] += r0.y; x[2] += r0.z; x[3] += r0.w; x[4] += r1.x; x[5] += r1.y; x[6] += r1.z; x[7] += r1.w;
-        } else if (g.epilogue == EDITOR_EPI_GELU) {             // aux <- pre-activation (bf16), C <- gelu(rounded pre-activation)
-            uint4 p;
-            p.x = pack_bf16x2(x[0], x[1]); p.y = pack_bf16x2(x[2], x[3]); p.z = pack_bf16x2(x[4], x[5]); p.w = pack_bf16x2(x[6], x[7]);
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = p;
-            const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                x[2 * e] = gelu_f(__uint_as_float(pw[e] << 16));
-                x[2 * e + 1] = gelu_f(__uint_as_float(pw[e] & 0xffff0000u));
-            }
-        } else if (g.epilogue == EDITOR_EPI_GELU_BWD) {
-            const uint4 p = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ldaux + n);
-            const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                x[2 * e] *= gelu_grad_f(__uint_as_float(pw[e] << 16));
-                x[2 * e + 1] *= gelu_grad_f(__uint_as_float(pw[e] & 0xffff0000u));
-            }
-        }
-        if (C_F32) {
-            float* o = Cf + (long)m * g.ldc + n;
-            *reinterpret_cast<float4*>(o) = make_float4(x[0], x[1], x[2], x[3]);
-            *reinterpret_cast<float4*>(o + 4) = make_float4(x[4], x[5], x[6], x[7]);
-        } else {
-            uint4 o;
-            o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]); o.z = pack_bf16x2(x[4], x[5]); o.w = pack_bf16x2(x[6], x[7]);
-            *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = o;
-        }
+    switch (g.epilogue) {
+        case EDITOR_EPI_RESIDUAL: epilogue_copy_out<C_F32, EDITOR_EPI_RESIDUAL, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
+        case EDITOR_EPI_GELU:     epilogue_copy_out<C_F32, EDITOR_EPI_GELU, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
+        case EDITOR_EPI_GELU_BWD: epilogue_copy_out<C_F32, EDITOR_EPI_GELU_BWD, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
+        default:                  epilogue_copy_out<C_F32, EDITOR_EPI_NONE, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
     }
 }
 
@@ -467,7 +491,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void gemm_bf16_pipe_kernel(GemmB16A
     // Two co-resident workgroups of a CU start half a tile period apart, so that one drains its output tile to HBM
     // while the other feeds the matrix core (identical tiles otherwise keep every CU of the chip in lockstep and the
     // chip alternates between an MFMA phase and an HBM-write-bound store phase).
-    if (g.stagger && g.stagger != 99 && ((bid >> 8) & 1) && bid < 512) {
+    if (g.stagger && g.stagger < 90 && ((bid >> 8) & 1) && bid < 512) {
         for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
     float4_t acc[MT][4];
@@ -614,9 +638,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void gemm_bf16_pipe_kernel(GemmB16A
     }
 #undef WAIT_LGKM
     constexpr bool kStaged = PBM * (PBN * 4 + 16) <= STAGES * PSTAGE;
-    // (the erf-heavy GELU forward epilogue is faster fully unrolled in registers: measured 372 vs 437 us per launch)
-    if (kStaged && g.beta == 0.f && (g.splitk == 1 || g.slabs) && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (g.ldaux & 7) == 0 &&
-        g.epilogue != EDITOR_EPI_GELU)
+    if (kStaged && g.beta == 0.f && (g.splitk == 1 || g.slabs) && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (g.ldaux & 7) == 0)
         epilogue_staged<C_F32, MT, PBM, PBN, NWAVES * 64>(g, acc, smem, m0, n0, wm, wn, lane, blockIdx.y);
     else
         epilogue_store<C_F32, MT>(g, acc, m0 + wm, n0 + wn, lane, blockIdx.y == 0);
