@@ -637,7 +637,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void gemm_bf16_pipe_kernel(GemmB16A
         mma(fa1, fb1);
     }
 #undef WAIT_LGKM
-    constexpr bool kStaged = PBM * (PBN * 4 + 16) <= STAGES * PSTAGE;
+    // Measured per-launch averages in the training step (rocprofv3): forward products (both operands k-major: qkv, fc1+GELU,
+    // proj/fc2+residual) are faster with the direct register epilogue (372 / 229 us vs 443 / 249 us staged), dgrad and
+    // wgrad (split-K slabs) with the LDS-staged one (252 vs 262 us; 170 vs 247 us).
+    constexpr bool kStaged = PBM * (PBN * 4 + 16) <= STAGES * PSTAGE && !(A_KMAJOR && B_KMAJOR);
     if (kStaged && g.beta == 0.f && (g.splitk == 1 || g.slabs) && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (g.ldaux & 7) == 0)
         epilogue_staged<C_F32, MT, PBM, PBN, NWAVES * 64>(g, acc, smem, m0, n0, wm, wn, lane, blockIdx.y);
     else
@@ -742,7 +745,7 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
     // large problems: 3-stage LDS-DMA pipeline (256x128 tiles)
     const bool pipe = glds && M >= 256 && N >= 128 && !getenv("EDITOR_GEMM_NO_PIPE");
     // split-K: per-split slabs in the workspace + a reduction kernel (pipelined path), else fp32 atomics into C
-    const bool slabs = splitk > 1 && pipe && splitk_ws && ldc == N && (((long)M * N) & 3) == 0 &&
+    const bool slabs = splitk > 1 && pipe && (transA || transB) && splitk_ws && ldc == N && (((long)M * N) & 3) == 0 &&
                        (reinterpret_cast<uintptr_t>(splitk_ws) & 15) == 0;
     if (splitk > 1 && !slabs && beta != 1.f) {
         hipLaunchKernelGGL(scale_c_kernel, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, stream,
