@@ -179,13 +179,10 @@ def main():
     reducer = GradReducer(model, force=use_dist)
     reducer.broadcast_parameters()
 
-    # solver/make_optimizer.py:4-29: SGD, momentum 0.9, wd 1e-4, bias lr x2 (BASE_LR 0.001)
-    decay, bias = [], []
-    for name, p in model.named_parameters():
-        if p.requires_grad:
-            (bias if "bias" in name else decay).append(p)
-    groups = [{"params": decay, "lr": 1e-3, "weight_decay": 1e-4}, {"params": bias, "lr": 2e-3, "weight_decay": 1e-4}]
-    opt = torch.optim.SGD(groups, momentum=0.9, foreach=True)
+    # solver/make_optimizer.py:4-29: SGD, momentum 0.9, wd 1e-4, bias lr x2 (BASE_LR 0.001) - fused HIP update
+    from editor_amd.optim import FusedSGD
+    opt = FusedSGD(model.named_parameters(), base_lr=1e-3, weight_decay=1e-4, bias_lr_factor=2.0,
+                   weight_decay_bias=1e-4, momentum=0.9)
 
     h, w = cfg.INPUT.SIZE_TRAIN
     b = args.batch

@@ -520,14 +520,12 @@ extern "C" int editor_layernorm_bwd(const void* dy, int dy_bf16, const float* x,
                (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out, dgamma ? workspace : nullptr, m_live));
     EDITOR_LAUNCH_CHECK();
     if (dgamma) {
-        // workspace rows are [block][2][D]: treat as P rows of 2D columns, then split
+        // workspace rows are [block][2][D] = P rows of 2D columns; dgamma and dbeta must be ONE (2,D) buffer
+        // (dbeta == dgamma + D) so the reduction writes both without extra copies
+        if (dbeta != dgamma + D) return (int)hipErrorInvalidValue;
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, stream, workspace, (int)blocks,
-                           (long)2 * D, workspace + (long)ws_rows * 2 * D, 0, 1.f);
+                           (long)2 * D, dgamma, 0, 1.f);
         EDITOR_LAUNCH_CHECK();
-        hipError_t e = hipMemcpyAsync(dgamma, workspace + (long)ws_rows * 2 * D, sizeof(float) * D, hipMemcpyDeviceToDevice, stream);
-        if (e != hipSuccess) return (int)e;
-        e = hipMemcpyAsync(dbeta, workspace + (long)ws_rows * 2 * D + D, sizeof(float) * D, hipMemcpyDeviceToDevice, stream);
-        if (e != hipSuccess) return (int)e;
     }
     return 0;
 }

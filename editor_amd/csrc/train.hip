@@ -1,0 +1,95 @@
+// Training-step kernels around the hot path (SURVEY.md 8(f) rows N4 and the drop-path RNG of K5), gfx950.
+//   fused multi-tensor SGD   torch.optim.SGD(momentum, weight_decay) over the per-parameter groups of
+//                            solver/make_optimizer.py:4-29 (bias lr x2) in ONE launch, HBM bound (5 x 4 B per weight)
+//   drop-path row scales     per-sample Bernoulli keep / keep_prob of every block and branch (vit_pytorch.py:52-69,511)
+//                            for the whole backbone in one launch (counter-based RNG)
+#include "common.h"
+#include "../../include/editor_hip.h"
+
+namespace {
+
+constexpr int kChunk = 16384;           // elements per workgroup
+
+// chunk c covers elements [off, off+len) of tensor t;  g' = g + wd*p ; m = first ? g' : mu*m + g' ; p -= lr*m
+__global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict__ p_ptrs, const float* const* __restrict__ g_ptrs,
+    float* const* __restrict__ m_ptrs, const int* __restrict__ chunk_tensor, const long* __restrict__ chunk_off,
+    const long* __restrict__ numel, const float* __restrict__ lr, const float* __restrict__ wd, float momentum, int first)
+{
+    const int t = chunk_tensor[blockIdx.x];
+    const long off = chunk_off[blockIdx.x];
+    const long n = min((long)kChunk, numel[t] - off);
+    float* __restrict__ p = p_ptrs[t] + off;
+    const float* __restrict__ g = g_ptrs[t] + off;
+    float* __restrict__ m = m_ptrs[t] + off;
+    if (!g_ptrs[t]) return;                                   // parameter without a gradient this step
+    const float l = lr[t], w = wd[t];
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m)) & 15) == 0;
+    if (vec) {
+        for (long i = threadIdx.x * 4L; i + 3 < n; i += 1024) {
+            float4 pv = *reinterpret_cast<float4*>(p + i);
+            const float4 gv = *reinterpret_cast<const float4*>(g + i);
+            float4 mv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(m + i);
+            const float4 d = make_float4(gv.x + w * pv.x, gv.y + w * pv.y, gv.z + w * pv.z, gv.w + w * pv.w);
+            mv = first ? d : make_float4(momentum * mv.x + d.x, momentum * mv.y + d.y, momentum * mv.z + d.z, momentum * mv.w + d.w);
+            pv.x -= l * mv.x; pv.y -= l * mv.y; pv.z -= l * mv.z; pv.w -= l * mv.w;
+            *reinterpret_cast<float4*>(m + i) = mv;
+            *reinterpret_cast<float4*>(p + i) = pv;
+        }
+        for (long i = (n & ~3L) + threadIdx.x; i < n; i += 256) {
+            const float d = g[i] + w * p[i];
+            const float mv = first ? d : momentum * m[i] + d;
+            m[i] = mv; p[i] -= l * mv;
+        }
+    } else {
+        for (long i = threadIdx.x; i < n; i += 256) {
+            const float d = g[i] + w * p[i];
+            const float mv = first ? d : momentum * m[i] + d;
+            m[i] = mv; p[i] -= l * mv;
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// scales[(l*2 + branch)*B*T + b*T + t] = keep(l,branch,b) / keep_prob_l ; keep = floor(keep_prob + U[0,1))
+__global__ void droppath_kernel(const float* __restrict__ rates, int L, long B, int T, uint64_t seed, float* __restrict__ scales)
+{
+    const long total = (long)L * 2 * B * T;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long s = e / T;                                 // (layer, branch, sample)
+        const int l = (int)(s / (2 * B));
+        const float keep_prob = 1.f - rates[l];
+        const uint64_t r = mix64(seed * 0x100000001B3ull + (uint64_t)s);
+        const float u = (float)(r >> 40) * (1.f / 16777216.f);
+        scales[e] = floorf(keep_prob + u) / keep_prob;
+    }
+}
+
+}  // namespace
+
+extern "C" int editor_sgd_multi(float* const* p_ptrs, const float* const* g_ptrs, float* const* m_ptrs,
+    const int* chunk_tensor, const long* chunk_off, const long* numel, const float* lr, const float* wd, float momentum,
+    int first, long nchunks, hipStream_t stream)
+{
+    if (nchunks < 1) return 0;
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)nchunks), dim3(256), 0, stream, p_ptrs, g_ptrs, m_ptrs, chunk_tensor,
+                       chunk_off, numel, lr, wd, momentum, first);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int editor_sgd_chunk_elems(void) { return kChunk; }
+
+extern "C" int editor_droppath_scales(const float* rates, int L, long B, int T, long seed, float* scales, hipStream_t stream)
+{
+    const long total = (long)L * 2 * B * T;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(droppath_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rates, L, B, T, (uint64_t)seed, scales);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}

@@ -16,6 +16,14 @@ import torch
 from . import ops
 
 _BF16_CACHE = {}
+_WEIGHT_EPOCH = 0
+
+
+def invalidate_weight_cache():
+    """Call after parameters were modified by something that does not bump tensor version counters
+    (editor_amd.optim.FusedSGD's raw HIP update)."""
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
 
 
 def act_weight(w, dtype):
@@ -27,12 +35,12 @@ def act_weight(w, dtype):
     key = id(w)
     ent = _BF16_CACHE.get(key)
     ver = w._version
-    if ent is None or ent[0]() is not w or ent[1] != ver or ent[3] != w.data_ptr():
+    if ent is None or ent[0]() is not w or ent[1] != ver or ent[3] != w.data_ptr() or ent[4] != _WEIGHT_EPOCH:
         if len(_BF16_CACHE) > 4096:                       # drop entries of dead parameters
             for k in [k for k, e in _BF16_CACHE.items() if e[0]() is None]:
                 del _BF16_CACHE[k]
         ent = (weakref.ref(w), ver, ops.cast(w.detach().contiguous().view(-1), torch.bfloat16).view(w.shape),
-               w.data_ptr())
+               w.data_ptr(), _WEIGHT_EPOCH)
         _BF16_CACHE[key] = ent
     return ent[2]
 

@@ -262,6 +262,8 @@ class EDITOR(nn.Module):
         self.act_dtype = _act_dtype(cfg)
         self.hma_compact = bool(getattr(cfg.MODEL, "HMA_COMPACT", True))
         self.teacher_index = None            # optional (B,N) bool: force the SFTS selection (bf16 protocol)
+        self._drop_rates_dev = None
+        self._drop_step = 0
         self.last_aux = {}
 
     # -- checkpoint compatibility (make_model.py:144-148) ---------------------------------------
@@ -289,12 +291,17 @@ class EDITOR(nn.Module):
         # softmax outputs of every layer; rows padded to a multiple of 4 floats in bf16 mode (16-byte stores)
         ldp = t if self.act_dtype == torch.float32 else (t + 3) // 4 * 4
         probs = torch.empty(base.depth, btot, base.heads, t, ldp, dtype=torch.float32, device=imgs.device)
+        scales = None
+        if self.training and max(base.drop_rates) > 0.0:                       # vit_pytorch.py:52-69: one launch for all
+            if self._drop_rates_dev is None or self._drop_rates_dev.device != imgs.device:
+                self._drop_rates_dev = torch.tensor(base.drop_rates, dtype=torch.float32, device=imgs.device)
+            self._drop_step += 1
+            seed = (int(torch.initial_seed()) * 1000003 + self._drop_step) & 0x7FFFFFFFFFFFFFFF
+            scales = ops.droppath_scales(self._drop_rates_dev, btot, t, seed)
         for i, blk in enumerate(base.blocks):
             rs_a = rs_m = None
-            p = base.drop_rates[i]
-            if self.training and p > 0.0:                                       # vit_pytorch.py:52-69
-                rs_a = self._drop_rows(btot, t, p, imgs.device)
-                rs_m = self._drop_rows(btot, t, p, imgs.device)
+            if scales is not None and base.drop_rates[i] > 0.0:
+                rs_a, rs_m = scales[i, 0], scales[i, 1]
             x = fn.TransformerBlockFn.apply(x, *_block_args(blk.norm1, blk.attn, blk.norm2, blk.mlp), None,
                                             probs[i], base.heads, 1e-6, self.act_dtype, rs_a, rs_m)
         x = fn.LayerNormFn.apply(x, base.norm.weight, base.norm.bias, 1e-6, None)

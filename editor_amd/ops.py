@@ -80,7 +80,7 @@ def _ptr(t, off=0):
     return t.data_ptr() + off * t.element_size()
 
 
-WS_ROWS = 1024
+WS_ROWS = 512
 
 
 # ---------------------------------------------------------------------------------------------
@@ -100,9 +100,10 @@ def layernorm_bwd(dy, x2d, gamma, mean, rstd, rowmask=None, mask_period=0, dx_in
                   m_live=None):
     m, d = x2d.shape
     dx = torch.empty(m, d, dtype=torch.float32, device=x2d.device)
-    dg = torch.empty(d, dtype=torch.float32, device=x2d.device) if want_param_grads else None
-    db = torch.empty(d, dtype=torch.float32, device=x2d.device) if want_param_grads else None
-    ws = workspace(x2d.device, (WS_ROWS + 1) * 2 * d)
+    dgb = torch.empty(2, d, dtype=torch.float32, device=x2d.device) if want_param_grads else None
+    dg = dgb[0] if want_param_grads else None
+    db = dgb[1] if want_param_grads else None
+    ws = workspace(x2d.device, WS_ROWS * 2 * d)
     call("editor_layernorm_bwd", dy, _is_bf16(dy), x2d, gamma, mean, rstd, m, d, rowmask, int(mask_period), dx_in, dx,
          dg, db, ws, WS_ROWS, m_live)
     return dx, dg, db
@@ -379,3 +380,11 @@ def ocfr_bwd(fn, inv, centers, label, dloss):
     df = torch.empty(b, d, dtype=torch.float32, device=fn.device)
     call("editor_ocfr_bwd", fn, inv, centers, label, dloss, b, d, df)
     return df
+
+
+def droppath_scales(rates, b, t, seed):
+    """(L,2,b*t) fp32 per-row drop-path scales keep/keep_prob (vit_pytorch.py:52-69) for every block and branch."""
+    l = rates.numel()
+    out = torch.empty(l, 2, b * t, dtype=torch.float32, device=rates.device)
+    call("editor_droppath_scales", rates, l, b, t, int(seed), out)
+    return out

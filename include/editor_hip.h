@@ -62,8 +62,8 @@ int editor_mask_or(const uint8_t* a, const uint8_t* b, const uint8_t* c, const u
 int editor_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, long M, int D,
                          const uint8_t* rowmask, int mask_period, void* y, int y_bf16, float* mean, float* rstd,
                          const int* m_live, editor_stream_t stream);
-/* backward: dx_out = (dx_in ? dx_in : 0) + dLN/dx ; dgamma/dbeta (D) fp32 (NULL to skip).
- * workspace: (ws_rows+1)*2*D floats. */
+/* backward: dx_out = (dx_in ? dx_in : 0) + dLN/dx ; dgamma/dbeta: ONE (2,D) fp32 buffer (dbeta == dgamma + D; NULL to
+ * skip).  workspace: ws_rows*2*D floats. */
 int editor_layernorm_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
                          const float* rstd, long M, int D, const uint8_t* rowmask, int mask_period,
                          const float* dx_in, float* dx_out, float* dgamma, float* dbeta, float* workspace,
@@ -185,6 +185,18 @@ int editor_ocfr_fwd(const float* feat, long ldf, const long* label, int B, int D
                     float* fnorm, float* inv_norm, float* workspace, float* loss, int accumulate, editor_stream_t stream);
 int editor_ocfr_bwd(const float* fnorm, const float* inv_norm, const float* centers, const long* label,
                     const float* dloss, int B, int D, float* dfeat, editor_stream_t stream);
+
+/* ---- training-step kernels (drop-path RNG of vit_pytorch.py:52-69) ----------------------- */
+
+/* torch.optim.SGD(momentum, weight_decay, dampening 0) over many tensors in one launch.  Pointer tables and per-tensor
+ * lr / wd live in device memory; chunk c covers elements [chunk_off[c], +editor_sgd_chunk_elems()) of tensor chunk_tensor[c].
+ * g_ptrs[t] == NULL skips tensor t.  first != 0: momentum buffers are initialised with the (decayed) gradient. */
+int editor_sgd_multi(float* const* p_ptrs, const float* const* g_ptrs, float* const* m_ptrs, const int* chunk_tensor,
+                     const long* chunk_off, const long* numel, const float* lr, const float* wd, float momentum,
+                     int first, long nchunks, editor_stream_t stream);
+/* per-row drop-path scales keep/keep_prob for L blocks x 2 branches x B samples, expanded over T tokens:
+ * scales (L,2,B*T) fp32; rates (L) fp32 on device; counter-based RNG keyed by `seed`. */
+int editor_droppath_scales(const float* rates, int L, long B, int T, long seed, float* scales, editor_stream_t stream);
 
 /* ---- bring-up probes (tests only) ------------------------------------------------------------- */
 int editor_probe_tr16(const int* addr, uint16_t* out, editor_stream_t stream);

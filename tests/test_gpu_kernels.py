@@ -319,3 +319,39 @@ def test_compact_plan_and_rows(ops):
     back = ops.scatter_rows(xa.reshape(-1, d).cuda(), plan.map_a, nmod * b * t).cpu().view(nmod, b, t, d)
     keep = torch.cat([torch.ones(b, 1, dtype=torch.bool), index.bool()], 1)
     assert torch.equal(back, dense.view(nmod, b, t, d) * keep.view(1, b, t, 1))
+
+
+def test_fused_sgd_matches_torch():
+    from editor_amd.optim import FusedSGD
+    g = _g(21)
+    shapes = [(768, 768), (3072,), (171, 2304), (1, 1, 768), (50001,), (3,)]
+    names = ["a.weight", "a.bias", "b.weight", "cls_token", "c.weight", "d.bias"]
+    ps = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in ps]
+    groups = [{"params": [r], "lr": 2e-3 if "bias" in n else 1e-3, "weight_decay": 1e-4} for n, r in zip(names, ref)]
+    topt = torch.optim.SGD(groups, momentum=0.9)
+    fopt = FusedSGD(list(zip(names, ps)), base_lr=1e-3, weight_decay=1e-4, bias_lr_factor=2.0, weight_decay_bias=1e-4,
+                    momentum=0.9)
+    for step in range(3):
+        for p, r in zip(ps, ref):
+            gr = torch.randn(p.shape, generator=g).cuda()
+            p.grad = gr.clone() if not (step == 1 and p.numel() == 3) else None      # a parameter without a gradient
+            r.grad = gr.clone() if p.grad is not None else None
+        fopt.step()
+        topt.step()
+        for p, r in zip(ps, ref):
+            assert rel_err(p.detach().cpu(), r.detach().cpu()) < 1e-6
+
+
+def test_droppath_scales(ops):
+    rates = torch.linspace(0, 0.1, 12).cuda()
+    s = ops.droppath_scales(rates, 384, 129, 1234).cpu()
+    assert s.shape == (12, 2, 384 * 129)
+    assert torch.all(s[0] == 1.0)                                   # rate 0: always kept, scale 1
+    per_sample = s.view(12, 2, 384, 129)
+    assert torch.all(per_sample == per_sample[..., :1])             # constant over the tokens of a sample
+    kp = 1 - 0.1
+    vals = per_sample[11, :, :, 0].flatten()
+    assert set(torch.unique(vals).tolist()) <= {0.0, float(torch.tensor(1.0) / torch.tensor(kp))}
+    assert abs(float((vals > 0).float().mean()) - kp) < 0.06         # ~90 % kept
+    assert not torch.equal(per_sample[11, 0, :, 0], per_sample[11, 1, :, 0])   # independent draws per branch
