@@ -80,7 +80,7 @@ def _ptr(t, off=0):
     return t.data_ptr() + off * t.element_size()
 
 
-WS_ROWS = 512
+WS_ROWS = 1024
 
 
 # ---------------------------------------------------------------------------------------------
