@@ -1,0 +1,204 @@
+// Loss head that consumes the hot path's outputs, gfx950.  Tiny, latency-bound kernels
+// (B x num_classes, B x 2304) whose job is to keep the whole training step inside libeditor_hip.so.
+//   CrossEntropyLabelSmooth(eps)        layers/softmax_loss.py:4-34
+//   TripletLoss() soft-margin form      layers/triplet_loss.py:16-33 (euclidean_dist), 51-84 (hard_example_mining),
+//                                       121-136 (SoftMarginLoss(dist_an - dist_ap, 1))
+// Every reduction runs in a fixed order (no atomics): the loss and its gradients are run-to-run deterministic.
+#include "common.h"
+#include "../../include/editor_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// one block per sample: row_loss[b] = -sum_c soft_c * log_softmax_c, soft = (1-eps) onehot + eps/C
+__global__ void ce_smooth_fwd_kernel(const float* __restrict__ logits, const long* __restrict__ target, int C, float eps,
+    float* __restrict__ row_loss)
+{
+    __shared__ float red[16];
+    const float* x = logits + (long)blockIdx.x * C;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) m = fmaxf(m, x[c]);
+    m = block_max(m, red);
+    float s = 0.f, sx = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { s += expf(x[c] - m); sx += x[c]; }
+    s = block_sum(s, red);
+    sx = block_sum(sx, red);
+    if (threadIdx.x == 0) {
+        const float lse = m + logf(s);
+        const float lp_t = x[target[blockIdx.x]] - lse;          // log p of the labelled class
+        const float lp_sum = sx - (float)C * lse;                // sum_c log p_c
+        row_loss[blockIdx.x] = -((1.f - eps) * lp_t + eps / (float)C * lp_sum);
+    }
+}
+
+// dlogits[b,c] = g/B * (softmax_c - soft_c)
+__global__ void ce_smooth_bwd_kernel(const float* __restrict__ logits, const long* __restrict__ target, int B, int C,
+    float eps, const float* __restrict__ g, float* __restrict__ dlogits)
+{
+    __shared__ float red[16];
+    const float* x = logits + (long)blockIdx.x * C;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) m = fmaxf(m, x[c]);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) s += expf(x[c] - m);
+    s = block_sum(s, red);
+    const float inv = 1.f / s, k = g[0] / (float)B, u = eps / (float)C;
+    const int t = (int)target[blockIdx.x];
+    float* d = dlogits + (long)blockIdx.x * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+        d[c] = k * (expf(x[c] - m) * inv - u - (c == t ? 1.f - eps : 0.f));
+}
+
+// out[0] (+)= scale * sum_i v[i], fixed order
+__global__ void sum_scalar_kernel(const float* __restrict__ v, int n, float scale, float* __restrict__ out, int accumulate)
+{
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + scale * s;
+}
+
+__global__ void row_sqnorm_kernel(const float* __restrict__ f, long ldf, int D, float* __restrict__ sq)
+{
+    __shared__ float red[16];
+    const float* x = f + (long)blockIdx.x * ldf;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) s += x[c] * x[c];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) sq[blockIdx.x] = s;
+}
+
+// one block per anchor: hardest positive (max distance among equal labels, self included as in the reference) and
+// hardest negative (min among different labels).  Ties resolve to the lowest index.
+// coef[i] = sigmoid(d_ap - d_an); coef[B+i] = 1/d_ap (0 where clamped); coef[2B+i] = 1/d_an.
+__global__ void triplet_mine_kernel(const float* __restrict__ gram, const float* __restrict__ sq,
+    const long* __restrict__ label, int B, int* __restrict__ idx, float* __restrict__ coef, float* __restrict__ row_loss)
+{
+    __shared__ float sv[2][256];
+    __shared__ int si[2][256];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const long li = label[i];
+    const float sqi = sq[i];
+    float bp = -INFINITY, bn = INFINITY;
+    int ip = -1, in_ = -1;
+    for (int j = tid; j < B; j += blockDim.x) {
+        const float q = sqi + sq[j] - 2.f * gram[(long)i * B + j];
+        const float d = sqrtf(fmaxf(q, 1e-12f));
+        if (label[j] == li) { if (d > bp) { bp = d; ip = j; } }
+        else                { if (d < bn) { bn = d; in_ = j; } }
+    }
+    sv[0][tid] = bp; si[0][tid] = ip; sv[1][tid] = bn; si[1][tid] = in_;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float a = sv[0][tid], b = sv[0][tid + o];
+            const int ia = si[0][tid], ib = si[0][tid + o];
+            if (ib >= 0 && (ia < 0 || b > a || (b == a && ib < ia))) { sv[0][tid] = b; si[0][tid] = ib; }
+            const float c = sv[1][tid], e = sv[1][tid + o];
+            const int ic = si[1][tid], ie = si[1][tid + o];
+            if (ie >= 0 && (ic < 0 || e < c || (e == c && ie < ic))) { sv[1][tid] = e; si[1][tid] = ie; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float ap = sv[0][0], an = sv[1][0];
+        const int p = si[0][0], n = si[1][0];
+        idx[i] = p; idx[B + i] = n;
+        const float z = ap - an;                                         // SoftMarginLoss(an - ap, 1) = log(1 + e^z)
+        row_loss[i] = z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z));
+        coef[i] = 1.f / (1.f + expf(-z));
+        const float qp = sqi + sq[p] - 2.f * gram[(long)i * B + p];
+        const float qn = n >= 0 ? sqi + sq[n] - 2.f * gram[(long)i * B + n] : 0.f;
+        coef[B + i] = qp > 1e-12f ? 1.f / ap : 0.f;                      // clamp(min) passes no gradient below the floor
+        coef[2 * B + i] = (n >= 0 && qn > 1e-12f) ? 1.f / an : 0.f;
+    }
+}
+
+// one block per feature row r: gather every anchor's contribution to row r (as anchor, as its positive, as its
+// negative) in anchor order.
+__global__ void triplet_bwd_kernel(const float* __restrict__ f, long ldf, int B, int D, const int* __restrict__ idx,
+    const float* __restrict__ coef, const float* __restrict__ g, float* __restrict__ df)
+{
+    const int r = blockIdx.x;
+    const float k = g[0] / (float)B;
+    const float* fr = f + (long)r * ldf;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float acc = 0.f;
+        for (int i = 0; i < B; ++i) {
+            const int p = idx[i], n = idx[B + i];
+            if (r != i && r != p && r != n) continue;
+            const float s = coef[i], wp = s * coef[B + i], wn = s * coef[2 * B + i];
+            const float fi = f[(long)i * ldf + c];
+            const float ep = (fi - f[(long)p * ldf + c]) * wp;
+            const float en = n >= 0 ? (fi - f[(long)n * ldf + c]) * wn : 0.f;
+            if (r == i) acc += ep - en;
+            if (r == p) acc -= ep;
+            if (r == n) acc += en;
+        }
+        df[(long)r * D + c] = k * acc;
+        (void)fr;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int editor_ce_smooth_fwd(const float* logits, const long* target, int B, int C, float eps, float* row_loss, float* loss,
+                         int accumulate, editor_stream_t stream)
+{
+    if (B <= 0 || C <= 0) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    ce_smooth_fwd_kernel<<<B, 256, 0, st>>>(logits, target, C, eps, row_loss);
+    sum_scalar_kernel<<<1, 256, 0, st>>>(row_loss, B, 1.f / (float)B, loss, accumulate);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+int editor_ce_smooth_bwd(const float* logits, const long* target, int B, int C, float eps, const float* dloss,
+                         float* dlogits, editor_stream_t stream)
+{
+    if (B <= 0 || C <= 0) return 1;
+    ce_smooth_bwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(logits, target, B, C, eps, dloss, dlogits);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+int editor_triplet_fwd(const float* feat, long ldf, const long* label, int B, int D, float* gram, float* sq, int* idx,
+                       float* coef, float* row_loss, float* loss, int accumulate, editor_stream_t stream)
+{
+    if (B <= 1 || D <= 0) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    row_sqnorm_kernel<<<B, 256, 0, st>>>(feat, ldf, D, sq);
+    // gram = feat feat^T on the exact-fp32 matrix cores (B operand in the (N,K) nn.Linear layout = feat itself)
+    const int rc = editor_gemm_f32(feat, feat, gram, B, B, D, ldf, ldf, B, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1.f, 0.f, nullptr,
+                                   nullptr, 1, EDITOR_EPI_NONE, nullptr, 0, stream);
+    if (rc) return rc;
+    triplet_mine_kernel<<<B, 256, 0, st>>>(gram, sq, label, B, idx, coef, row_loss);
+    sum_scalar_kernel<<<1, 256, 0, st>>>(row_loss, B, 1.f / (float)B, loss, accumulate);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+int editor_triplet_bwd(const float* feat, long ldf, int B, int D, const int* idx, const float* coef, const float* dloss,
+                       float* dfeat, editor_stream_t stream)
+{
+    if (B <= 1 || D <= 0) return 1;
+    triplet_bwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(feat, ldf, B, D, idx, coef, dloss, dfeat);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -303,6 +303,43 @@ class OCFRFn(torch.autograd.Function):
         return grads[0], grads[1], grads[2], None, None, None, None, None
 
 
+class CrossEntropyLabelSmoothFn(torch.autograd.Function):
+    """CrossEntropyLabelSmooth.forward (layers/softmax_loss.py:21-34)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, eps):
+        logits = logits.contiguous().float()
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        ops.ce_smooth_fwd(logits, target, eps, loss, accumulate=False)
+        ctx.save_for_backward(logits, target)
+        ctx.eps = eps
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, target = ctx.saved_tensors
+        return ops.ce_smooth_bwd(logits, target, ctx.eps, dloss.contiguous().view(1).float()), None, None
+
+
+class TripletSoftMarginFn(torch.autograd.Function):
+    """TripletLoss(margin=None).forward (layers/triplet_loss.py:121-136): batch-hard mining + SoftMarginLoss."""
+
+    @staticmethod
+    def forward(ctx, feat, label):
+        feat = feat.float()
+        if feat.stride(1) != 1:
+            feat = feat.contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=feat.device)
+        idx, coef = ops.triplet_fwd(feat, label, loss, accumulate=False)
+        ctx.save_for_backward(feat, idx, coef)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        feat, idx, coef = ctx.saved_tensors
+        return ops.triplet_bwd(feat, idx, coef, dloss.contiguous().view(1).float()), None
+
+
 class GatherRowsFn(torch.autograd.Function):
     """out[r] = x2d[src[r]] (zeros where src[r] < 0): row movement between the dense token tensor and the packed
     layouts of the compacted HMA head.  Every source row is gathered at most once, so backward is a plain scatter."""

@@ -1,37 +1,43 @@
-"""Loss head that CONSUMES the hot path's outputs - row N1 of SURVEY.md 8(f) ("next", not yet a HIP kernel).
+"""Loss head that CONSUMES the hot path's train-mode outputs - row N1 of SURVEY.md 8(f).
 
-Host-side tensor ops (device plumbing) restating the reference's loss assembly so that bench.py times a
-complete training step and the harness matches engine/processor.py:82-92:
-    CrossEntropyLabelSmooth(eps=0.1)   layers/softmax_loss.py:4-34
-    TripletLoss() soft-margin, batch-hard, un-normalised Euclidean   layers/triplet_loss.py:51-136
-    loss_func = ID_LOSS_WEIGHT * xent + TRIPLET_LOSS_WEIGHT * triplet   layers/make_loss.py:36-56
+Mirrors the reference's loss assembly so that bench.py times a complete training step and a harness written for
+engine/processor.py:82-92 runs unchanged:
+    CrossEntropyLabelSmooth(eps=0.1)                                   layers/softmax_loss.py:4-34
+    TripletLoss() soft-margin, batch-hard, un-normalised Euclidean     layers/triplet_loss.py:51-136
+    loss_func = ID_LOSS_WEIGHT * xent + TRIPLET_LOSS_WEIGHT * triplet  layers/make_loss.py:36-56
+Both terms run as HIP kernels (csrc/loss.hip) through the C ABI; CPU tensors are rejected, there is no fallback.
 """
 import torch
-import torch.nn.functional as F
+
+from . import functional as Fn
 
 
 def cross_entropy_label_smooth(logits, target, eps=0.1):
-    logp = F.log_softmax(logits.float(), dim=1)
-    c = logits.shape[1]
-    onehot = torch.zeros_like(logp).scatter_(1, target.unsqueeze(1), 1)
-    soft = (1 - eps) * onehot + eps / c
-    return (-soft * logp).mean(0).sum()
+    return Fn.CrossEntropyLabelSmoothFn.apply(logits, target, float(eps))
 
 
 def triplet_soft_margin(feat, labels):
-    feat = feat.float()
-    n = feat.shape[0]
-    sq = feat.pow(2).sum(1, keepdim=True)
-    dist = (sq + sq.t() - 2 * feat @ feat.t()).clamp(min=1e-12).sqrt()
-    same = labels.view(n, 1).eq(labels.view(1, n))
-    d_ap = dist.masked_fill(~same, float("-inf")).max(1).values
-    d_an = dist.masked_fill(same, float("inf")).min(1).values
-    return F.soft_margin_loss(d_an - d_ap, torch.ones_like(d_an))
+    return Fn.TripletSoftMarginFn.apply(feat, labels)
 
 
-def loss_pairs(output, target):
+def make_loss(cfg=None, num_classes=None):
+    """layers/make_loss.py:13-56 for the configuration the reference trains with (sampler softmax_triplet,
+    METRIC_LOSS_TYPE triplet, NO_MARGIN, label smoothing on).  Returns loss_func(score, feat, target, target_cam)."""
+    idw = float(getattr(getattr(cfg, "MODEL", None), "ID_LOSS_WEIGHT", 1.0)) if cfg is not None else 1.0
+    trw = float(getattr(getattr(cfg, "MODEL", None), "TRIPLET_LOSS_WEIGHT", 1.0)) if cfg is not None else 1.0
+
+    def loss_func(score, feat, target, target_cam=None):
+        return idw * cross_entropy_label_smooth(score, target) + trw * triplet_soft_margin(feat, target)
+
+    return loss_func
+
+
+def loss_pairs(output, target, loss_fn=None):
     """engine/processor.py:82-92: odd-length output = (score_i, feat_i) pairs + trailing aux loss."""
-    loss = output[-1]
-    for i in range(0, len(output) - 1, 2):
-        loss = loss + cross_entropy_label_smooth(output[i], target) + triplet_soft_margin(output[i + 1], target)
+    loss_fn = loss_fn or make_loss()
+    npair = len(output) - (len(output) % 2)
+    loss = output[-1] if len(output) % 2 == 1 else None
+    for i in range(0, npair, 2):
+        term = loss_fn(score=output[i], feat=output[i + 1], target=target)
+        loss = term if loss is None else loss + term
     return loss

@@ -382,6 +382,41 @@ def ocfr_bwd(fn, inv, centers, label, dloss):
     return df
 
 
+def ce_smooth_fwd(logits, target, eps, loss, accumulate):
+    b, c = logits.shape
+    call("editor_ce_smooth_fwd", logits, target, b, c, float(eps), workspace(logits.device, b), loss,
+         1 if accumulate else 0)
+
+
+def ce_smooth_bwd(logits, target, eps, dloss):
+    b, c = logits.shape
+    d = torch.empty_like(logits)
+    call("editor_ce_smooth_bwd", logits, target, b, c, float(eps), dloss, d)
+    return d
+
+
+def triplet_fwd(feat, label, loss, accumulate):
+    """Returns (idx (2B) int32, coef (3B) fp32) saved for backward."""
+    feat, ldf = _rows_view(feat)
+    b, d = feat.shape
+    dev = feat.device
+    gram = torch.empty(b, b, dtype=torch.float32, device=dev)
+    sq = torch.empty(b, dtype=torch.float32, device=dev)
+    idx = torch.empty(2 * b, dtype=torch.int32, device=dev)
+    coef = torch.empty(3 * b, dtype=torch.float32, device=dev)
+    call("editor_triplet_fwd", _ptr(feat), ldf, label, b, d, gram, sq, idx, coef, workspace(dev, b), loss,
+         1 if accumulate else 0)
+    return idx, coef
+
+
+def triplet_bwd(feat, idx, coef, dloss):
+    feat, ldf = _rows_view(feat)
+    b, d = feat.shape
+    df = torch.empty(b, d, dtype=torch.float32, device=feat.device)
+    call("editor_triplet_bwd", _ptr(feat), ldf, b, d, idx, coef, dloss, df)
+    return df
+
+
 def droppath_scales(rates, b, t, seed):
     """(L,2,b*t) fp32 per-row drop-path scales keep/keep_prob (vit_pytorch.py:52-69) for every block and branch."""
     l = rates.numel()

@@ -186,6 +186,22 @@ int editor_ocfr_fwd(const float* feat, long ldf, const long* label, int B, int D
 int editor_ocfr_bwd(const float* fnorm, const float* inv_norm, const float* centers, const long* label,
                     const float* dloss, int B, int D, float* dfeat, editor_stream_t stream);
 
+/* ---- loss head (layers/make_loss.py:36-56 consumes the hot path's train-mode outputs) ------- */
+
+/* CrossEntropyLabelSmooth(eps).forward (layers/softmax_loss.py:21-34): loss (+)= mean_b( -sum_c soft_bc log_softmax_bc ),
+ * soft = (1-eps) onehot + eps/C.  row_loss: B floats of scratch.  bwd: dlogits = dloss[0]/B * (softmax - soft). */
+int editor_ce_smooth_fwd(const float* logits, const long* target, int B, int C, float eps, float* row_loss, float* loss,
+                         int accumulate, editor_stream_t stream);
+int editor_ce_smooth_bwd(const float* logits, const long* target, int B, int C, float eps, const float* dloss,
+                         float* dlogits, editor_stream_t stream);
+/* TripletLoss() without margin (layers/triplet_loss.py:16-33,51-84,121-136): Euclidean distances with the 1e-12
+ * clamp, batch-hard positive / negative per anchor, loss (+)= mean softplus(d_ap - d_an).  feat rows have stride ldf.
+ * Scratch / saved for backward: gram (B,B), sq (B), idx (2B: positive, negative), coef (3B), row_loss (B). */
+int editor_triplet_fwd(const float* feat, long ldf, const long* label, int B, int D, float* gram, float* sq, int* idx,
+                       float* coef, float* row_loss, float* loss, int accumulate, editor_stream_t stream);
+int editor_triplet_bwd(const float* feat, long ldf, int B, int D, const int* idx, const float* coef, const float* dloss,
+                       float* dfeat, editor_stream_t stream);
+
 /* ---- training-step kernels (drop-path RNG of vit_pytorch.py:52-69) ----------------------- */
 
 /* torch.optim.SGD(momentum, weight_decay, dampening 0) over many tensors in one launch.  Pointer tables and per-tensor

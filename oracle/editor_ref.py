@@ -380,3 +380,34 @@ def projection_loss(outputs, seed=5):
         r = synth.uniform(seed, "proj/%d" % i, tuple(o.shape))
         total = total + (o * r).mean()
     return total
+
+
+# ----------------------------------------------------------------------------------------------
+# N1  loss head (layers/make_loss.py:36-56; softmax_loss.py:4-34; triplet_loss.py:16-33,51-136)
+# ----------------------------------------------------------------------------------------------
+def cross_entropy_label_smooth(logits, target, eps=0.1):
+    """CrossEntropyLabelSmooth.forward: (-((1-eps)*onehot + eps/K) * log_softmax).mean(0).sum()."""
+    logp = F.log_softmax(logits, dim=1)
+    k = logits.shape[1]
+    soft = torch.zeros_like(logp).scatter_(1, target.unsqueeze(1), 1) * (1 - eps) + eps / k
+    return (-soft * logp).mean(0).sum()
+
+
+def triplet_soft_margin(feat, labels):
+    """TripletLoss(margin=None): un-normalised Euclidean distances (clamp 1e-12, sqrt), batch-hard mining,
+    SoftMarginLoss(dist_an - dist_ap, 1)."""
+    n = feat.shape[0]
+    sq = feat.pow(2).sum(1, keepdim=True)
+    dist = (sq.expand(n, n) + sq.expand(n, n).t() - 2 * feat @ feat.t()).clamp(min=1e-12).sqrt()
+    same = labels.view(n, 1).eq(labels.view(1, n))
+    d_ap = dist[same].view(n, -1).max(1).values
+    d_an = dist[~same].view(n, -1).min(1).values
+    return F.soft_margin_loss(d_an - d_ap, torch.ones_like(d_an))
+
+
+def loss_pairs(output, target):
+    """engine/processor.py:82-92: (score_i, feat_i) pairs + trailing aux loss."""
+    loss = output[-1] if len(output) % 2 == 1 else 0.0
+    for i in range(0, len(output) - (len(output) % 2), 2):
+        loss = loss + cross_entropy_label_smooth(output[i], target) + triplet_soft_margin(output[i + 1], target)
+    return loss

@@ -184,3 +184,30 @@ def state_dict_keys():
 
 if __name__ == "__main__" and "keys" in sys.argv[1:]:
     state_dict_keys()
+
+
+def f7_loss(seed=51):
+    """F7 (row N1): the reference's loss head - make_loss(softmax_triplet, label smoothing on, soft-margin triplet)
+    (layers/make_loss.py:36-56, softmax_loss.py:4-34, triplet_loss.py:51-136) on seeded scores / features."""
+    from types import SimpleNamespace
+    ref_shims.install()
+    import importlib
+    mk = importlib.import_module("layers.make_loss")
+    cfg = SimpleNamespace(DATALOADER=SimpleNamespace(SAMPLER="softmax_triplet"),
+                          MODEL=SimpleNamespace(METRIC_LOSS_TYPE="triplet", NO_MARGIN=True, IF_LABELSMOOTH="on",
+                                                ID_LOSS_WEIGHT=1.0, TRIPLET_LOSS_WEIGHT=1.0),
+                          SOLVER=SimpleNamespace(MARGIN=0.3))
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        loss_fn, _ = mk.make_loss(cfg, num_classes=171)
+    b, c, d = 32, 171, 2304
+    score = synth.normal(seed, "loss/score", (b, c), 2.0).requires_grad_(True)
+    feat = synth.normal(seed, "loss/feat", (b, d), 1.0).requires_grad_(True)
+    target = torch.arange(4).repeat_interleave(8)
+    loss = loss_fn(score=score, feat=feat, target=target, target_cam=None)
+    loss.backward()
+    save("f7_loss", loss=loss, dscore=score.grad, dfeat_norm=feat.grad.norm(), dfeat=feat.grad[:, :64], seed=seed)
+
+
+if __name__ == "__main__" and "f7" in sys.argv[1:]:
+    f7_loss()

@@ -103,3 +103,17 @@ def test_f6_blocks(oracle):
     assert rel_err(a[:, :2, :8, :], g["block3_attn"]) < 1e-5
     assert rel_err(z[:, ::16, :64], g["hma_out"]) < 1e-5
     assert abs(z.norm().item() / float(g["hma_out_norm"]) - 1) < 1e-5
+
+
+def test_f7_loss_head(oracle):
+    g = load_golden("f7_loss")
+    seed = int(g["seed"])
+    score = synth.normal(seed, "loss/score", (32, 171), 2.0).requires_grad_(True)
+    feat = synth.normal(seed, "loss/feat", (32, 2304), 1.0).requires_grad_(True)
+    target = torch.arange(4).repeat_interleave(8)
+    loss = oracle.loss_pairs((score, feat), target)
+    loss.backward()
+    assert rel_err(loss.detach(), g["loss"]) < 1e-6
+    assert rel_err(score.grad, g["dscore"]) < 1e-5
+    assert rel_err(feat.grad[:, :64], g["dfeat"]) < 1e-5
+    assert abs(feat.grad.norm().item() / float(g["dfeat_norm"]) - 1) < 1e-5
