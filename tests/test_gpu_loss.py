@@ -32,7 +32,7 @@ def test_loss_terms_match_oracle(oracle, b, k, c, d):
     score = synth.normal(seed, "s", (b, c), 3.0)
     wide = synth.normal(seed, "f", (b, d + 16), 0.7)            # features arrive as a strided column slice
     target = torch.arange(b // k).repeat_interleave(k)
-    target = target[synth.integers(seed, "perm", (b,), 0, 1 << 30).argsort()]
+    target = target[synth.integers(seed, "perm", (b,), 1 << 30).argsort()]
     up = 0.37
     sr, wr = score.clone().requires_grad_(True), wide.clone().requires_grad_(True)
     (oracle.cross_entropy_label_smooth(sr, target) * up).backward()
