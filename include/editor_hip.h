@@ -202,6 +202,25 @@ int editor_triplet_fwd(const float* feat, long ldf, const long* label, int B, in
 int editor_triplet_bwd(const float* feat, long ldf, int B, int D, const int* idx, const float* coef, const float* dloss,
                        float* dfeat, editor_stream_t stream);
 
+/* ---- retrieval evaluation (utils/metrics.py consumes the hot path's eval-mode features) ------ */
+
+/* F.normalize(x, p=2, dim=1): y = x / max(||x||, eps) (utils/metrics.py:259-261). */
+int editor_l2norm_rows(const float* x, long ldx, long M, int D, float eps, float* y, editor_stream_t stream);
+/* euclidean_distance (utils/metrics.py:12-18): dist (Q,G) = qq + gg^T - 2 qf gf^T, fp32.  qq (Q), gg (G): scratch. */
+int editor_distmat_f32(const float* qf, long ldq, const float* gf, long ldg, int Q, int G, int D, float* qq, float* gg,
+                       float* dist, editor_stream_t stream);
+/* np.argsort(distmat, axis=1) (utils/metrics.py:143): order (Q,G) int32, ascending distance, exactly tied distances by
+ * ascending gallery index.  P = power of two >= G; keys: Q*P 64-bit words of scratch. */
+int editor_rank_sort(const float* dist, int Q, int G, int P, unsigned long long* keys, int* order, editor_stream_t stream);
+/* eval_func / eval_func_msrv (utils/metrics.py:151-183, 66-123): per query, drop the gallery entries that share the
+ * query's pid AND aux id (aux = camera ids, or scene ids for the MSVR310 protocol); ap (Q) = average precision,
+ * first_pos (Q) = 0-based rank of the first match among the kept entries (-1: query has no match, skipped);
+ * totals[0] = sum of ap over valid queries, totals[1] = number of valid queries, cmc_counts[r], r < max_rank <= 1024 =
+ * number of valid queries matched within rank r.  The caller divides (cmc = counts / valid, mAP = sum / valid). */
+int editor_rank_metrics(const int* order, const long* q_pids, const long* g_pids, const long* q_aux, const long* g_aux,
+                        int Q, int G, int max_rank, double* ap, int* first_pos, double* totals, int* cmc_counts,
+                        editor_stream_t stream);
+
 /* ---- training-step kernels (drop-path RNG of vit_pytorch.py:52-69) ----------------------- */
 
 /* torch.optim.SGD(momentum, weight_decay, dampening 0) over many tensors in one launch.  Pointer tables and per-tensor

@@ -211,3 +211,46 @@ def f7_loss(seed=51):
 
 if __name__ == "__main__" and "f7" in sys.argv[1:]:
     f7_loss()
+
+
+def retrieval_case(seed, nq, ng, d, ids, cams):
+    """Seeded query/gallery features with identity structure (so that ranks are non-trivial) + labels."""
+    n = nq + ng
+    pids = synth.integers(seed, "ret/pid", (n,), ids).numpy()
+    camids = synth.integers(seed, "ret/cam", (n,), cams).numpy()
+    scenes = synth.integers(seed, "ret/scene", (n,), 3).numpy()
+    proto = synth.normal(seed, "ret/proto", (ids, d), 1.0)
+    feats = proto[torch.from_numpy(pids)] * 0.6 + synth.normal(seed, "ret/noise", (n, d), 1.0)
+    return feats, pids, camids, scenes
+
+
+def f8_retrieval(seed=71):
+    """F8 (row N2): the reference's R1_mAP_eval / eval_func / eval_func_msrv (utils/metrics.py) on seeded features."""
+    import tempfile
+    np.str = str                                     # utils/metrics.py:47 uses the removed alias
+    sys.path.insert(0, "/root/reference")
+    import utils.metrics as M
+    nq, ng, d = 48, 200, 64
+    feats, pids, camids, scenes = retrieval_case(seed, nq, ng, d, 12, 4)
+    ev = M.R1_mAP_eval(nq, max_rank=50, feat_norm=True)
+    ev.reset()
+    for s in range(0, nq + ng, 31):
+        ev.update((feats[s:s + 31], pids[s:s + 31], camids[s:s + 31]))
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        cmc, m_ap, dist, _, _, qf, gf = ev.compute()
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:       # eval_func_msrv writes re.txt into the cwd
+        os.chdir(tmp)
+        try:
+            cmc_s, map_s = M.eval_func_msrv(dist, pids[:nq], pids[nq:], camids[:nq], camids[nq:], scenes[:nq], scenes[nq:])
+        finally:
+            os.chdir(cwd)
+    raw = M.euclidean_distance(feats[:nq], feats[nq:])
+    cmc_raw, map_raw = M.eval_func(raw, pids[:nq], pids[nq:], camids[:nq], camids[nq:], max_rank=20)
+    save("f8_retrieval", seed=seed, cmc=cmc, mAP=np.float64(m_ap), dist=dist[:8], order=np.argsort(dist, axis=1)[:, :50],
+         cmc_scene=cmc_s, mAP_scene=np.float64(map_s), cmc_raw=cmc_raw, mAP_raw=np.float64(map_raw), dist_raw=raw[:8])
+
+
+if __name__ == "__main__" and "f8" in sys.argv[1:]:
+    f8_retrieval()

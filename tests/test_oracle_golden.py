@@ -117,3 +117,31 @@ def test_f7_loss_head(oracle):
     assert rel_err(score.grad, g["dscore"]) < 1e-5
     assert rel_err(feat.grad[:, :64], g["dfeat"]) < 1e-5
     assert abs(feat.grad.norm().item() / float(g["dfeat_norm"]) - 1) < 1e-5
+
+
+def _retrieval_case(seed, nq, ng, d, ids, cams):
+    n = nq + ng
+    pids = synth.integers(seed, "ret/pid", (n,), ids).numpy()
+    camids = synth.integers(seed, "ret/cam", (n,), cams).numpy()
+    scenes = synth.integers(seed, "ret/scene", (n,), 3).numpy()
+    proto = synth.normal(seed, "ret/proto", (ids, d), 1.0)
+    feats = proto[torch.from_numpy(pids)] * 0.6 + synth.normal(seed, "ret/noise", (n, d), 1.0)
+    return feats, pids, camids, scenes
+
+
+def test_f8_retrieval_metrics():
+    import numpy as np
+    from oracle import metrics_ref as mr
+    g = load_golden("f8_retrieval")
+    nq = 48
+    feats, pids, camids, scenes = _retrieval_case(int(g["seed"]), nq, 200, 64, 12, 4)
+    cmc, m_ap, dist = mr.r1_map_eval(feats, pids, camids, nq, max_rank=50)
+    assert np.array_equal(dist[:8], g["dist"])
+    assert np.array_equal(cmc, g["cmc"]) and m_ap == float(g["mAP"])
+    assert np.array_equal(np.argsort(dist, axis=1)[:, :50], g["order"])
+    cmc_s, map_s, _ = mr.eval_func(dist, pids[:nq], pids[nq:], scenes[:nq], scenes[nq:], 50)
+    assert np.array_equal(cmc_s, g["cmc_scene"]) and map_s == float(g["mAP_scene"])
+    raw = mr.euclidean_distance(feats[:nq], feats[nq:])
+    cmc_r, map_r, _ = mr.eval_func(raw, pids[:nq], pids[nq:], camids[:nq], camids[nq:], 20)
+    assert np.array_equal(raw[:8], g["dist_raw"])
+    assert np.array_equal(cmc_r, g["cmc_raw"]) and map_r == float(g["mAP_raw"])
