@@ -127,18 +127,28 @@ __global__ void triplet_mine_kernel(const float* __restrict__ gram, const float*
 }
 
 // one block per feature row r: gather every anchor's contribution to row r (as anchor, as its positive, as its
-// negative) in anchor order.
+// negative) in anchor order.  The few anchors that touch row r are listed in LDS first.
 __global__ void triplet_bwd_kernel(const float* __restrict__ f, long ldf, int B, int D, const int* __restrict__ idx,
     const float* __restrict__ coef, const float* __restrict__ g, float* __restrict__ df)
 {
+    __shared__ unsigned char flag[1024];
+    __shared__ int list[1024];
+    __shared__ int nlist;
     const int r = blockIdx.x;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) flag[i] = (i == r || idx[i] == r || idx[B + i] == r) ? 1 : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int i = 0; i < B; ++i) if (flag[i]) list[n++] = i;
+        nlist = n;
+    }
+    __syncthreads();
     const float k = g[0] / (float)B;
-    const float* fr = f + (long)r * ldf;
+    const int n_l = nlist;
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
         float acc = 0.f;
-        for (int i = 0; i < B; ++i) {
-            const int p = idx[i], n = idx[B + i];
-            if (r != i && r != p && r != n) continue;
+        for (int q = 0; q < n_l; ++q) {
+            const int i = list[q], p = idx[i], n = idx[B + i];
             const float s = coef[i], wp = s * coef[B + i], wn = s * coef[2 * B + i];
             const float fi = f[(long)i * ldf + c];
             const float ep = (fi - f[(long)p * ldf + c]) * wp;
@@ -148,7 +158,6 @@ __global__ void triplet_bwd_kernel(const float* __restrict__ f, long ldf, int B,
             if (r == n) acc += en;
         }
         df[(long)r * D + c] = k * acc;
-        (void)fr;
     }
 }
 
@@ -195,7 +204,7 @@ int editor_triplet_fwd(const float* feat, long ldf, const long* label, int B, in
 int editor_triplet_bwd(const float* feat, long ldf, int B, int D, const int* idx, const float* coef, const float* dloss,
                        float* dfeat, editor_stream_t stream)
 {
-    if (B <= 1 || D <= 0) return 1;
+    if (B <= 1 || B > 1024 || D <= 0) return 1;
     triplet_bwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(feat, ldf, B, D, idx, coef, dloss, dfeat);
     EDITOR_LAUNCH_CHECK();
     return 0;
