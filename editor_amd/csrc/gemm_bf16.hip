@@ -41,6 +41,7 @@ struct GemmB16Args {
     int stagger;                             // experiment: start delay (x 8k cycles) of every second workgroup
     const int* m_live;                       // device scalar: only the first *m_live token rows are live (NULL: all)
     int live_is_k;                           // the token-row extent is the reduction (wgrad) instead of M
+    int pp_staged;                           // 256x256 kernel: LDS-staged epilogue (full-line stores) instead of the direct one
 };
 
 // exact-erf GELU (nn.GELU default) for bf16 outputs: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. 4
@@ -647,6 +648,274 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void gemm_bf16_pipe_kernel(GemmB16A
         epilogue_store<C_F32, MT>(g, acc, m0 + wm, n0 + wn, lane, blockIdx.y == 0);
 }
 
+// =====================================================================================================
+// 256 x 256 "ping-pong" variant.  Eight wavefronts as two groups of four (wr = 0 / 1, one wave of each group per SIMD)
+// that run ONE BARRIER APART: every s_barrier flips the roles, so that while one group feeds the matrix core with a
+// 16-MFMA cluster (one 64x32 quadrant of its 128x64 output over the whole K-tile) the other group issues its LDS
+// fragment reads and its share of the LDS-DMA for a later K-tile.  Per K-tile a wave runs four such phases
+//   P1: read A0,B0 (12 x ds_read_b128)  DMA B1(t+1)  | MFMA A0 x B0
+//   P2: read A1    (8)                  DMA A0(t+2)  | MFMA A1 x B0
+//   P3: read B1    (4, over B0)         DMA B0(t+2)  | MFMA A1 x B1
+//   P4:                                 DMA A1(t+2), s_waitcnt vmcnt(6)  | MFMA A0 x B1
+// LDS = 2 K-tile buffers x 4 units of 16 KiB.  A "unit" is the part of an operand tile that ONE phase reads: A0 = the
+// first 64 rows of each 128-row wave-row (rows 0-63 and 128-191 of the tile), A1 the others; B0 = the first 32 columns
+// of each 64-column wave-column, B1 the others - so a unit is free again right after its phase and is refilled two
+// K-tiles ahead, 5-7 phases before it is read.  One counted vmcnt per K-tile (three units stay in flight across it).
+// Fragments are read one phase after the wait that retires their unit; a unit is restaged no earlier than the phase
+// after its last read, whose lgkmcnt(0) precedes the barrier (so the other group's reads are retired too).
+// =====================================================================================================
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+template <int IMM>
+__device__ __forceinline__ short8_t lds_rd128(uint32_t addr)
+{
+    short8_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+    return v;
+}
+template <int IMM>
+__device__ __forceinline__ short8_t lds_rdtr(uint32_t addr)
+{
+    short4_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(IMM));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(IMM + 1024));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// Per-lane BYTE offsets (32-bit) of the two 1 KiB pieces this wave stages of a unit, relative to the operand's
+// k0 = 0 position.  SPAN = 64 (A: rows per wave-row half) or 32 (B); image index rho in [0,128) -> tile-local index
+// (rho / SPAN) * 2*SPAN + sub*SPAN + rho % SPAN.  The K-tile position is a wave-uniform offset added at issue time.
+template <bool KMAJOR, int SPAN>
+__device__ __forceinline__ void pp_unit_offsets(long ld, int r0, int R, int sub, int wu, int lane, uint32_t (&vo)[2])
+{
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int piece = wu * 2 + j;
+        if (KMAJOR) {
+            const int rho = piece * 8 + (lane >> 3);
+            const int loc = (rho / SPAN) * (2 * SPAN) + sub * SPAN + (rho % SPAN);
+            const int c = (lane & 7) ^ (rho & 7);
+            vo[j] = (uint32_t)(((long)min(r0 + loc, R - 1) * ld + c * 8) * 2);
+        } else {
+            const int kr = piece * 4 + (lane >> 4);
+            const int p = lane & 15;
+            const int col = ((((p >> 1) ^ swz_rowk(kr)) << 4) | ((p & 1) << 3));
+            const int loc = (col / SPAN) * (2 * SPAN) + sub * SPAN + (col % SPAN);
+            vo[j] = (uint32_t)(((long)kr * ld + min(r0 + loc, R - 8)) * 2);
+        }
+    }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR, bool C_F32>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
+{
+    constexpr int UNIT = 16384, KTB = 4 * UNIT;                 // per K-tile buffer: A0 | A1 | B0 | B1
+    constexpr int UA0 = 0, UA1 = UNIT, UB0 = 2 * UNIT, UB1 = 3 * UNIT;
+    constexpr int GM = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int grp = GM * g.tiles_n;
+    const int gm0 = (wgid / grp) * GM, rem = wgid % grp;
+    const int gsz = min(GM, g.tiles_m - gm0);
+    const int tile_m = gm0 + rem % gsz, tile_n = rem / gsz;
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    int ktiles = g.K / BK;
+    if (g.m_live) {
+        const int live = *g.m_live;
+        if (g.live_is_k) ktiles = min(ktiles, (live + BK - 1) / BK);
+        else if (m0 >= live) return;
+    }
+    const int per = (ktiles + g.splitk - 1) / g.splitk;
+    const int kt0 = blockIdx.y * per, kt1 = min(ktiles, kt0 + per);
+    const int nk = max(kt1 - kt0, 0);
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int wr = wu >> 2, wc = wu & 3;
+    const int li = lane & 15, lg = lane >> 4;
+
+    float4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane fragment addresses inside a unit (buffer 0); [s] for k-major images, [i] / [j] for row-k images
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    uint32_t adA[4], adB[2];
+    if (A_KMAJOR) {
+        const int row = wr * 64 + li;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) adA[s] = smem_base + row * 128 + (((s * 4 + lg) ^ (row & 7)) << 4);
+        adA[2] = adA[3] = 0;
+    } else {
+        const int k0 = lg * 8 + (li >> 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) adA[i] = smem_base + k0 * 256 + (((wr * 4 + i) ^ swz_rowk(k0)) << 5) + ((li & 3) << 3);
+    }
+    if (B_KMAJOR) {
+        const int row = wc * 32 + li;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) adB[s] = smem_base + row * 128 + (((s * 4 + lg) ^ (row & 7)) << 4);
+    } else {
+        const int k0 = lg * 8 + (li >> 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) adB[j] = smem_base + k0 * 256 + (((wc * 2 + j) ^ swz_rowk(k0)) << 5) + ((li & 3) << 3);
+    }
+    // LDS-DMA source offsets of this wave's two pieces of each unit (A0, A1, B0, B1)
+    uint32_t voA[2][2], voB[2][2];
+    pp_unit_offsets<A_KMAJOR, 64>(g.lda, m0, g.M, 0, wu, lane, voA[0]);
+    pp_unit_offsets<A_KMAJOR, 64>(g.lda, m0, g.M, 1, wu, lane, voA[1]);
+    pp_unit_offsets<B_KMAJOR, 32>(g.ldb, n0, g.N, 0, wu, lane, voB[0]);
+    pp_unit_offsets<B_KMAJOR, 32>(g.ldb, n0, g.N, 1, wu, lane, voB[1]);
+    const long kstepA = A_KMAJOR ? (long)BK * 2 : (long)BK * g.lda * 2;       // bytes per K-tile
+    const long kstepB = B_KMAJOR ? (long)BK * 2 : (long)BK * g.ldb * 2;
+    const char* baseA = reinterpret_cast<const char*>(g.A) + kt0 * kstepA;
+    const char* baseB = reinterpret_cast<const char*>(g.B) + kt0 * kstepB;
+    short8_t fa[4][2], fb0[2][2], fb1[2][2];
+
+    // (DS immediate offsets are 16 bits: the second K-tile buffer, 64 KiB up, goes through the address register)
+    auto read_a = [&](auto U, auto BUF) {
+        constexpr int base = decltype(U)::value, bo = decltype(BUF)::value * KTB;
+        static_for<0, 4>([&](auto i) {
+            static_for<0, 2>([&](auto s) {
+                constexpr int I = decltype(i)::value, S = decltype(s)::value;
+                if constexpr (A_KMAJOR) fa[I][S] = lds_rd128<base + I * 2048>(adA[S] + bo);
+                else fa[I][S] = lds_rdtr<base + S * 8192>(adA[I] + bo);
+            });
+        });
+    };
+    auto read_b = [&](short8_t (&fbv)[2][2], auto U, auto BUF) {
+        constexpr int base = decltype(U)::value, bo = decltype(BUF)::value * KTB;
+        static_for<0, 2>([&](auto j) {
+            static_for<0, 2>([&](auto s) {
+                constexpr int J = decltype(j)::value, S = decltype(s)::value;
+                if constexpr (B_KMAJOR) fbv[J][S] = lds_rd128<base + J * 2048>(adB[S] + bo);
+                else fbv[J][S] = lds_rdtr<base + S * 8192>(adB[J] + bo);
+            });
+        });
+    };
+    auto mma_q = [&](short8_t (&fbv)[2][2], auto MI, auto NJ) {
+        constexpr int mi = decltype(MI)::value, nj = decltype(NJ)::value;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mi * 4 + i][nj * 2 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbv[j][s], fa[i][s], acc[mi * 4 + i][nj * 2 + j], 0, 0, 0);
+    };
+    auto dma2 = [&](const char* src, const uint32_t (&vo)[2], char* unit) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + vo[j]),
+                                             (__attribute__((address_space(3))) void*)(unit + (wu * 2 + j) * 1024), 16, 0, 0);
+    };
+    auto stage_a = [&](int t, int sub) {   // unit A<sub> of K-tile t
+        dma2(baseA + t * kstepA, voA[sub], smem + (t & 1) * KTB + (sub ? UA1 : UA0));
+    };
+    auto stage_b = [&](int t, int sub) {
+        dma2(baseB + t * kstepB, voB[sub], smem + (t & 1) * KTB + (sub ? UB1 : UB0));
+    };
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+#define PP_WAIT_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_MMA(fbv, MI, NJ) do { __builtin_amdgcn_s_setprio(1); mma_q(fbv, MI{}, NJ{}); __builtin_amdgcn_s_setprio(0); } while (0)
+
+    // one K-tile (four phases) out of buffer BUF.  Units: A0,B0 are read in P1, B1 in P2, A1 in P3; each is refilled
+    // for K-tile t+2 in the phase after (A1: two phases after, at P1 of t+1).
+    auto ktile = [&](int t, auto BUF) {
+        using B = decltype(BUF);
+        // P1
+        read_b(fb0, std::integral_constant<int, UB0>{}, B{});
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(std::integral_constant<int, UA0>{}, B{});
+        if (t + 1 < nk) stage_a(t + 1, 1);
+        PP_WAIT_LGKM0(); PP_BAR();
+        PP_MMA(fb0, c0, c0);
+        PP_BAR();
+        // P2
+        read_b(fb1, std::integral_constant<int, UB1>{}, B{});
+        if (t + 2 < nk) stage_a(t + 2, 0);
+        PP_WAIT_LGKM0(); PP_BAR();
+        PP_MMA(fb1, c0, c1);
+        PP_BAR();
+        // P3
+        read_a(std::integral_constant<int, UA1>{}, B{});
+        if (t + 2 < nk) stage_b(t + 2, 0);
+        PP_WAIT_LGKM0(); PP_BAR();
+        PP_MMA(fb1, c1, c1);
+        PP_BAR();
+        // P4
+        if (t + 2 < nk) {
+            stage_b(t + 2, 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            // through A1(t+1); three units stay in flight
+        } else if (t + 1 < nk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_BAR();
+        PP_MMA(fb0, c1, c0);
+        PP_BAR();
+    };
+
+    if (nk > 0) {
+        stage_a(0, 0); stage_b(0, 0); stage_b(0, 1); stage_a(0, 1);
+        if (nk > 1) {
+            stage_a(1, 0); stage_b(1, 0); stage_b(1, 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    PP_BAR();
+    if (wr == 1) PP_BAR();                                              // group 1 runs one barrier behind group 0
+    int t = 0;
+    for (; t + 1 < nk; t += 2) { ktile(t, c0{}); ktile(t + 1, c1{}); }
+    if (t < nk) ktile(t, c0{});
+    if (wr == 0) PP_BAR();                                              // re-align the two groups
+#undef PP_MMA
+#undef PP_WAIT_LGKM0
+
+    const bool staged = g.pp_staged && g.beta == 0.f && (g.splitk == 1 || g.slabs) && (g.N & 7) == 0 && (g.ldc & 7) == 0 &&
+                        (g.ldaux & 7) == 0;
+    if (staged) {
+        // two passes of 128 rows through the (now free) operand buffers: fp32 image, padded rows
+        constexpr int RBP = 256 * 4 + 16;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            PP_BAR();
+            if (wr == pass) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<float4_t*>(smem + (i * 16 + li) * RBP + (wc * 64 + j * 16 + lg * 4) * 4) = acc[i][j];
+            }
+            PP_BAR();
+            const int mp = m0 + pass * 128;
+            switch (g.epilogue) {
+                case EDITOR_EPI_RESIDUAL: epilogue_copy_out<C_F32, EDITOR_EPI_RESIDUAL, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
+                case EDITOR_EPI_GELU:     epilogue_copy_out<C_F32, EDITOR_EPI_GELU, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
+                case EDITOR_EPI_GELU_BWD: epilogue_copy_out<C_F32, EDITOR_EPI_GELU_BWD, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
+                default:                  epilogue_copy_out<C_F32, EDITOR_EPI_NONE, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
+            }
+        }
+    } else {
+        epilogue_store<C_F32, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, blockIdx.y == 0);
+    }
+#undef PP_BAR
+}
+
 __global__ void scale_c_kernel(float* C, long rows, int cols, long ld, float beta)
 {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -706,8 +975,37 @@ int launch_pipe_t(GemmB16Args g, hipStream_t stream)
 }
 
 template <bool AK, bool BK_, bool CF>
+int launch_pp(GemmB16Args g, hipStream_t stream)
+{
+    constexpr int LDS = 128 * (256 * 4 + 16) > 131072 ? 128 * (256 * 4 + 16) : 131072;
+    auto kern = gemm_bf16_pp_kernel<AK, BK_, CF>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    g.tiles_m = (g.M + 255) / 256;
+    g.tiles_n = (g.N + 255) / 256;
+    // measured: the LDS-staged epilogue (full-line 16-byte stores) beats the direct one on every layout here
+    // (fwd N=2304,K=768: 701 vs 530 TFLOP/s; dgrad 974 vs 905)
+    const char* st = getenv("EDITOR_GEMM_PP_STAGED");
+    g.pp_staged = st ? atoi(st) : 1;
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(512), LDS, stream, g);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool AK, bool BK_, bool CF>
 int launch_pipe(const GemmB16Args& g, hipStream_t stream)
 {
+    // 256x256 ping-pong kernel where it measures faster (tools/gemm_bench.py, M = 49 536 token rows): forward products
+    // with >= 4 tile columns (qkv 566 -> 701, fc1 627 -> 699 TFLOP/s) and every dgrad (777 -> 896, 850 -> 974, 604 -> 624,
+    // 649 -> 747); N = 768 forward outputs tie (3 tile columns: 582 tiles on 256 CUs) and wgrad (both operands through
+    // ds_read_b64_tr_b16, twice the LDS instructions per phase) is slower (742 vs 792), so those stay on 256x128.
+    static const int pp_mode = getenv("EDITOR_GEMM_PP") ? atoi(getenv("EDITOR_GEMM_PP")) : -1;   // 1 force, 0 off
+    const bool pp_auto = g.M >= 2048 && g.splitk == 1 && ((AK && BK_) ? (g.N >= 1024 && g.N % 256 == 0) : (AK && !BK_ && g.N >= 256));
+    if (g.N >= 256 && (pp_mode == 1 || (pp_mode < 0 && pp_auto))) return launch_pp<AK, BK_, CF>(g, stream);
     // 256-wide tiles unless they would leave the machine badly filled (N = 768: 3 tile columns)
     const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.splitk;
     // measured (tools/gemm_bench.py): the 256x128 3-stage form is >= the 256x256 2-stage form on every hot-path
@@ -755,7 +1053,7 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
     GemmB16Args g{(const bf16_t*)A, (const bf16_t*)B, slabs ? (void*)splitk_ws : C, M, N, K, lda, ldb, ldc, alpha,
                   slabs ? 0.f : beta, bias, rowscale, splitk, (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux,
                   slabs ? 1 : 0, getenv("EDITOR_GEMM_STAGGER") ? atoi(getenv("EDITOR_GEMM_STAGGER")) : 0,
-                  m_live, transA ? 1 : 0};
+                  m_live, transA ? 1 : 0, 0};
     if (m_live && (!pipe || (splitk > 1 && !slabs))) return (int)hipErrorInvalidValue;   // live-row form: pipelined path only
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
     int rc;
