@@ -337,12 +337,13 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
             if (m >= g.M || n >= g.N) continue;                  // N is a multiple of 8 on this path (checked on the host)
             float x[8] = {lo[it].x, lo[it].y, lo[it].z, lo[it].w, hi[it].x, hi[it].y, hi[it].z, hi[it].w};
             const float rs = g.rowscale ? g.rowscale[m] : 1.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                x[e] *= g.alpha;
-                if (add_bias) x[e] += g.bias[n + e];
-                x[e] *= rs;
+            float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (add_bias) {                                      // n is a multiple of 8: two aligned 16-byte loads
+                const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n), b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
+                bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (x[e] * g.alpha + bv[e]) * rs;
             if (EPI == EDITOR_EPI_RESIDUAL) {
                 const float* r = reinterpret_cast<const float*>(g.aux) + (long)m * g.ldaux + n;
                 const float4 r0 = *reinterpret_cast<const float4*>(r), r1 = *reinterpret_cast<const float4*>(r + 4);
@@ -999,12 +1000,13 @@ int launch_pp(GemmB16Args g, hipStream_t stream)
 template <bool AK, bool BK_, bool CF>
 int launch_pipe(const GemmB16Args& g, hipStream_t stream)
 {
-    // 256x256 ping-pong kernel where it measures faster (tools/gemm_bench.py, M = 49 536 token rows): forward products
-    // with >= 4 tile columns (qkv 566 -> 701, fc1 627 -> 699 TFLOP/s) and every dgrad (777 -> 896, 850 -> 974, 604 -> 624,
-    // 649 -> 747); N = 768 forward outputs tie (3 tile columns: 582 tiles on 256 CUs) and wgrad (both operands through
-    // ds_read_b64_tr_b16, twice the LDS instructions per phase) is slower (742 vs 792), so those stay on 256x128.
+    // 256x256 ping-pong kernel where it measures faster (tools/gemm_bench.py with GEMM_EPI=1, M = 49 536 token rows,
+    // TFLOP/s 256x128 -> 256x256): qkv+bias 596 -> 828, fc1+bias+GELU 412 -> 516, proj+residual 344 -> 448, fc2+residual
+    // 702 -> 865, dgrads 777 -> 896, 850 -> 974, 604 -> 624, 649 -> 747, fc2 dgrad+GELU' 460 -> 507.  wgrad (both operands
+    // through ds_read_b64_tr_b16, twice the LDS instructions per phase, and few output tiles) is slower (742 vs 792) and
+    // stays on 256x128 with split-K slabs.
     static const int pp_mode = getenv("EDITOR_GEMM_PP") ? atoi(getenv("EDITOR_GEMM_PP")) : -1;   // 1 force, 0 off
-    const bool pp_auto = g.M >= 2048 && g.splitk == 1 && ((AK && BK_) ? (g.N >= 1024 && g.N % 256 == 0) : (AK && !BK_ && g.N >= 256));
+    const bool pp_auto = g.M >= 2048 && g.splitk == 1 && AK && g.N >= 512;
     if (g.N >= 256 && (pp_mode == 1 || (pp_mode < 0 && pp_auto))) return launch_pp<AK, BK_, CF>(g, stream);
     // 256-wide tiles unless they would leave the machine badly filled (N = 768: 3 tile columns)
     const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.splitk;

@@ -46,6 +46,24 @@ def main():
         if not only or kind_only == "fwd":
             t = bench(lambda: ops.gemm(x, w, y, m, n, k, k, k, n, 0, 0), iters)
             rows.append(("fwd", n, k, fl / t / 1e9))
+        if os.environ.get("GEMM_EPI") and (not only or kind_only == "fwd"):
+            # the hot path's real forward epilogues: bias (qkv), bias + GELU + saved pre-activation (fc1),
+            # bias + drop-path row scale + fp32 residual (proj / fc2)
+            bias = torch.randn(n, device=dev, generator=g)
+            t = bench(lambda: ops.gemm(x, w, y, m, n, k, k, k, n, 0, 0, bias=bias), iters)
+            rows.append(("fwd+bias", n, k, fl / t / 1e9))
+            pre = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+            t = bench(lambda: ops.gemm(x, w, y, m, n, k, k, k, n, 0, 0, bias=bias, epilogue=ops.EPI_GELU, aux=pre), iters)
+            rows.append(("fwd+gelu", n, k, fl / t / 1e9))
+            res = torch.randn(m, n, device=dev, generator=g)
+            yf = torch.empty(m, n, device=dev)
+            rs = torch.rand(m, device=dev, generator=g)
+            t = bench(lambda: ops.gemm(x, w, yf, m, n, k, k, k, n, 0, 0, bias=bias, rowscale=rs, epilogue=ops.EPI_RESIDUAL, aux=res), iters)
+            rows.append(("fwd+resid", n, k, fl / t / 1e9))
+            dpre = torch.empty(m, k, device=dev, dtype=torch.bfloat16)
+            prek = torch.randn(m, k, device=dev, generator=g).bfloat16()
+            t = bench(lambda: ops.gemm(dy, w, dpre, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=prek), iters)
+            rows.append(("dgrad+gelu'", n, k, fl / t / 1e9))
         if not only or kind_only == "dgrad":
             t = bench(lambda: ops.gemm(dy, w, dx, m, k, n, n, k, k, 0, 1), iters)
             rows.append(("dgrad", n, k, fl / t / 1e9))
