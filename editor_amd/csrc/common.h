@@ -10,16 +10,16 @@ typedef uint16_t bf16_t;   // raw bfloat16 bits; arithmetic is always done in fp
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
     return __uint_as_float(((uint32_t)v) << 16);
 }
-// round-to-nearest-even, NaN preserved (matches torch's float->bfloat16 cast)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even, NaN stays NaN (matches torch's float->bfloat16 cast): gfx950's v_cvt_pk_bf16_f32, one
+// instruction per PAIR of values (the shift/add software form costs ~9 VALU instructions per value and made the GEMM
+// epilogues VALU-bound)
+typedef float float2_t_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t_ __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const float2_t_ v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t_));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "../../include/editor_hip.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) short short4_t;
@@ -42,6 +43,7 @@ struct GemmB16Args {
     const int* m_live;                       // device scalar: only the first *m_live token rows are live (NULL: all)
     int live_is_k;                           // the token-row extent is the reduction (wgrad) instead of M
     int pp_staged;                           // 256x256 kernel: LDS-staged epilogue (full-line stores) instead of the direct one
+    unsigned long long* trace;               // debug (EDITOR_GEMM_TRACE): per-workgroup s_memtime stamps
 };
 
 // exact-erf GELU (nn.GELU default) for bf16 outputs: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. 4
@@ -335,6 +337,7 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
             const int row = c / GPR, cg = c % GPR;
             const int m = m0 + row, n = n0 + cg * 8;
             if (m >= g.M || n >= g.N) continue;                  // N is a multiple of 8 on this path (checked on the host)
+            if (g.stagger == 91 && m >= 0) continue;             // experiment: no math, no stores
             float x[8] = {lo[it].x, lo[it].y, lo[it].z, lo[it].w, hi[it].x, hi[it].y, hi[it].z, hi[it].w};
             const float rs = g.rowscale ? g.rowscale[m] : 1.f;
             float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -374,7 +377,8 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
             } else {
                 uint4 o;
                 o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]); o.z = pack_bf16x2(x[4], x[5]); o.w = pack_bf16x2(x[6], x[7]);
-                *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = o;
+                if (g.stagger == 92) { if (o.x == 0x12345678u) *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = o; }   // experiment: math, no stores
+                else *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = o;
             }
         }
     }
@@ -742,6 +746,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const int wr = wu >> 2, wc = wu & 3;
     const int li = lane & 15, lg = lane >> 4;
+    // De-phase the first wave of workgroups (one per CU): identical tiles otherwise keep all 256 CUs in lockstep, and
+    // the chip alternates between a phase that only uses the matrix cores and a phase in which every CU drains its
+    // output tile at once and the HBM write bandwidth is the limit.  Spread over four start offsets, some CUs are
+    // always storing while the others compute; the offsets persist because a CU's next workgroup starts when its
+    // previous one ends.
+    if (g.stagger && g.stagger < 90 && bid < 256) {
+        const int ph = (bid >> 3) & 3;
+        for (int i = 0; i < ph * g.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+#define PP_STAMP(k) do { if (g.trace && threadIdx.x == 0) g.trace[(long)(blockIdx.y * gridDim.x + bid) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    PP_STAMP(0);
 
     float4_t acc[8][4];
 #pragma unroll
@@ -879,11 +894,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
         }
     }
     PP_BAR();
+    PP_STAMP(1);
     if (wr == 1) PP_BAR();                                              // group 1 runs one barrier behind group 0
     int t = 0;
     for (; t + 1 < nk; t += 2) { ktile(t, c0{}); ktile(t + 1, c1{}); }
     if (t < nk) ktile(t, c0{});
     if (wr == 0) PP_BAR();                                              // re-align the two groups
+    PP_STAMP(2);
 #undef PP_MMA
 #undef PP_WAIT_LGKM0
 
@@ -910,10 +927,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
                 case EDITOR_EPI_GELU_BWD: epilogue_copy_out<C_F32, EDITOR_EPI_GELU_BWD, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
                 default:                  epilogue_copy_out<C_F32, EDITOR_EPI_NONE, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
             }
+            PP_STAMP(3 + pass);
         }
     } else {
         epilogue_store<C_F32, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, blockIdx.y == 0);
     }
+    if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(5); }
+#undef PP_STAMP
 #undef PP_BAR
 }
 
@@ -992,6 +1012,32 @@ int launch_pp(GemmB16Args g, hipStream_t stream)
     // (fwd N=2304,K=768: 701 vs 530 TFLOP/s; dgrad 974 vs 905)
     const char* st = getenv("EDITOR_GEMM_PP_STAGED");
     g.pp_staged = st ? atoi(st) : 1;
+    static const bool trace = getenv("EDITOR_GEMM_TRACE") != nullptr;
+    if (trace) {                                                   // debug: per-workgroup phase timeline, printed per launch
+        const int nwg = g.tiles_m * g.tiles_n * g.splitk;
+        static unsigned long long* buf = nullptr;
+        if (!buf && hipMalloc(&buf, sizeof(unsigned long long) * 8 * 65536) != hipSuccess) return 1;
+        if (nwg <= 65536) {
+            hipMemsetAsync(buf, 0, sizeof(unsigned long long) * 8 * nwg, stream);
+            g.trace = buf;
+            hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(512), LDS, stream, g);
+            hipStreamSynchronize(stream);
+            static unsigned long long host[8 * 65536];
+            hipMemcpy(host, buf, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost);
+            double seg[5] = {0, 0, 0, 0, 0};
+            unsigned long long t_min = ~0ull, t_max = 0;
+            for (int i = 0; i < nwg; ++i) {
+                const unsigned long long* r = host + (long)i * 8;
+                for (int k = 0; k < 5; ++k) seg[k] += (double)(r[k == 4 ? 5 : k + 1] - r[k == 4 ? 4 : k]);
+                if (r[0] < t_min) t_min = r[0];
+                if (r[5] > t_max) t_max = r[5];
+            }
+            fprintf(stderr, "[pp trace] M=%d N=%d K=%d epi=%d cf32=%d wgs=%d span=%.0f | per-wg mean ticks: prologue %.0f main %.0f "
+                    "epi0 %.0f epi1 %.0f drain %.0f\n", g.M, g.N, g.K, g.epilogue, (int)CF, nwg, (double)(t_max - t_min),
+                    seg[0] / nwg, seg[1] / nwg, seg[2] / nwg, seg[3] / nwg, seg[4] / nwg);
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(512), LDS, stream, g);
     EDITOR_LAUNCH_CHECK();
     return 0;
@@ -1055,7 +1101,7 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
     GemmB16Args g{(const bf16_t*)A, (const bf16_t*)B, slabs ? (void*)splitk_ws : C, M, N, K, lda, ldb, ldc, alpha,
                   slabs ? 0.f : beta, bias, rowscale, splitk, (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux,
                   slabs ? 1 : 0, getenv("EDITOR_GEMM_STAGGER") ? atoi(getenv("EDITOR_GEMM_STAGGER")) : 0,
-                  m_live, transA ? 1 : 0, 0};
+                  m_live, transA ? 1 : 0, 0, nullptr};
     if (m_live && (!pipe || (splitk > 1 && !slabs))) return (int)hipErrorInvalidValue;   // live-row form: pipelined path only
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
     int rc;
