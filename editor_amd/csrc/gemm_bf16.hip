@@ -46,21 +46,38 @@ struct GemmB16Args {
     unsigned long long* trace;               // debug (EDITOR_GEMM_TRACE): per-workgroup s_memtime stamps
 };
 
-// exact-erf GELU (nn.GELU default) for bf16 outputs: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. 4
-// orders below bf16 resolution) - one v_exp + one v_rcp + 6 FMAs instead of libm's branchy erff; the SAME exponential
-// exp(-a^2/2) also gives the Gaussian term of the derivative.  (The f32 parity kernels keep erff.)
-__device__ __forceinline__ void erf_half_terms(float a, float& cdf, float& gauss)
+// exact-erf GELU (nn.GELU default) for bf16 outputs, two values per instruction (v_pk_fma_f32 / v_pk_mul_f32):
+// Phi(a) = 0.5 erfc(-a/sqrt2) with erfc(z) ~ (1 + a1 z + ... + a6 z^6)^-16 for z >= 0 (Abramowitz-Stegun 7.1.28,
+// |abs err| <= 3e-7 -> 8e-7 on gelu in fp32 arithmetic, four orders below bf16 resolution): six packed FMAs, four packed
+// squarings and ONE reciprocal per value - no exponential, where libm's erff is branchy and the 7.1.26 form needs
+// v_exp + v_rcp (quarter-rate instructions; the GELU epilogue was VALU-bound on them).  The f32 parity kernels keep erff.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f_t phi2(v2f_t a)
 {
-    const float z = fabsf(a) * 0.70710678118654752f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
-    const float e = __expf(-z * z);                                   // = exp(-a^2/2)
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float erf_abs = fmaf(-poly, e, 1.f);
-    cdf = 0.5f * (1.f + copysignf(erf_abs, a));                        // Phi(a)
-    gauss = e;
+    const v2f_t z = __builtin_elementwise_abs(a) * 0.70710678118654752f;
+    v2f_t p = __builtin_elementwise_fma(z, (v2f_t)(0.0000430638f), (v2f_t)(0.0002765672f));
+    p = __builtin_elementwise_fma(p, z, (v2f_t)(0.0001520143f));
+    p = __builtin_elementwise_fma(p, z, (v2f_t)(0.0092705272f));
+    p = __builtin_elementwise_fma(p, z, (v2f_t)(0.0422820123f));
+    p = __builtin_elementwise_fma(p, z, (v2f_t)(0.0705230784f));
+    p = __builtin_elementwise_fma(p, z, (v2f_t)(1.0f));
+    p = p * p; p = p * p; p = p * p; p = p * p;                              // overflow -> inf -> rcp 0: the tails are exact
+    v2f_t h, r;
+    h.x = 0.5f * __builtin_amdgcn_rcpf(p.x); h.y = 0.5f * __builtin_amdgcn_rcpf(p.y);     // 0.5 erfc(|a|/sqrt2)
+    r.x = a.x > 0.f ? 1.f - h.x : h.x; r.y = a.y > 0.f ? 1.f - h.y : h.y;
+    return r;
 }
-__device__ __forceinline__ float gelu_f(float a) { float c, g; erf_half_terms(a, c, g); return a * c; }
-__device__ __forceinline__ float gelu_grad_f(float a) { float c, g; erf_half_terms(a, c, g); return fmaf(a * 0.3989422804014327f, g, c); }
+__device__ __forceinline__ v2f_t unpack_bf16x2(uint32_t w) { return v2f_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+__device__ __forceinline__ v2f_t gelu2(v2f_t a) { return a * phi2(a); }
+// d/da gelu = Phi(a) + a phi(a), phi(a) = exp(-a^2/2)/sqrt(2 pi)
+__device__ __forceinline__ v2f_t gelu_grad2(v2f_t a)
+{
+    const v2f_t q = a * a * -0.72134752044448170f;                           // -a^2/2 * log2(e)
+    v2f_t e; e.x = __builtin_amdgcn_exp2f(q.x); e.y = __builtin_amdgcn_exp2f(q.y);
+    return __builtin_elementwise_fma(a * 0.3989422804014327f, e, phi2(a));
+}
+__device__ __forceinline__ float gelu_f(float a) { return gelu2(v2f_t{a, a}).x; }
+__device__ __forceinline__ float gelu_grad_f(float a) { return gelu_grad2(v2f_t{a, a}).x; }
 
 // ---- LDS images -------------------------------------------------------------------------------------
 // k-major tile  [128 rows][64 k]  : byte = row*128 + ((chunk ^ (row&7)) * 16), chunk = k/8
@@ -188,12 +205,12 @@ __device__ __forceinline__ void epilogue_store(const GemmB16Args& g, float4_t (&
             } else if (g.epilogue == EDITOR_EPI_GELU) {       // aux = v (pre-activation, bf16), C = gelu(v)
                 uint2 pre; pre.x = pack_bf16x2(v.x, v.y); pre.y = pack_bf16x2(v.z, v.w);
                 *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = pre;
-                v.x = gelu_f(__uint_as_float(pre.x << 16)); v.y = gelu_f(__uint_as_float(pre.x & 0xffff0000u));
-                v.z = gelu_f(__uint_as_float(pre.y << 16)); v.w = gelu_f(__uint_as_float(pre.y & 0xffff0000u));
+                const v2f_t g0 = gelu2(unpack_bf16x2(pre.x)), g1 = gelu2(unpack_bf16x2(pre.y));
+                v.x = g0.x; v.y = g0.y; v.z = g1.x; v.w = g1.y;
             } else if (g.epilogue == EDITOR_EPI_GELU_BWD) {   // C = v * gelu'(aux), aux = saved pre-activation
                 const uint2 pre = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ldaux + n);
-                v.x *= gelu_grad_f(__uint_as_float(pre.x << 16)); v.y *= gelu_grad_f(__uint_as_float(pre.x & 0xffff0000u));
-                v.z *= gelu_grad_f(__uint_as_float(pre.y << 16)); v.w *= gelu_grad_f(__uint_as_float(pre.y & 0xffff0000u));
+                const v2f_t g0 = gelu_grad2(unpack_bf16x2(pre.x)), g1 = gelu_grad2(unpack_bf16x2(pre.y));
+                v.x *= g0.x; v.y *= g0.y; v.z *= g1.x; v.w *= g1.y;
             }
             if (C_F32) {
                 float* c = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n;
@@ -337,7 +354,6 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
             const int row = c / GPR, cg = c % GPR;
             const int m = m0 + row, n = n0 + cg * 8;
             if (m >= g.M || n >= g.N) continue;                  // N is a multiple of 8 on this path (checked on the host)
-            if (g.stagger == 91 && m >= 0) continue;             // experiment: no math, no stores
             float x[8] = {lo[it].x, lo[it].y, lo[it].z, lo[it].w, hi[it].x, hi[it].y, hi[it].z, hi[it].w};
             const float rs = g.rowscale ? g.rowscale[m] : 1.f;
             float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -358,16 +374,16 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
                 const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    x[2 * e] = gelu_f(__uint_as_float(pw[e] << 16));
-                    x[2 * e + 1] = gelu_f(__uint_as_float(pw[e] & 0xffff0000u));
+                    const v2f_t gv = gelu2(unpack_bf16x2(pw[e]));
+                    x[2 * e] = gv.x; x[2 * e + 1] = gv.y;
                 }
             } else if (EPI == EDITOR_EPI_GELU_BWD) {
                 const uint4 p = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ldaux + n);
                 const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    x[2 * e] *= gelu_grad_f(__uint_as_float(pw[e] << 16));
-                    x[2 * e + 1] *= gelu_grad_f(__uint_as_float(pw[e] & 0xffff0000u));
+                    const v2f_t gv = gelu_grad2(unpack_bf16x2(pw[e]));
+                    x[2 * e] *= gv.x; x[2 * e + 1] *= gv.y;
                 }
             }
             if (C_F32) {
@@ -377,8 +393,7 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
             } else {
                 uint4 o;
                 o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]); o.z = pack_bf16x2(x[4], x[5]); o.w = pack_bf16x2(x[6], x[7]);
-                if (g.stagger == 92) { if (o.x == 0x12345678u) *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = o; }   // experiment: math, no stores
-                else *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = o;
+                *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = o;
             }
         }
     }
@@ -906,7 +921,53 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
 
     const bool staged = g.pp_staged && g.beta == 0.f && (g.splitk == 1 || g.slabs) && (g.N & 7) == 0 && (g.ldc & 7) == 0 &&
                         (g.ldaux & 7) == 0;
-    if (staged) {
+    if (staged && !C_F32 && (g.epilogue == EDITOR_EPI_NONE || g.epilogue == EDITOR_EPI_GELU)) {
+        // bf16 outputs whose epilogue is per-element: scale / bias / row scale in registers, ONE pass of the whole
+        // 256x256 tile through LDS as bf16 (rows padded to 528 B), then 16-byte row-contiguous stores.  GELU: the
+        // staged value is the (rounded) pre-activation, which is an output anyway; the activation is computed from it
+        // on the way out, as the unfused form would.
+        constexpr int RB = 256 * 2 + 16;
+        PP_BAR();
+        const bool add_bias = g.bias && blockIdx.y == 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ml = wr * 128 + i * 16 + li;
+            const float rs = (g.rowscale && m0 + ml < g.M) ? g.rowscale[m0 + ml] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nl = wc * 64 + j * 16 + lg * 4;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (add_bias && n0 + nl < g.N) bv = *reinterpret_cast<const float4*>(g.bias + n0 + nl);
+                uint2 o;
+                o.x = pack_bf16x2((acc[i][j][0] * g.alpha + bv.x) * rs, (acc[i][j][1] * g.alpha + bv.y) * rs);
+                o.y = pack_bf16x2((acc[i][j][2] * g.alpha + bv.z) * rs, (acc[i][j][3] * g.alpha + bv.w) * rs);
+                *reinterpret_cast<uint2*>(smem + ml * RB + nl * 2) = o;
+            }
+        }
+        PP_BAR();
+        PP_STAMP(3);
+        bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+        bf16_t* Ab = reinterpret_cast<bf16_t*>(g.aux);
+        const bool gelu = g.epilogue == EDITOR_EPI_GELU;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int c = threadIdx.x + it * 512;
+            const int row = c >> 5, cg = c & 31;
+            const int m = m0 + row, n = n0 + cg * 8;
+            uint4 p = *reinterpret_cast<const uint4*>(smem + row * RB + cg * 16);
+            if (m >= g.M || n >= g.N) continue;
+            if (gelu) {
+                *reinterpret_cast<uint4*>(Ab + (long)m * g.ldaux + n) = p;
+                uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                { const v2f_t gv = gelu2(unpack_bf16x2(pw[e])); pw[e] = pack_bf16x2(gv.x, gv.y); }
+                p = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+            }
+            *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = p;
+        }
+        PP_STAMP(4);
+    } else if (staged) {
         // two passes of 128 rows through the (now free) operand buffers: fp32 image, padded rows
         constexpr int RBP = 256 * 4 + 16;
 #pragma unroll 1
@@ -998,7 +1059,7 @@ int launch_pipe_t(GemmB16Args g, hipStream_t stream)
 template <bool AK, bool BK_, bool CF>
 int launch_pp(GemmB16Args g, hipStream_t stream)
 {
-    constexpr int LDS = 128 * (256 * 4 + 16) > 131072 ? 128 * (256 * 4 + 16) : 131072;
+    constexpr int LDS = 256 * (256 * 2 + 16);                   // >= 2 K-tile buffers, the fp32 half-tile image and the bf16 tile image
     auto kern = gemm_bf16_pp_kernel<AK, BK_, CF>;
     static bool attr_done = false;
     if (!attr_done) {
