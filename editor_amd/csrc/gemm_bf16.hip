@@ -341,6 +341,23 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         float4 lo[ITERS / 2], hi[ITERS / 2];
+        // the epilogue's global operands (residual rows / saved pre-activations) are requested for the whole half up
+        // front, so that their latency is paid once and under the LDS reads instead of once per item
+        float4 ra[EPI == EDITOR_EPI_RESIDUAL ? ITERS / 2 : 1], rb[EPI == EDITOR_EPI_RESIDUAL ? ITERS / 2 : 1];
+        uint4 pa[EPI == EDITOR_EPI_GELU_BWD ? ITERS / 2 : 1];
+        if (EPI == EDITOR_EPI_RESIDUAL || EPI == EDITOR_EPI_GELU_BWD) {
+#pragma unroll
+            for (int it = 0; it < ITERS / 2; ++it) {
+                const int c = threadIdx.x + (half * (ITERS / 2) + it) * NTHREADS;
+                const int m = min(m0 + c / GPR, g.M - 1), n = min(n0 + (c % GPR) * 8, g.N - 8);
+                if (EPI == EDITOR_EPI_RESIDUAL) {
+                    const float* r = reinterpret_cast<const float*>(g.aux) + (long)m * g.ldaux + n;
+                    ra[it] = *reinterpret_cast<const float4*>(r); rb[it] = *reinterpret_cast<const float4*>(r + 4);
+                } else {
+                    pa[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ldaux + n);
+                }
+            }
+        }
 #pragma unroll
         for (int it = 0; it < ITERS / 2; ++it) {
             const int c = threadIdx.x + (half * (ITERS / 2) + it) * NTHREADS;
@@ -364,8 +381,7 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = (x[e] * g.alpha + bv[e]) * rs;
             if (EPI == EDITOR_EPI_RESIDUAL) {
-                const float* r = reinterpret_cast<const float*>(g.aux) + (long)m * g.ldaux + n;
-                const float4 r0 = *reinterpret_cast<const float4*>(r), r1 = *reinterpret_cast<const float4*>(r + 4);
+                const float4 r0 = ra[it], r1 = rb[it];
                 x[0] += r0.x; x[1] += r0.y; x[2] += r0.z; x[3] += r0.w; x[4] += r1.x; x[5] += r1.y; x[6] += r1.z; x[7] += r1.w;
             } else if (EPI == EDITOR_EPI_GELU) {                 // aux <- pre-activation (bf16), C <- gelu(rounded pre-activation)
                 uint4 p;
@@ -378,7 +394,7 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
                     x[2 * e] = gv.x; x[2 * e + 1] = gv.y;
                 }
             } else if (EPI == EDITOR_EPI_GELU_BWD) {
-                const uint4 p = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ldaux + n);
+                const uint4 p = pa[it];
                 const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
