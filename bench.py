@@ -243,7 +243,8 @@ def main():
                        "global_batch": world * b, "parallelism": f"dp{world}", "loss": round(lossv, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "kernel": "gemm_bf16_pipe_kernel (256x128x64 tiles, 3 LDS-DMA stages, v_mfma_f32_16x16x32_bf16)",
+                         "kernel": "bf16 GEMM family: gemm_bf16_pp_kernel (256x256x64 ping-pong, fwd + dgrad) and gemm_bf16_pipe_kernel "
+                                   "(256x128x64, 3 LDS-DMA stages, wgrad), v_mfma_f32_16x16x32_bf16",
                          "launches_per_step": launches, "gemm_ms_per_step": round(ms, 3),
                          "alg_tflop_per_step": round(flops / 1e12, 2),
                          "by_kind": {k: {"tflops": round(f / (m_ * 1e-3) / 1e12, 1), "ms_per_step": round(m_, 3), "launches": n}
