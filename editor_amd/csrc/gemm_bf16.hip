@@ -945,18 +945,28 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
         constexpr int RB = 256 * 2 + 16;
         PP_BAR();
         const bool add_bias = g.bias && blockIdx.y == 0;
+        float4 bv[4];                                          // this lane's four column groups: loaded once, not per row
+        float rsv[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = wc * 64 + j * 16 + lg * 4;
+            bv[j] = (add_bias && n0 + nl < g.N) ? *reinterpret_cast<const float4*>(g.bias + n0 + nl) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int ml = wr * 128 + i * 16 + li;
-            const float rs = (g.rowscale && m0 + ml < g.M) ? g.rowscale[m0 + ml] : 1.f;
+            rsv[i] = (g.rowscale && m0 + ml < g.M) ? g.rowscale[m0 + ml] : 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ml = wr * 128 + i * 16 + li;
+            const float rs = rsv[i];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int nl = wc * 64 + j * 16 + lg * 4;
-                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (add_bias && n0 + nl < g.N) bv = *reinterpret_cast<const float4*>(g.bias + n0 + nl);
                 uint2 o;
-                o.x = pack_bf16x2((acc[i][j][0] * g.alpha + bv.x) * rs, (acc[i][j][1] * g.alpha + bv.y) * rs);
-                o.y = pack_bf16x2((acc[i][j][2] * g.alpha + bv.z) * rs, (acc[i][j][3] * g.alpha + bv.w) * rs);
+                o.x = pack_bf16x2((acc[i][j][0] * g.alpha + bv[j].x) * rs, (acc[i][j][1] * g.alpha + bv[j].y) * rs);
+                o.y = pack_bf16x2((acc[i][j][2] * g.alpha + bv[j].z) * rs, (acc[i][j][3] * g.alpha + bv[j].w) * rs);
                 *reinterpret_cast<uint2*>(smem + ml * RB + nl * 2) = o;
             }
         }
