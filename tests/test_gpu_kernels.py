@@ -262,6 +262,58 @@ def test_gemm_epilogues(ops, dtype):
     assert rel_err(out.float().cpu(), pr.grad) < tol
 
 
+@pytest.mark.parametrize("tb", [0, 1])
+@pytest.mark.parametrize("m,n,k", [(2100, 768, 512), (2560, 520, 128), (4100, 1024, 768), (2049, 256, 64)])
+def test_gemm_bf16_pingpong_kernel(ops, tb, m, n, k):
+    """The 256x256 ping-pong kernel (selected for M >= 2048, N >= 512, A k-major; forced here for the narrower N too):
+    ragged M and N edges, short and odd K-tile counts, every fused epilogue, bf16 and fp32 outputs, the live-row form."""
+    import os
+    os.environ["EDITOR_GEMM_PP"] = "1"            # read once at first use inside the library: set before any launch
+    a = torch.randn(m, k, generator=_g(1)).bfloat16()
+    b = (torch.randn((k, n) if tb else (n, k), generator=_g(2)) * 0.1).bfloat16()
+    bias = torch.randn(n, generator=_g(3)) * 0.1
+    rs = torch.rand(m, generator=_g(5)) + 0.5
+    ref = a.float().double() @ (b.float() if tb else b.float().t()).double()
+    ldb = b.shape[1]
+    ag, bg = a.cuda(), b.cuda()
+    # plain, and bias + row scale, bf16 out (one-pass bf16-staged epilogue)
+    c = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(ag, bg, c, m, n, k, k, ldb, n, 0, tb)
+    assert rel_err(c.float().cpu(), ref) < 4e-3
+    ops.gemm(ag, bg, c, m, n, k, k, ldb, n, 0, tb, alpha=0.5, bias=bias.cuda(), rowscale=rs.cuda())
+    want = rs.view(-1, 1).double() * (0.5 * ref + bias.double())
+    assert rel_err(c.float().cpu(), want) < 4e-3
+    # GELU forward (pre-activation saved)
+    pre = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    act = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(ag, bg, act, m, n, k, k, ldb, n, 0, tb, bias=bias.cuda(), epilogue=ops.EPI_GELU, aux=pre)
+    assert rel_err(pre.float().cpu(), ref + bias.double()) < 4e-3
+    assert rel_err(act.float().cpu(), F.gelu(pre.float().cpu())) < 4e-3
+    # the packed-math erfc form against exact erf on the stored pre-activations: well inside bf16 rounding
+    assert (act.float().cpu() - F.gelu(pre.float().cpu())).abs().max() <= 2.0 ** -8 * act.float().abs().max().item()
+    # GELU' epilogue (bf16 out, two-pass fp32 staging)
+    pre2 = torch.randn(m, n, generator=_g(7)).bfloat16()
+    pr = pre2.float().requires_grad_(True)
+    F.gelu(pr).backward(ref.float())
+    out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(ag, bg, out, m, n, k, k, ldb, n, 0, tb, epilogue=ops.EPI_GELU_BWD, aux=pre2.cuda())
+    assert rel_err(out.float().cpu(), pr.grad) < 6e-3
+    # fp32 residual epilogue and fp32 plain
+    res = torch.randn(m, n, generator=_g(4))
+    cf = torch.empty(m, n, device="cuda")
+    ops.gemm(ag, bg, cf, m, n, k, k, ldb, n, 0, tb, bias=bias.cuda(), rowscale=rs.cuda(), epilogue=ops.EPI_RESIDUAL,
+             aux=res.cuda())
+    assert rel_err(cf.cpu(), rs.view(-1, 1).double() * (ref + bias.double()) + res.double()) < 1e-5
+    ops.gemm(ag, bg, cf, m, n, k, k, ldb, n, 0, tb)
+    assert rel_err(cf.cpu(), ref) < 1e-5
+    # live-row form (compacted HMA): tiles at or beyond *m_live are skipped, rows below it are exact
+    live = 1000
+    c.fill_(7.0)
+    ops.gemm(ag, bg, c, m, n, k, k, ldb, n, 0, tb, m_live=torch.tensor([live], dtype=torch.int32, device="cuda"))
+    assert rel_err(c[:live].float().cpu(), ref[:live]) < 4e-3
+    assert float((c[1024:] - 7.0).abs().max()) == 0.0          # 256-row tiles from row 1024 on were never touched
+
+
 def test_attention_varlen_matches_dense_reference(ops):
     """Compacted (variable-length) attention == per-sequence dense softmax attention (fp32 reference)."""
     heads, hd = 12, 64
