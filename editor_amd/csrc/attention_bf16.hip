@@ -103,6 +103,11 @@ __device__ __forceinline__ bool bit_of(unsigned long long lo, unsigned long long
 {
     return bit < 64 ? (lo >> bit) & 1ull : (hi >> (bit - 64)) & 1ull;
 }
+// the four validity bits of key tile t (one 64-bit shift per tile; the per-key tests are 32-bit)
+__device__ __forceinline__ uint32_t nibble_of(unsigned long long lo, unsigned long long hi, int t)
+{
+    return (uint32_t)((t < 16 ? lo >> (4 * t) : hi >> (4 * (t - 16))) & 0xfull);
+}
 
 template <int NT, bool BWD>
 __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
@@ -157,17 +162,18 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
                 for (int s = 0; s < 2; ++s)
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(kimg, t * 16, s, lane), qf[s], acc, 0, 0, 0);
                 float sv[4], tm = -INFINITY;
+                const uint32_t vb = nibble_of(kv0, kv1, t);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    sv[r] = bit_of(kv0, kv1, t * 4 + r) ? acc[r] * sc : -INFINITY;
+                    sv[r] = (vb >> r) & 1u ? acc[r] * sc : -INFINITY;
                     tm = fmaxf(tm, sv[r]);
                 }
-                if (tm > m) { l *= exp2f(m - tm); m = tm; }              // (m == -inf: l == 0, stays 0)
-                if (m > -INFINITY) l += (exp2f(sv[0] - m) + exp2f(sv[1] - m)) + (exp2f(sv[2] - m) + exp2f(sv[3] - m));
+                if (tm > m) { l *= __builtin_amdgcn_exp2f(m - tm); m = tm; }              // (m == -inf: l == 0, stays 0)
+                if (m > -INFINITY) l += (__builtin_amdgcn_exp2f(sv[0] - m) + __builtin_amdgcn_exp2f(sv[1] - m)) + (__builtin_amdgcn_exp2f(sv[2] - m) + __builtin_amdgcn_exp2f(sv[3] - m));
             }
             const float M = group_max(m);
-            const float L = group_sum(m > -INFINITY ? l * exp2f(m - M) : 0.f);
-            lse = (qok && L > 0.f) ? M + log2f(L) : INFINITY;          // +inf -> P == 0 (masked query)
+            const float L = group_sum(m > -INFINITY ? l * __builtin_amdgcn_exp2f(m - M) : 0.f);
+            lse = (qok && L > 0.f) ? M + __builtin_amdgcn_logf(L) : INFINITY;          // +inf -> P == 0 (masked query)
             if (a.lse && lg == 0 && q < T) a.lse[row_idx0 + q] = lse;
         } else {
             lse = q < T ? a.lse[row_idx0 + q] : INFINITY;
@@ -208,9 +214,10 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
                     if (BWD) dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(vimg, t * 16, s, lane), dof[s], dp, 0, 0, 0);
                 }
                 float pv[4];
+                const uint32_t vb = nibble_of(kv0, kv1, t);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    pv[r] = bit_of(kv0, kv1, t * 4 + r) ? exp2f(acc[r] * sc - lse) : 0.f;
+                    pv[r] = (vb >> r) & 1u ? __builtin_amdgcn_exp2f(acc[r] * sc - lse) : 0.f;
                 if (!BWD) {
                     if (pr && 16 * t + 4 * lg < a.ldp)
                         *reinterpret_cast<float4*>(pr + 16 * t + 4 * lg) = make_float4(pv[0], pv[1], pv[2], pv[3]);
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
                 for (int r = 0; r < 4; ++r) {
                     const int qq = 16 * u + 4 * lg + r;
                     const float l = lse_s[qq];
-                    const float pp = kok ? exp2f(s_[r] * sc - l) : 0.f;      // l == +inf -> 0
+                    const float pp = kok ? __builtin_amdgcn_exp2f(s_[r] * sc - l) : 0.f;      // l == +inf -> 0
                     pv[r] = pp;
                     dsv[r] = pp * (dp[r] - dl_s[qq]) * a.scale;
                 }
