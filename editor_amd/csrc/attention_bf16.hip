@@ -152,6 +152,70 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
 #pragma unroll
         for (int s = 0; s < 2; ++s) qf[s] = frag_own(qbase, ld, q0, T, s, lane);
         float lse;                                        // log2-sum-exp2 of the scaled scores of row q
+        if constexpr (!BWD && NT <= 14) {
+            // ---- short sequences (backbone: T = 129 / 193): the lane's 4*NT scores stay in registers, so S^T = K Q^T
+            // is computed ONCE and each key costs one exponential (the streaming form below recomputes the scores in
+            // its second sweep and pays the online-rescale exponentials on top: 9 instead of 4 per 4 keys) -----------
+            float4_t sreg[NT];
+            float m = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                sreg[t] = float4_t{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                if (t < nt) {
+                    float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(kimg, t * 16, s, lane), qf[s], acc, 0, 0, 0);
+                    const uint32_t vb = nibble_of(kv0, kv1, t);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sreg[t][r] = (vb >> r) & 1u ? acc[r] * sc : -INFINITY;
+                        m = fmaxf(m, sreg[t][r]);
+                    }
+                }
+            }
+            const float M = group_max(m);
+            const float Ms = M > -INFINITY ? M : 0.f;                  // (fully masked row: every exponent is -inf -> 0)
+            float l = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t < nt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sreg[t][r] = __builtin_amdgcn_exp2f(sreg[t][r] - Ms); l += sreg[t][r]; }
+                }
+            const float L = group_sum(l);
+            const bool live = qok && L > 0.f;
+            const float inv = live ? __builtin_amdgcn_rcpf(L) : 0.f;
+            lse = live ? M + __builtin_amdgcn_logf(L) : INFINITY;
+            if (a.lse && lg == 0 && q < T) a.lse[row_idx0 + q] = lse;
+            float* pr = (a.probs && q < T) ? a.probs + (prow0 + q) * a.ldp : nullptr;
+            float4_t o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < NT / 2; ++s2)
+                if (2 * s2 < nt) {
+                    uint2 pk[2];
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int t = 2 * s2 + half;
+                        const float p0 = sreg[t][0] * inv, p1 = sreg[t][1] * inv, p2 = sreg[t][2] * inv, p3 = sreg[t][3] * inv;
+                        if (pr && 16 * t + 4 * lg < a.ldp) *reinterpret_cast<float4*>(pr + 16 * t + 4 * lg) = make_float4(p0, p1, p2, p3);
+                        pk[half] = pack4(p0, p1, p2, p3);
+                    }
+                    const short8_t pf = join(pk[0], pk[1]);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(vimg, s2, dt, lane), pf, o[dt], 0, 0, 0);
+                }
+            if (q < T) {
+                bf16_t* orow = a.out + (row0 + q) * D + hh * HD + 4 * lg;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *reinterpret_cast<uint2*>(orow + dt * 16) = pack4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+            }
+            continue;
+        }
         if (!BWD) {
             // ---- sweep 1: online max / sum over this lane's keys, then across the 4 lane groups ------------------
             float m = -INFINITY, l = 0.f;
