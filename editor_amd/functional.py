@@ -69,11 +69,21 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None):
     return dx, dw, db
 
 
-def _splitk_for(n_out, k_out, m_red):
-    """wgrad has few output tiles and a long reduction: split the reduction so that about one full wave of
-    workgroups (2 per CU x 256 CUs) is resident, and no more (every split adds a pass of fp32 atomics)."""
-    tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
-    return max(1, min(512 // max(tiles, 1), m_red // 512))
+def _splitk_for(n_out, k_out, m_red, cus=256):
+    """wgrad has few output tiles and a long reduction: split the reduction over workgroups.  Cost model fitted to
+    tools/gemm_bench.py on the four hot-path shapes (units = one 64-deep K-tile of a 256x128 output tile, ~1.3 us):
+    rounds of `cus` workgroups x (K-tiles per split + 15 for the tile prologue / epilogue) + 3.3 per split for its
+    fp32 partial tile and its slab in the reduction kernel.  E.g. (2304,768): 4 splits (one 84 %-full round) beat 9
+    (two full rounds); (3072,768): 7 beat 3."""
+    tiles = ((n_out + 255) // 256) * ((k_out + 127) // 128)
+    nk = max(1, m_red // 64)
+    best, best_cost = 1, float("inf")
+    for sk in range(1, max(1, min(32, nk // 16)) + 1):
+        rounds = (tiles * sk + cus - 1) // cus
+        cost = rounds * (nk / sk + 15.0) + 3.3 * sk
+        if cost < best_cost - 1e-9:
+            best, best_cost = sk, cost
+    return best
 
 
 class TransformerBlockFn(torch.autograd.Function):
