@@ -15,6 +15,7 @@ HEADER = os.path.join(HERE, "..", "include", "editor_hip.h")
 LIB_PATH = os.path.join(HERE, "libeditor_hip.so")
 
 _CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
+       "unsigned": ctypes.c_ulonglong,            # the header's only unsigned scalar type is `unsigned long long`
        "editor_stream_t": ctypes.c_void_p}
 
 

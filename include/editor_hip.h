@@ -221,6 +221,17 @@ int editor_rank_metrics(const int* order, const long* q_pids, const long* g_pids
                         int Q, int G, int max_rank, double* ap, int* first_pos, double* totals, int* cmc_counts,
                         editor_stream_t stream);
 
+/* ---- input transform on device (data/datasets/make_dataloader.py:245-253, 55-146) ------------ */
+
+/* RandomHorizontalFlip -> Pad(pad, 0) -> RandomCrop(H,W) -> ToTensor -> Normalize(mean,std) -> RandomErasing('pixel')
+ * of a batch of decoded + resized images.  in: uint8 (B,H,W,3); params: int32 (B,8) = {flip, crop_top, crop_left,
+ * erase, e_top, e_left, e_h, e_w} drawn on the host in the reference's order; mean / stdv: HOST pointers to 3 floats;
+ * noise: fp32 (B,3,H,W) N(0,1) fill for erased pixels, or NULL to generate it on the device from `seed`;
+ * out: fp32 (B,3,H,W). */
+int editor_augment_u8(const uint8_t* in, const int* params, int B, int H, int W, int pad, const float* mean,
+                      const float* stdv, const float* noise, unsigned long long seed, float* out,
+                      editor_stream_t stream);
+
 /* ---- training-step kernels (drop-path RNG of vit_pytorch.py:52-69) ----------------------- */
 
 /* torch.optim.SGD(momentum, weight_decay, dampening 0) over many tensors in one launch.  Pointer tables and per-tensor

@@ -254,3 +254,43 @@ def f8_retrieval(seed=71):
 
 if __name__ == "__main__" and "f8" in sys.argv[1:]:
     f8_retrieval()
+
+
+def f9_input(seed=91):
+    """F9 (row N3): the reference's RandomIdentitySampler (data/datasets/sampler.py, imported) and the rectangle choice
+    of its RandomErasing (make_dataloader.py:55-146; the module imports cv2 / torchvision, which are absent here, so the
+    class is compiled from the file's syntax tree at capture time - nothing of it is stored)."""
+    import ast, importlib.util, math, random
+    spec = importlib.util.spec_from_file_location("ref_sampler", "/root/reference/data/datasets/sampler.py")
+    sampler = importlib.util.module_from_spec(spec)          # (the package __init__ pulls in cv2 / torchvision)
+    spec.loader.exec_module(sampler)
+    n_ids = 23
+    data = []
+    for pid in range(n_ids):
+        for k in range(3 + (pid * 7) % 29):
+            data.append((f"img_{pid}_{k}.jpg", pid, k % 4, 0))
+    random.seed(seed); np.random.seed(seed)
+    order = np.asarray(list(iter(sampler.RandomIdentitySampler(data, 32, 8))), dtype=np.int64)
+    tree = ast.parse(open("/root/reference/data/datasets/make_dataloader.py").read())
+    keep = [n for n in tree.body if (isinstance(n, ast.ClassDef) and n.name == "RandomErasing")
+            or (isinstance(n, ast.FunctionDef) and n.name == "_get_pixels")]
+    ns = {"torch": torch, "random": random, "math": math}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "<reference RandomErasing>", "exec"), ns)
+    re_ = ns["RandomErasing"](probability=0.5, mode="pixel", max_count=1, device="cpu")
+    random.seed(seed + 1)
+    rects = []
+    for _ in range(64):
+        img = torch.zeros(3, 256, 128)
+        torch.manual_seed(0)
+        re_(img)                                   # erased pixels are N(0,1) draws: non-zero almost surely
+        nz = (img != 0).any(0)
+        if nz.any():
+            ys, xs = torch.where(nz)
+            rects.append((1, int(ys.min()), int(xs.min()), int(ys.max() - ys.min() + 1), int(xs.max() - xs.min() + 1)))
+        else:
+            rects.append((0, 0, 0, 0, 0))
+    save("f9_input", seed=seed, sampler_order=order, rects=np.asarray(rects, dtype=np.int32))
+
+
+if __name__ == "__main__" and "f9" in sys.argv[1:]:
+    f9_input()

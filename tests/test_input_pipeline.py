@@ -1,0 +1,71 @@
+"""Row N3: host-side input-pipeline pieces against goldens captured from the reference (CPU), and the device transform
+against the oracle (GPU)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from editor_amd import synth
+
+
+def _data():
+    data = []
+    for pid in range(23):
+        for k in range(3 + (pid * 7) % 29):
+            data.append((f"img_{pid}_{k}.jpg", pid, k % 4, 0))
+    return data
+
+
+def test_identity_sampler_matches_reference():
+    from editor_amd.data import RandomIdentitySampler
+    g = load_golden("f9_input")
+    seed = int(g["seed"])
+    random.seed(seed); np.random.seed(seed)
+    s = RandomIdentitySampler(_data(), 32, 8)
+    order = np.asarray(list(iter(s)), dtype=np.int64)
+    assert np.array_equal(order, g["sampler_order"])
+    assert len(order) % 32 == 0 and len(s) >= len(order)
+    pids = np.asarray([d[1] for d in _data()])[order].reshape(-1, 4, 8)
+    assert (pids == pids[:, :, :1]).all()                      # P x K batches: K consecutive instances per identity
+
+
+def test_erasing_rectangles_match_reference():
+    from editor_amd.data import ErasingParams
+    g = load_golden("f9_input")
+    random.seed(int(g["seed"]) + 1)
+    ep = ErasingParams(0.5)
+    rects = np.asarray([ep(256, 128) for _ in range(64)], dtype=np.int32)
+    assert np.array_equal(rects, g["rects"])
+    assert 10 < rects[:, 0].sum() < 54
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,b", [(256, 128, 32), (128, 256, 5), (384, 128, 3)])
+def test_device_train_transform_matches_oracle(h, w, b):
+    from editor_amd.data import DeviceTrainTransform
+    from oracle import augment_ref
+    img = synth.integers(5, "aug/img", (b, h, w, 3), 256).to(torch.uint8)
+    noise = synth.normal(5, "aug/noise", (b, 3, h, w), 1.0)
+    tf = DeviceTrainTransform((h, w), prob=0.5, padding=10, re_prob=0.5)
+    random.seed(3); torch.manual_seed(3)
+    params = tf.draw(b)
+    params[0] = torch.tensor([1, 0, 20, 1, 0, 0, h - 1, w - 1])          # extremes: corner crops, near-full erase
+    params[1] = torch.tensor([0, 20, 0, 0, 0, 0, 0, 0])
+    ref = augment_ref.train_transform(img, params, 10, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5), noise)
+    out = tf(img.cuda(), params, noise.cuda())
+    assert torch.equal(out.cpu(), ref)                                      # byte / fp32 arithmetic: bit-exact
+    # device-generated fill: untouched pixels identical, erased ones ~ N(0,1)
+    out2 = tf(img.cuda(), params, None, seed=11).cpu()
+    erased = torch.zeros(b, h, w, dtype=torch.bool)
+    for i in range(b):
+        _, _, _, e, t, l, eh, ew = [int(v) for v in params[i]]
+        if e:
+            erased[i, t:t + eh, l:l + ew] = True
+    m = erased[:, None].expand(-1, 3, -1, -1)
+    assert torch.equal(out2[~m], ref[~m])
+    z = out2[m]
+    assert abs(z.mean().item()) < 0.02 and abs(z.std().item() - 1) < 0.02
+    with pytest.raises(RuntimeError):
+        tf(img, params, noise)
