@@ -39,7 +39,6 @@ struct GemmB16Args {
     int splitk, tiles_m, tiles_n;
     int epilogue; void* aux; long ldaux;     // EDITOR_EPI_* (editor_hip.h)
     int slabs;                               // split-K partial tiles go to per-split slabs of C (= workspace)
-    int stagger;                             // experiment: start delay (x 8k cycles) of every second workgroup
     const int* m_live;                       // device scalar: only the first *m_live token rows are live (NULL: all)
     int live_is_k;                           // the token-row extent is the reduction (wgrad) instead of M
     int pp_staged;                           // 256x256 kernel: LDS-staged epilogue (full-line stores) instead of the direct one
@@ -525,12 +524,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void gemm_bf16_pipe_kernel(GemmB16A
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const int wm = (w / WAVES_N) * WM, wn = (w % WAVES_N) * 64;
-    // Two co-resident workgroups of a CU start half a tile period apart, so that one drains its output tile to HBM
-    // while the other feeds the matrix core (identical tiles otherwise keep every CU of the chip in lockstep and the
-    // chip alternates between an MFMA phase and an HBM-write-bound store phase).
-    if (g.stagger && g.stagger < 90 && ((bid >> 8) & 1) && bid < 512) {
-        for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     float4_t acc[MT][4];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -777,15 +770,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const int wr = wu >> 2, wc = wu & 3;
     const int li = lane & 15, lg = lane >> 4;
-    // De-phase the first wave of workgroups (one per CU): identical tiles otherwise keep all 256 CUs in lockstep, and
-    // the chip alternates between a phase that only uses the matrix cores and a phase in which every CU drains its
-    // output tile at once and the HBM write bandwidth is the limit.  Spread over four start offsets, some CUs are
-    // always storing while the others compute; the offsets persist because a CU's next workgroup starts when its
-    // previous one ends.
-    if (g.stagger && g.stagger < 90 && bid < 256) {
-        const int ph = (bid >> 3) & 3;
-        for (int i = 0; i < ph * g.stagger; ++i) __builtin_amdgcn_s_sleep(32);
-    }
 #define PP_STAMP(k) do { if (g.trace && threadIdx.x == 0) g.trace[(long)(blockIdx.y * gridDim.x + bid) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     PP_STAMP(0);
 
@@ -1097,8 +1081,8 @@ int launch_pp(GemmB16Args g, hipStream_t stream)
     g.tiles_n = (g.N + 255) / 256;
     // measured: the LDS-staged epilogue (full-line 16-byte stores) beats the direct one on every layout here
     // (fwd N=2304,K=768: 701 vs 530 TFLOP/s; dgrad 974 vs 905)
-    const char* st = getenv("EDITOR_GEMM_PP_STAGED");
-    g.pp_staged = st ? atoi(st) : 1;
+    static const int staged_mode = getenv("EDITOR_GEMM_PP_STAGED") ? atoi(getenv("EDITOR_GEMM_PP_STAGED")) : 1;
+    g.pp_staged = staged_mode;
     static const bool trace = getenv("EDITOR_GEMM_TRACE") != nullptr;
     if (trace) {                                                   // debug: per-workgroup phase timeline, printed per launch
         const int nwg = g.tiles_m * g.tiles_n * g.splitk;
@@ -1141,15 +1125,6 @@ int launch_pipe(const GemmB16Args& g, hipStream_t stream)
     static const int pp_mode = getenv("EDITOR_GEMM_PP") ? atoi(getenv("EDITOR_GEMM_PP")) : -1;   // 1 force, 0 off
     const bool pp_auto = g.M >= 2048 && g.splitk == 1 && AK && g.N >= 512;
     if (g.N >= 256 && (pp_mode == 1 || (pp_mode < 0 && pp_auto))) return launch_pp<AK, BK_, CF>(g, stream);
-    // 256-wide tiles unless they would leave the machine badly filled (N = 768: 3 tile columns)
-    const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.splitk;
-    // measured (tools/gemm_bench.py): the 256x128 3-stage form is >= the 256x256 2-stage form on every hot-path
-    // shape (the 2-stage pipeline exposes DMA latency); keep 256x256 opt-in until it gets a half-tile schedule.
-    const bool wide = getenv("EDITOR_GEMM_WIDE") && g.N >= 256 && (g.N % 256 == 0 || g.N >= 1024) &&
-                      (t256 >= 1024 || (t256 % 256 == 0) || (t256 % 256) >= 160);
-    if (wide) return launch_pipe_t<AK, BK_, CF, 256, 256, 2, 8>(g, stream);
-    // 128x128, 2 stages, 4 waves: 64 KiB -> two workgroups per CU, one's prologue/epilogue under the other's main loop
-    if (getenv("EDITOR_GEMM_SMALL")) return launch_pipe_t<AK, BK_, CF, 128, 128, 2, 4>(g, stream);
     return launch_pipe_t<AK, BK_, CF, 256, 128, 3, 8>(g, stream);
 }
 
@@ -1174,9 +1149,9 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
     if (splitk > ktiles) splitk = ktiles;
     if (splitk > 1 && !c_f32) return (int)hipErrorInvalidValue;
     // direct-to-LDS staging needs whole BK tiles along the reduction and >= 8 valid elements to clamp to
-    const bool glds = (K % BK == 0) && M >= 8 && N >= 8 && !getenv("EDITOR_GEMM_NO_GLDS");
+    const bool glds = (K % BK == 0) && M >= 8 && N >= 8;
     // large problems: 3-stage LDS-DMA pipeline (256x128 tiles)
-    const bool pipe = glds && M >= 256 && N >= 128 && !getenv("EDITOR_GEMM_NO_PIPE");
+    const bool pipe = glds && M >= 256 && N >= 128;
     // split-K: per-split slabs in the workspace + a reduction kernel (pipelined path), else fp32 atomics into C
     const bool slabs = splitk > 1 && pipe && (transA || transB) && splitk_ws && ldc == N && (((long)M * N) & 3) == 0 &&
                        (reinterpret_cast<uintptr_t>(splitk_ws) & 15) == 0;
@@ -1187,7 +1162,7 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
     }
     GemmB16Args g{(const bf16_t*)A, (const bf16_t*)B, slabs ? (void*)splitk_ws : C, M, N, K, lda, ldb, ldc, alpha,
                   slabs ? 0.f : beta, bias, rowscale, splitk, (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux,
-                  slabs ? 1 : 0, getenv("EDITOR_GEMM_STAGGER") ? atoi(getenv("EDITOR_GEMM_STAGGER")) : 0,
+                  slabs ? 1 : 0,
                   m_live, transA ? 1 : 0, 0, nullptr};
     if (m_live && (!pipe || (splitk > 1 && !slabs))) return (int)hipErrorInvalidValue;   // live-row form: pipelined path only
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
