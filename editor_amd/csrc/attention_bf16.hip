@@ -395,6 +395,64 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Rollout step (SFTS.py:150-153, row-vector form):  r_out[k] = sum_q r_in[q] * P_l[q,k]  for one layer l, with the
+// probabilities RECOMPUTED from that layer's saved q/k and row log-sum-exps (P[q,k] = exp2(s[q,k] - lse[q]), exactly
+// the values the forward produced) instead of read from a materialised (3B,h,T,T) tensor: the forward then skips its
+// 314 MB-per-layer probability output (201 -> 131 us) and the 3.7 GB buffer disappears.  Same skeleton as the DKV
+// pass: own = keys, LDS holds the Q image, lse and r_in; the weighted sum over queries is fp32 VALU work.
+// r_in == NULL: one-hot CLS row (the first step, l = L-1).  final: write r_out[1:] to a (BH, T-1) score tensor.
+// ---------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void attn_rollout_step_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
+    const float* __restrict__ r_in, int T, int heads, float scale, long Mtot, float* __restrict__ r_out, int final_step)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Tp = NT * 16;
+    char* qimg = smem;
+    float* lse_s = reinterpret_cast<float*>(smem + Tp * ROWB);
+    float* w_s = lse_s + Tp;
+    const int D = heads * HD;
+    const int b = blockIdx.x / heads, hh = blockIdx.x % heads;
+    const long ld = 3L * D;
+    const long row0 = (long)b * T;
+    const int nt = min(NT, ((T + 31) >> 5) << 1);
+    const bf16_t* qbase = qkv + row0 * ld + hh * HD;
+    load_image(qimg, qbase, ld, T, nt * 16);
+    for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
+        lse_s[t] = t < T ? lse[(long)hh * Mtot + row0 + t] : INFINITY;
+        w_s[t] = t < T ? (r_in ? r_in[(long)blockIdx.x * T + t] : (t == 0 ? 1.f : 0.f)) : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const float sc = scale * kLog2e;
+    for (int k0 = w * 16; k0 < T; k0 += nw * 16) {
+        const int key = k0 + li;
+        short8_t kf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) kf[s] = frag_own(qbase + D, ld, k0, T, s, lane);
+        float acc = 0.f;
+#pragma unroll 2
+        for (int u = 0; u < nt; ++u) {
+            float4_t s_ = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                s_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(qimg, u * 16, s, lane), kf[s], s_, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = 16 * u + 4 * lg + r;
+                acc = fmaf(__builtin_amdgcn_exp2f(s_[r] * sc - lse_s[qq]), w_s[qq], acc);    // lse = +inf (pad rows) -> 0
+            }
+        }
+        acc = group_sum(acc);
+        if (lg == 0 && key < T) {
+            if (final_step) { if (key >= 1) r_out[(long)blockIdx.x * (T - 1) + key - 1] = acc; }
+            else r_out[(long)blockIdx.x * T + key] = acc;
+        }
+    }
+}
+
 template <typename K>
 int set_lds(K kern, size_t bytes)
 {
@@ -467,4 +525,26 @@ extern "C" int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* do
     if (!cu) Mtot = (long)B * T;
     AttnArgs a{qkv, dout, out, nullptr, dqkv, nullptr, const_cast<float*>(lse), workspace, mask, T, heads, scale, 0, cu, Mtot};
     return dispatch(a, B, 1, stream);
+}
+
+extern "C" int editor_attn_rollout_step_bf16(const uint16_t* qkv, const float* lse, const float* r_in, int B, int T, int heads,
+                                             int hd, float scale, float* r_out, int final_step, hipStream_t stream)
+{
+    if (hd != HD || T < 2 || B < 1 || !qkv || !lse || !r_out) return (int)hipErrorInvalidValue;
+    const int threads = pick_threads(T);
+    const dim3 grid(B * heads);
+    const long Mtot = (long)B * T;
+#define ROLL_CASE(NTV) case NTV: {                                                                                   \
+        auto k = attn_rollout_step_kernel<NTV>;                                                                          \
+        const size_t lds = (size_t)NTV * 16 * ROWB + (size_t)2 * NTV * 16 * sizeof(float);                              \
+        int rc = set_lds(k, lds); if (rc) return rc;                                                                     \
+        hipLaunchKernelGGL(k, grid, dim3(threads), lds, stream, qkv, lse, r_in, T, heads, scale, Mtot, r_out, final_step); \
+        break; }
+    switch (pick_nt(T)) {
+        ROLL_CASE(10) ROLL_CASE(14) ROLL_CASE(26) ROLL_CASE(38)
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef ROLL_CASE
+    EDITOR_LAUNCH_CHECK();
+    return 0;
 }

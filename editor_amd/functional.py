@@ -111,7 +111,11 @@ class TransformerBlockFn(torch.autograd.Function):
         wq, wp, w1, w2 = (act_weight(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w))
         h1, mean1, rstd1 = ops.layernorm_fwd(x2d, n1w, n1b, eps, act_dtype, mask, 0, m_live=m_live)
         qkv = _linear_fwd(h1, wq, qkvb, act_dtype, m_live)
-        ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, probs_out, cu=cu)
+        if isinstance(probs_out, list):            # bf16 backbone: no probability tensor; the rollout recomputes it
+            ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, None, cu=cu)
+            probs_out.append((qkv, attn_saved))
+        else:
+            ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, probs_out, cu=cu)
         x1 = torch.empty_like(x2d)                  # x1 = x + rs * (ao Wp^T + b): residual add in the GEMM epilogue
         ops.gemm(ao, wp, x1, m, d, d, d, d, d, 0, 0, bias=projb, rowscale=rowscale_attn,
                  epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)

@@ -261,6 +261,7 @@ class EDITOR(nn.Module):
             nn.init.normal_(self.AL_HEAD.weight, std=0.001)
         self.act_dtype = _act_dtype(cfg)
         self.hma_compact = bool(getattr(cfg.MODEL, "HMA_COMPACT", True))
+        self.rollout_probs = bool(getattr(cfg.MODEL, "ROLLOUT_PROBS", False))
         self.teacher_index = None            # optional (B,N) bool: force the SFTS selection (bf16 protocol)
         self._drop_rates_dev = None
         self._drop_step = 0
@@ -289,8 +290,13 @@ class EDITOR(nn.Module):
                                   base.pos_embed, sie, cam if sie is not None else None, float(base.sie_xishu),
                                   self.act_dtype)
         # softmax outputs of every layer; rows padded to a multiple of 4 floats in bf16 mode (16-byte stores)
+        # f32 parity mode: the (L,3B,h,T,T) softmax outputs are materialised as the reference does.  bf16 mode: every
+        # block hands back its (qkv, row log-sum-exp) instead and the rollout recomputes the probabilities from them
+        # (cfg.MODEL.ROLLOUT_PROBS = True keeps the materialised form: rows padded to a multiple of 4 floats).
+        recompute = self.act_dtype != torch.float32 and not self.rollout_probs
         ldp = t if self.act_dtype == torch.float32 else (t + 3) // 4 * 4
-        probs = torch.empty(base.depth, btot, base.heads, t, ldp, dtype=torch.float32, device=imgs.device)
+        probs = [] if recompute else torch.empty(base.depth, btot, base.heads, t, ldp, dtype=torch.float32,
+                                                 device=imgs.device)
         scales = None
         if self.training and max(base.drop_rates) > 0.0:                       # vit_pytorch.py:52-69: one launch for all
             if self._drop_rates_dev is None or self._drop_rates_dev.device != imgs.device:
@@ -303,7 +309,7 @@ class EDITOR(nn.Module):
             if scales is not None and base.drop_rates[i] > 0.0:
                 rs_a, rs_m = scales[i, 0], scales[i, 1]
             x = fn.TransformerBlockFn.apply(x, *_block_args(blk.norm1, blk.attn, blk.norm2, blk.mlp), None,
-                                            probs[i], base.heads, 1e-6, self.act_dtype, rs_a, rs_m)
+                                            probs if recompute else probs[i], base.heads, 1e-6, self.act_dtype, rs_a, rs_m)
         x = fn.LayerNormFn.apply(x, base.norm.weight, base.norm.bias, 1e-6, None)
         return x, probs
 
@@ -315,8 +321,14 @@ class EDITOR(nn.Module):
 
     def _select(self, probs, mask_fre, b):
         """Part_Attention x3 + union with the frequency mask (SFTS.py:145-164,183-187) -> (B,N) uint8."""
-        l, btot, h, t = probs.shape[:4]
-        scores = ops.attn_rollout(probs)                                        # (3B, h, N)
+        if isinstance(probs, list):                                             # bf16: per-layer (qkv, lse)
+            base = self.BACKBONE.base
+            h, t = base.heads, base.num_patches + 1
+            btot = probs[0][0].shape[0] // t
+            scores = ops.attn_rollout_qk(probs, btot, t, h, probs[0][0].shape[1] // (3 * h))
+        else:
+            l, btot, h, t = probs.shape[:4]
+            scores = ops.attn_rollout(probs)                                    # (3B, h, N)
         m = ops.topk_mask(scores.view(btot * h, t - 1), self.head_k, group=h)    # (3B, N)
         nmod = btot // b
         index = ops.mask_or(m[:b], m[b:2 * b], m[2 * b:3 * b] if nmod > 2 else None, mask_fre)

@@ -47,6 +47,21 @@ def attn_rollout(probs):
     return scores
 
 
+def attn_rollout_qk(layers, b, t, heads, hd):
+    """Rollout scores (B, H, T-1) from the per-layer (qkv, lse) pairs of the bf16 backbone, first layer first:
+    r = e_cls^T A_{L-1}; r <- r A_l for l = L-2 .. 0, each A_l recomputed on the fly (no probability tensor)."""
+    dev = layers[0][0].device
+    bufs = [torch.empty(b * heads, t, dtype=torch.float32, device=dev) for _ in range(2)]
+    scores = torch.empty(b, heads, t - 1, dtype=torch.float32, device=dev)
+    r_in = None
+    for i, (qkv, lse) in enumerate(reversed(layers)):
+        last = i == len(layers) - 1
+        out = scores if last else bufs[i & 1]
+        call("editor_attn_rollout_step_bf16", qkv, lse, r_in, b, t, heads, hd, hd ** -0.5, out, 1 if last else 0)
+        r_in = out
+    return scores
+
+
 def mask_or(a, b=None, c=None, d=None):
     out = torch.empty_like(a)
     call("editor_mask_or", a, b, c, d, out, a.numel())

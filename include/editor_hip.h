@@ -140,6 +140,13 @@ int editor_attention_fwd_f32(const float* qkv, int B, int T, int heads, int hd, 
 int editor_attention_bwd_f32(const float* qkv, const float* dout, const float* probs, int B, int T, int heads, int hd,
                              float scale, float* dqkv, float* workspace, editor_stream_t stream);
 
+/* One step of the attention rollout (SFTS.py:150-153) WITHOUT materialised probabilities: r_out[bh][k] =
+ * sum_q r_in[bh][q] * P_l[q,k], P_l recomputed from layer l's packed qkv (B*T, 3*heads*64) and the forward's lse
+ * (heads*B*T).  r_in NULL = one-hot CLS row (first step, last layer).  final_step: r_out is (B*heads, T-1) and receives
+ * r[1:] (the CLS->patch scores); otherwise (B*heads, T).  Dense, unmasked sequences (the backbone). */
+int editor_attn_rollout_step_bf16(const uint16_t* qkv, const float* lse, const float* r_in, int B, int T, int heads, int hd,
+                                  float scale, float* r_out, int final_step, editor_stream_t stream);
+
 /* Fused bf16 form (hd must be 64; T <= 608).  probs optional (NULL skips the write).  lse (heads*Mtot fp32, log2 units
  * of the scaled scores, +inf for masked queries) is written by the forward (NULL to skip) and consumed by the backward,
  * which recomputes the probabilities from it; `out` is the forward output (delta = rowsum(dO*O));

@@ -3,7 +3,7 @@ All calls go through the C ABI (editor_amd.ops -> libeditor_hip.so)."""
 import pytest
 import torch
 
-from conftest import load_golden, t
+from conftest import load_golden, rel_err, t
 from editor_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -89,3 +89,27 @@ def test_probe_mfma16(ops):
     d = torch.zeros(16, 16, device="cuda")
     _lib.call("editor_probe_mfma16", a.cuda(), b.cuda(), d)
     assert torch.allclose(d.cpu(), a @ b, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", [129, 193])
+def test_rollout_recomputed_from_qk_matches_materialised(t):
+    """bf16 backbone form: rollout steps that recompute P from (qkv, lse) == the rollout over the probabilities the
+    forward writes (same bf16 products; only exp2(s - lse) vs exp2(s - max)/sum differs, by rounding)."""
+    from editor_amd import ops
+    b, heads, hd, layers = 6, 12, 64, 5
+    g = torch.Generator().manual_seed(3)
+    ldp = (t + 3) // 4 * 4
+    probs = torch.empty(layers, b, heads, t, ldp, device="cuda")
+    pairs = []
+    for l in range(layers):
+        qkv = (torch.randn(b * t, 3 * heads * hd, generator=g) * 0.7).bfloat16().cuda()
+        _, lse = ops.attention_fwd(qkv, b, t, heads, hd, None, probs[l])
+        pairs.append((qkv, lse))
+    ref = ops.attn_rollout(probs)
+    got = ops.attn_rollout_qk(pairs, b, t, heads, hd)
+    assert got.shape == ref.shape == (b, heads, t - 1)
+    assert rel_err(got.cpu(), ref.cpu()) < 2e-5
+    k = 2
+    same = (got.topk(k, dim=-1).indices.sort(-1).values == ref.topk(k, dim=-1).indices.sort(-1).values).all(-1)
+    assert same.float().mean().item() > 0.98                      # selections agree except on near-ties
