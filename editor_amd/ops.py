@@ -233,6 +233,20 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
     (fp32 -> exact-f32 MFMA, bf16 -> bf16 MFMA with fp32 accumulate; c may be fp32 for bf16 inputs)."""
     if a.dtype == torch.float32:
         assert b.dtype == torch.float32 and c.dtype == torch.float32 and m_live is None
+        if (splitk == 1 and not trans_a and not trans_b and m <= 512 and k >= 1024 and k % 128 == 0 and epilogue == 0
+                and rowscale is None and beta == 0.0 and ldc == n and a_off == b_off == c_off == 0):
+            # few output tiles, long reduction (REDUCE layers, classifier heads: 128 x 768 x 1536 is 24 workgroups of 96
+            # k-steps, 71 us): eight reduction chunks as a BATCH - chunk 0 (+bias) straight into C, chunks 1..7 into
+            # workspace slabs - then one fixed-order reduction.  Deterministic, unlike the fp32-atomic split-K.
+            s_ = 8
+            kc = k // s_
+            slabs = workspace(a.device, (s_ - 1) * m * n)
+            call("editor_gemm_f32", a, b, c, m, n, kc, lda, ldb, ldc, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, float(alpha), 0.0, bias,
+                 None, 1, 0, None, n)
+            call("editor_gemm_f32", _ptr(a, kc), _ptr(b, kc), slabs, m, n, kc, lda, ldb, n, 0, 0, s_ - 1, kc, kc, m * n,
+                 1, 0, 0, 0, float(alpha), 0.0, None, None, 1, 0, None, n)
+            call("editor_reduce_rows", slabs, s_ - 1, m * n, c, 1, 1.0)
+            return
         call("editor_gemm_f32", _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), m, n, k, lda, ldb, ldc,
              int(trans_a), int(trans_b), 1, 0, 0, 0, 1, 0, 0, 0, float(alpha), float(beta), bias, rowscale, int(splitk),
              int(epilogue), aux, n)
@@ -415,7 +429,7 @@ def triplet_fwd(feat, label, loss, accumulate):
     feat, ldf = _rows_view(feat)
     b, d = feat.shape
     dev = feat.device
-    gram = torch.empty(b, b, dtype=torch.float32, device=dev)
+    gram = torch.empty(9, b, b, dtype=torch.float32, device=dev)       # Gram matrix + 8 reduction-chunk slabs
     sq = torch.empty(b, dtype=torch.float32, device=dev)
     idx = torch.empty(2 * b, dtype=torch.int32, device=dev)
     coef = torch.empty(3 * b, dtype=torch.float32, device=dev)

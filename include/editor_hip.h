@@ -203,7 +203,8 @@ int editor_ce_smooth_bwd(const float* logits, const long* target, int B, int C, 
                          float* dlogits, editor_stream_t stream);
 /* TripletLoss() without margin (layers/triplet_loss.py:16-33,51-84,121-136): Euclidean distances with the 1e-12
  * clamp, batch-hard positive / negative per anchor, loss (+)= mean softplus(d_ap - d_an).  feat rows have stride ldf.
- * Scratch / saved for backward: gram (B,B), sq (B), idx (2B: positive, negative), coef (3B), row_loss (B). */
+ * Scratch / saved for backward: gram (9,B,B: the Gram matrix + 8 reduction-chunk slabs), sq (B), idx (2B: positive,
+ * negative), coef (3B), row_loss (B). */
 int editor_triplet_fwd(const float* feat, long ldf, const long* label, int B, int D, float* gram, float* sq, int* idx,
                        float* coef, float* row_loss, float* loss, int accumulate, editor_stream_t stream);
 int editor_triplet_bwd(const float* feat, long ldf, int B, int D, const int* idx, const float* coef, const float* dloss,
