@@ -253,6 +253,41 @@ __global__ void cast_rows_kernel(const float* __restrict__ in, const float* __re
     }
 }
 
+// The same cast with the COLUMN SUMS of its (rounded) output on the side: the bias gradient of the nn.Linear this
+// gradient feeds (db = colsum(dy)) otherwise costs one more pass over dy.  One wave per row, lanes own fixed columns,
+// per-block partial rows -> reduce_rows_kernel (fixed order).  D a multiple of 256, D <= 256 * kMaxV.
+__device__ __forceinline__ float round_like(float v, float) { return v; }
+__device__ __forceinline__ float round_like(float v, bf16_t) { return bf16_to_f32(f32_to_bf16(v)); }
+template <typename TO>
+__global__ __launch_bounds__(256) void cast_rows_colsum_kernel(const float* __restrict__ in, const float* __restrict__ rowscale,
+    long M, int D, TO* __restrict__ out, float* __restrict__ partials)
+{
+    __shared__ float red[4][256 * kMaxV];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nv = D >> 8;
+    float4 cs[kMaxV];
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long row = (long)blockIdx.x * 4 + w; row < M; row += (long)gridDim.x * 4) {
+        const float r = rowscale ? rowscale[row] : 1.f;
+#pragma unroll
+        for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+            const int c0 = (i * 64 + lane) * 4;
+            float4 v = *reinterpret_cast<const float4*>(in + row * D + c0);
+            v.x *= r; v.y *= r; v.z *= r; v.w *= r;
+            Vec4<TO>::st(out + row * D + c0, v);
+            cs[i].x += round_like(v.x, TO{}); cs[i].y += round_like(v.y, TO{});
+            cs[i].z += round_like(v.z, TO{}); cs[i].w += round_like(v.w, TO{});
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) if (i < nv)
+        *reinterpret_cast<float4*>(&red[w][(i * 64 + lane) * 4]) = cs[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256)
+        partials[(long)blockIdx.x * D + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Patch embedding glue.  im2col of non-overlapping 16x16 patches: row (b*N+p), col (c*256 + i*16 + j)
 // == Conv2d(k=16,s=16) weight layout (768,3,16,16) flattened (vit_pytorch.py:438,455-457).
@@ -596,6 +631,21 @@ extern "C" int editor_cast_rows(const float* in, const float* rowscale, long M, 
     if (D % 4) return (int)hipErrorInvalidValue;
     DISPATCH_T(out_bf16, hipLaunchKernelGGL(cast_rows_kernel<TT>, dim3(grid_for(M * (D / 4))), dim3(256), 0, stream,
                in, rowscale, M, D, (TT*)out, m_live));
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_cast_rows_colsum(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16,
+                                       float* colsum, float* workspace, int ws_rows, hipStream_t stream)
+{
+    if ((D & 255) || D > 256 * kMaxV || ws_rows < 1 || !colsum || !workspace) return (int)hipErrorInvalidValue;
+    long blocks = (M + 3) / 4;
+    if (blocks > ws_rows) blocks = ws_rows;
+    DISPATCH_T(out_bf16, hipLaunchKernelGGL(cast_rows_colsum_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, stream,
+               in, rowscale, M, D, (TT*)out, workspace));
+    EDITOR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((D + 63) / 64), dim3(1024), 0, stream, workspace, (int)blocks, (long)D, colsum,
+                       0, 1.f);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

@@ -54,8 +54,9 @@ def _linear_fwd(x2d, w_act, bias, out_dtype, m_live=None):
     return y
 
 
-def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None):
-    """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy)."""
+def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None):
+    """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy) (or the
+    caller's, when the kernel that produced dy summed its columns on the way)."""
     m, n = dy.shape
     k = x2d.shape[1]
     dx = torch.empty(m, k, dtype=x2d.dtype, device=dy.device)
@@ -65,8 +66,9 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None):
         ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=gelu_pre, m_live=m_live)
     dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
     ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, splitk=_splitk_for(n, k, m), m_live=m_live)   # both stored (Kred=m, .)
-    db = ops.colsum(dy) if need_bias else None
-    return dx, dw, db
+    if need_bias and db is None:
+        db = ops.colsum(dy)
+    return dx, dw, (db if need_bias else None)
 
 
 def _splitk_for(n_out, k_out, m_red, cus=256):
@@ -144,18 +146,26 @@ class TransformerBlockFn(torch.autograd.Function):
         wq, wp, w1, w2 = (act_weight(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w))
         dx2 = dx2.contiguous().view(m, d)
         # ---- MLP branch:  x2 = x1 + rs * fc2(gelu(fc1(LN2(x1))))
-        dy = _scaled_cast(dx2, rs_mlp, act_dtype, m_live)
-        da, dw2, db2 = _linear_bwd(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live)      # da = (dy W2) * gelu'(a)
+        dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2)
+        da, dw2, db2 = _linear_bwd(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live, db=dbias)      # da = (dy W2) * gelu'(a)
         dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live)
         dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w, mean2, rstd2, mask, 0, dx_in=dx2, m_live=m_live)
         # ---- attention branch:  x1 = x + rs * proj(attn(qkv(LN1(x))))
-        dy = _scaled_cast(dx1, rs_attn, act_dtype, m_live)
-        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live)
+        dy, dbias = _scaled_cast_colsum(dx1, rs_attn, act_dtype, m_live, hb_proj)
+        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live, db=dbias)
         dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, amask, attn_saved, ao, cu=cu)
         dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live)
         dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1, m_live=m_live)
         return (dx.view(xshape), dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2,
                 None, None, None, None, None, None, None, None, None, None)
+
+
+def _scaled_cast_colsum(dx, rowscale, dtype, m_live, want_colsum):
+    """_scaled_cast, plus the column sums of the result when the consumer has a bias (dense bf16 rows only)."""
+    if (want_colsum and m_live is None and dtype == torch.bfloat16 and dx.dtype == torch.float32
+            and dx.shape[1] % 256 == 0 and dx.shape[1] <= 1024):
+        return ops.cast_rows_colsum(dx, rowscale, dtype)
+    return _scaled_cast(dx, rowscale, dtype, m_live), None
 
 
 def _scaled_cast(dx, rowscale, dtype, m_live=None):

@@ -165,6 +165,16 @@ def cast_rows(x2d, rowscale, dtype, m_live=None):
     return out
 
 
+def cast_rows_colsum(x2d, rowscale, dtype):
+    """cast_rows + the column sums of its output (bias gradient) in the same pass."""
+    m, d = x2d.shape
+    out = torch.empty(m, d, dtype=dtype, device=x2d.device)
+    cs = torch.empty(d, dtype=torch.float32, device=x2d.device)
+    ws = workspace(x2d.device, WS_ROWS * d)
+    call("editor_cast_rows_colsum", x2d, rowscale, m, d, out, _is_bf16(out), cs, ws, WS_ROWS)
+    return out, cs
+
+
 def im2col16(img, dtype):
     b, c, h, w = img.shape
     out = torch.empty(b * (h // 16) * (w // 16), c * 256, dtype=dtype, device=img.device)

@@ -81,6 +81,10 @@ int editor_cast_f32_to_bf16(const float* in, uint16_t* out, long n, editor_strea
  * per-sample drop-path factor keep/keep_prob of vit_pytorch.py:52-69 folded in. */
 int editor_cast_rows(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16,
                      const int* m_live, editor_stream_t stream);
+/* editor_cast_rows plus colsum[d] = sum_m out[m,d] (the rounded values): the bias gradient of the nn.Linear that `out`
+ * feeds, without another pass over it.  D a multiple of 256; workspace: ws_rows*D floats. */
+int editor_cast_rows_colsum(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16, float* colsum,
+                            float* workspace, int ws_rows, editor_stream_t stream);
 int editor_cast_bf16_to_f32(const uint16_t* in, float* out, long n, editor_stream_t stream);
 
 /* PatchEmbed_overlap with stride == patch == 16 (vit_pytorch.py:449-458): im2col rows (b*N+p), cols (c,i,j). */

@@ -407,3 +407,14 @@ def test_droppath_scales(ops):
     assert set(torch.unique(vals).tolist()) <= {0.0, float(torch.tensor(1.0) / torch.tensor(kp))}
     assert abs(float((vals > 0).float().mean()) - kp) < 0.06         # ~90 % kept
     assert not torch.equal(per_sample[11, 0, :, 0], per_sample[11, 1, :, 0])   # independent draws per branch
+
+
+def test_cast_rows_colsum(ops):
+    m, d = 1037, 768
+    x = torch.randn(m, d, generator=_g(1)) * 3
+    rs = torch.rand(m, generator=_g(2)) * 1.3
+    out, cs = ops.cast_rows_colsum(x.cuda(), rs.cuda(), torch.bfloat16)
+    ref = (x * rs.view(-1, 1)).bfloat16()
+    assert torch.equal(out.cpu(), ref)
+    assert rel_err(cs.cpu(), ref.float().sum(0)) < 1e-5
+    assert rel_err(cs.cpu(), ops.colsum(out).cpu()) < 1e-6          # == the separate pass it replaces
