@@ -236,18 +236,25 @@ class SFTSApplyFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feat, index, training):
+        # Also hands out the (nmod, B, D) cls tokens (SFTS leaves them untouched): taking them with feat[i, :, 0] makes
+        # autograd build a zero (nmod,B,T,D) tensor per modality and add it to this node's gradient (three 152 MB fills
+        # and adds per step); here their gradient is added into row 0 of the gradient this node writes anyway.
         out, loss = ops.sfts_apply(feat, index, training)
         ctx.save_for_backward(feat, index)
         ctx.training = training
+        cls = feat[:, :, 0].contiguous()
         if training:
-            return out, loss.view(())
-        return out, feat.new_zeros(())
+            return out, loss.view(()), cls
+        return out, feat.new_zeros(()), cls
 
     @staticmethod
-    def backward(ctx, dout, dloss):
+    def backward(ctx, dout, dloss, dcls):
         feat, index = ctx.saved_tensors
         dl = dloss.contiguous().view(1).float() if ctx.training else None
-        return ops.sfts_apply_bwd(feat, index, dout.contiguous(), dl), None, None
+        dfeat = ops.sfts_apply_bwd(feat, index, dout.contiguous(), dl)
+        if dcls is not None:
+            dfeat[:, :, 0] += dcls
+        return dfeat, None, None
 
 
 class PoolFn(torch.autograd.Function):

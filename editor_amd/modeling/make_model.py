@@ -341,10 +341,11 @@ class EDITOR(nn.Module):
         nmod, b, t, d = feats_s.shape
         mask = torch.cat([torch.ones(b, 1, dtype=torch.uint8, device=index.device), index], dim=1).contiguous()
         mods = []
+        feats_mod = feats_s.unbind(0)                  # (unbind's backward is one stack; per-index selects zero-fill and add)
         for i, tag in enumerate(("R", "N", "T")):
             args = _block_args(getattr(fb, "norm" + tag), getattr(fb, "attn" + tag), getattr(fb, "norm" + tag + "_"),
                                getattr(fb, "mlp" + tag))
-            mods.append(fn.TransformerBlockFn.apply(feats_s[i], *args, mask, None, self.hma_heads, 1e-5,
+            mods.append(fn.TransformerBlockFn.apply(feats_mod[i], *args, mask, None, self.hma_heads, 1e-5,
                                                     self.act_dtype, None, None))
         loss_ocfr = None
         if self.training:
@@ -364,10 +365,11 @@ class EDITOR(nn.Module):
         plan = ops.CompactPlan(index, t, nmod)
         xa = fn.GatherRowsFn.apply(feats_s.reshape(nmod * b * t, d), plan.map_a, plan.live_a, 1, plan.ma)   # layout A
         mods = []
+        xa_mod = torch.split(xa, plan.ma, dim=0)       # (split's backward is one cat; slices would zero-fill and add)
         for i, tag in enumerate(("R", "N", "T")):
             args = _block_args(getattr(fb, "norm" + tag), getattr(fb, "attn" + tag), getattr(fb, "norm" + tag + "_"),
                                getattr(fb, "mlp" + tag))
-            mods.append(fn.TransformerBlockFn.apply(xa[i * plan.ma:(i + 1) * plan.ma], *args, plan.mask_a, None,
+            mods.append(fn.TransformerBlockFn.apply(xa_mod[i], *args, plan.mask_a, None,
                                                     self.hma_heads, 1e-5, self.act_dtype, None, None, plan.cu, t,
                                                     plan.live_a))
         xa = torch.cat(mods, dim=0)
@@ -408,8 +410,9 @@ class EDITOR(nn.Module):
                 self.last_aux["index"] = index
         del probs
         feats = feats.view(3, b, t, dim)
-        cls_tri = [feats[i, :, 0] for i in range(3)]
         training = self.training
+        feats_s, loss_bcc, cls_all = fn.SFTSApplyFn.apply(feats, index, training)
+        cls_tri = list(cls_all.unbind(0))
         if training:
             if self.AL:
                 ori = torch.cat(cls_tri, dim=-1)
@@ -417,7 +420,6 @@ class EDITOR(nn.Module):
             else:
                 mod_scores = [fn.LinearFn.apply(self._bn(self.BACKBONE_BN, c), self.BACKBONE_HEAD.weight, None)
                               for c in cls_tri]
-        feats_s, loss_bcc = fn.SFTSApplyFn.apply(feats, index, training)
         if self.hma_compact and self.act_dtype == torch.bfloat16 and b * t >= 256:
             pooled, num, loss_ocfr = self._hma_compact(feats_s, index, label)
         else:                      # dense-masked form, as the reference computes it (always used in f32 parity mode)

@@ -174,7 +174,7 @@ def test_sfts_apply_and_pool(oracle):
     dout = torch.randn(3, b, t, d, generator=g)
     (sum((o * dd).sum() for o, dd in zip(outs, dout)) + 1.7 * loss).backward()
     fg = feat.clone().cuda().requires_grad_(True)
-    o, l = fn.SFTSApplyFn.apply(fg, index.to(torch.uint8).cuda(), True)
+    o, l, _cls = fn.SFTSApplyFn.apply(fg, index.to(torch.uint8).cuda(), True)
     ((o * dout.cuda()).sum() + 1.7 * l).backward()
     assert rel_err(o.cpu(), torch.stack(outs).detach()) == 0
     assert rel_err(l.cpu(), loss.detach()) < 1e-5
