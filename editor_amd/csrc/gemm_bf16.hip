@@ -42,6 +42,7 @@ struct GemmB16Args {
     const int* m_live;                       // device scalar: only the first *m_live token rows are live (NULL: all)
     int live_is_k;                           // the token-row extent is the reduction (wgrad) instead of M
     int pp_staged;                           // 256x256 kernel: LDS-staged epilogue (full-line stores) instead of the direct one
+    float* colsum;                           // EDITOR_EPI_COLSUM: [tiles_m][N] column sums of the rounded output tile rows
     unsigned long long* trace;               // debug (EDITOR_GEMM_TRACE): per-workgroup s_memtime stamps
 };
 
@@ -992,6 +993,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
         bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
         bf16_t* Ab = reinterpret_cast<bf16_t*>(g.aux);
         const bool gelu = g.epilogue == EDITOR_EPI_GELU;
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of this thread's 8 columns (same for all its rows)
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
             const int c = threadIdx.x + it * 512;
@@ -1007,7 +1009,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
                 { const v2f_t gv = gelu2(unpack_bf16x2(pw[e])); pw[e] = pack_bf16x2(gv.x, gv.y); }
                 p = make_uint4(pw[0], pw[1], pw[2], pw[3]);
             }
+            if (g.colsum) {
+                const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const v2f_t u = unpack_bf16x2(pw[e]); cs[2 * e] += u.x; cs[2 * e + 1] += u.y; }
+            }
             *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = p;
+        }
+        if (g.colsum) {       // 16 threads share each column group: fold through LDS (the tile image is no longer needed)
+            PP_BAR();
+            float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(threadIdx.x >> 5) * 256 + (threadIdx.x & 31) * 8 + e] = cs[e];
+            PP_BAR();
+            if (threadIdx.x < 256 && n0 + (int)threadIdx.x < g.N) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += red[r * 256 + threadIdx.x];
+                g.colsum[(long)tile_m * g.N + n0 + threadIdx.x] = t;
+            }
         }
         PP_STAMP(4);
     } else if (staged) {
@@ -1157,7 +1177,7 @@ int launch_pipe(const GemmB16Args& g, hipStream_t stream)
     // stays on 256x128 with split-K slabs.
     static const int pp_mode = getenv("EDITOR_GEMM_PP") ? atoi(getenv("EDITOR_GEMM_PP")) : -1;   // 1 force, 0 off
     const bool pp_auto = g.M >= 2048 && g.splitk == 1 && AK && g.N >= 512;
-    if (g.N >= 256 && (pp_mode == 1 || (pp_mode < 0 && pp_auto))) return launch_pp<AK, BK_, CF>(g, stream);
+    if (g.N >= 256 && (pp_mode == 1 || g.colsum || (pp_mode < 0 && pp_auto))) return launch_pp<AK, BK_, CF>(g, stream);
     return launch_pipe_t<AK, BK_, CF, 256, 128, 3, 8>(g, stream);
 }
 
@@ -1176,6 +1196,11 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
     if (transB && (N & 7)) return (int)hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15)
         return (int)hipErrorInvalidValue;
+    const bool want_colsum = (epilogue & EDITOR_EPI_COLSUM) != 0;
+    epilogue &= ~EDITOR_EPI_COLSUM;
+    if (want_colsum && (c_f32 || epilogue == EDITOR_EPI_RESIDUAL || splitk > 1 || !splitk_ws || transA || M < 2048 || N < 512 ||
+                        (N & 7) || (ldc & 7) || (ldaux & 7) || (K % BK) || beta != 0.f || m_live))
+        return (int)hipErrorInvalidValue;                        // the column sums exist in the one-pass 256x256 epilogue only
     if (epilogue != EDITOR_EPI_NONE && (!aux || (ldaux & 3) || splitk > 1)) return (int)hipErrorInvalidValue;
     if (splitk < 1) splitk = 1;
     const int ktiles = (K + BK - 1) / BK;
@@ -1196,7 +1221,7 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
     GemmB16Args g{(const bf16_t*)A, (const bf16_t*)B, slabs ? (void*)splitk_ws : C, M, N, K, lda, ldb, ldc, alpha,
                   slabs ? 0.f : beta, bias, rowscale, splitk, (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux,
                   slabs ? 1 : 0,
-                  m_live, transA ? 1 : 0, 0, nullptr};
+                  m_live, transA ? 1 : 0, 0, want_colsum ? splitk_ws : nullptr, nullptr};
     if (m_live && (!pipe || (splitk > 1 && !slabs))) return (int)hipErrorInvalidValue;   // live-row form: pipelined path only
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
     int rc;

@@ -54,20 +54,26 @@ def _linear_fwd(x2d, w_act, bias, out_dtype, m_live=None):
     return y
 
 
-def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None):
+def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None):
     """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy) (or the
-    caller's, when the kernel that produced dy summed its columns on the way)."""
+    caller's, when the kernel that produced dy summed its columns on the way).  dx_colsum: also return colsum(dx) - the
+    bias gradient of the layer BELOW - from the dgrad's own epilogue when it can deliver it (else None)."""
     m, n = dy.shape
     k = x2d.shape[1]
     dx = torch.empty(m, k, dtype=x2d.dtype, device=dy.device)
+    dxcs = None
+    if dx_colsum and ops.gemm_colsum_ok(m, k, n, dx.dtype, 0, 1, m_live):
+        dxcs = torch.empty(k, dtype=torch.float32, device=dy.device)
     if gelu_pre is None:
-        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, m_live=m_live)    # B stored (Kred=n, Nout=k)
+        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, m_live=m_live, colsum=dxcs)    # B stored (Kred=n, Nout=k)
     else:
-        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=gelu_pre, m_live=m_live)
+        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=gelu_pre, m_live=m_live, colsum=dxcs)
     dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
     ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, splitk=_splitk_for(n, k, m), m_live=m_live)   # both stored (Kred=m, .)
     if need_bias and db is None:
         db = ops.colsum(dy)
+    if dx_colsum is not None:
+        return dx, dw, (db if need_bias else None), dxcs
     return dx, dw, (db if need_bias else None)
 
 
@@ -147,8 +153,9 @@ class TransformerBlockFn(torch.autograd.Function):
         dx2 = dx2.contiguous().view(m, d)
         # ---- MLP branch:  x2 = x1 + rs * fc2(gelu(fc1(LN2(x1))))
         dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2)
-        da, dw2, db2 = _linear_bwd(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live, db=dbias)      # da = (dy W2) * gelu'(a)
-        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live)
+        da, dw2, db2, da_cs = _linear_bwd(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live, db=dbias,
+                                          dx_colsum=hb_fc1)                              # da = (dy W2) * gelu'(a)
+        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs)
         dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w, mean2, rstd2, mask, 0, dx_in=dx2, m_live=m_live)
         # ---- attention branch:  x1 = x + rs * proj(attn(qkv(LN1(x))))
         dy, dbias = _scaled_cast_colsum(dx1, rs_attn, act_dtype, m_live, hb_proj)

@@ -237,8 +237,17 @@ def pool_bwd(dout, num, nmod, t):
 EPI_NONE, EPI_RESIDUAL, EPI_GELU, EPI_GELU_BWD = 0, 1, 2, 3
 
 
+EPI_COLSUM = 0x100
+
+
+def gemm_colsum_ok(m, n, k, c_dtype, trans_a, splitk, m_live):
+    """Can editor_gemm_bf16 also deliver the column sums of its (bf16) output?  (one-pass 256x256 epilogue only)"""
+    return (c_dtype == torch.bfloat16 and not trans_a and splitk == 1 and m_live is None and m >= 2048 and n >= 512
+            and n % 8 == 0 and k % 64 == 0)
+
+
 def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=0.0, bias=None, rowscale=None,
-         splitk=1, a_off=0, b_off=0, c_off=0, epilogue=0, aux=None, m_live=None):
+         splitk=1, a_off=0, b_off=0, c_off=0, epilogue=0, aux=None, m_live=None, colsum=None):
     """c = alpha * op(a) op(b) (+bias) (+beta*c) (*rowscale); dtype picks the kernel family
     (fp32 -> exact-f32 MFMA, bf16 -> bf16 MFMA with fp32 accumulate; c may be fp32 for bf16 inputs)."""
     if a.dtype == torch.float32:
@@ -264,6 +273,17 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
         assert b.dtype == torch.bfloat16
         if m_live is not None and (m < 256 or n < 128 or k % 64):
             raise RuntimeError("live-row GEMM needs the pipelined path (M >= 256, N >= 128, K % 64 == 0)")
+        if colsum is not None:
+            # colsum (n) fp32 <- column sums of the rounded output (bias gradient of the layer this gradient feeds):
+            # per-tile-row partials from the GEMM epilogue, folded in a fixed order
+            assert gemm_colsum_ok(m, n, k, c.dtype, trans_a, splitk, m_live) and ldc == n
+            tiles_m = (m + 255) // 256
+            part = workspace(a.device, tiles_m * n)
+            call("editor_gemm_bf16", _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), 0, m, n, k, lda, ldb, ldc,
+                 int(trans_a), int(trans_b), float(alpha), float(beta), bias, rowscale, 1, int(epilogue) | EPI_COLSUM, aux,
+                 n, part, None)
+            call("editor_reduce_rows", part, tiles_m, n, colsum, 0, 1.0)
+            return
         call("editor_gemm_bf16", _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), 1 if c.dtype == torch.float32 else 0,
              m, n, k, lda, ldb, ldc, int(trans_a), int(trans_b), float(alpha), float(beta), bias, rowscale, int(splitk),
              int(epilogue), aux, n, workspace(a.device, int(splitk) * m * n) if splitk > 1 else None, m_live)

@@ -418,3 +418,22 @@ def test_cast_rows_colsum(ops):
     assert torch.equal(out.cpu(), ref)
     assert rel_err(cs.cpu(), ref.float().sum(0)) < 1e-5
     assert rel_err(cs.cpu(), ops.colsum(out).cpu()) < 1e-6          # == the separate pass it replaces
+
+
+def test_gemm_bf16_colsum_side_output(ops):
+    """dgrad + GELU' with the column sums of its output (the next layer's bias gradient) from the same epilogue."""
+    m, n, k = 2300, 1024, 256
+    dy = torch.randn(m, k, generator=_g(1)).bfloat16()
+    w = (torch.randn(k, n, generator=_g(2)) * 0.1).bfloat16()
+    pre = torch.randn(m, n, generator=_g(3)).bfloat16()
+    out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    cs = torch.empty(n, device="cuda")
+    ops.gemm(dy.cuda(), w.cuda(), out, m, n, k, k, n, n, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=pre.cuda(), colsum=cs)
+    ref = torch.empty_like(out)
+    ops.gemm(dy.cuda(), w.cuda(), ref, m, n, k, k, n, n, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=pre.cuda())
+    assert torch.equal(out, ref)
+    assert rel_err(cs.cpu(), ref.float().sum(0).cpu()) < 1e-5
+    assert rel_err(cs.cpu(), ops.colsum(ref).cpu()) < 1e-5
+    cs2 = torch.empty(n, device="cuda")
+    ops.gemm(dy.cuda(), w.cuda(), out, m, n, k, k, n, n, 0, 1, colsum=cs2)              # plain epilogue too
+    assert rel_err(cs2.cpu(), out.float().sum(0).cpu()) < 1e-5
