@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--preset", default="RGBNT201")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="(experimental) time a hipGraph replay of the captured step")
     ap.add_argument("--no-replay", action="store_true", help="skip the GEMM replay (clean rocprof per-step totals)")
     args = ap.parse_args()
 
@@ -204,13 +205,44 @@ def main():
         step()
     probe = _GemmProbe()
     probe.install()
+    # --graph (experimental, single GPU): the whole step (forward, loss, backward, fused SGD: ~1100 launches) is captured
+    # once into a hipGraph and the timed region replays it; the drop-path generator and the SGD pointer table are
+    # replay-safe (device-resident counter, captured upload).  Off by default: on ROCm 7.2 the capture of this step
+    # crashed intermittently inside the runtime.
+    graph = None
+    if not use_dist and args.graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()                                            # allocator / lazy-attribute warm-up on the capture stream
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            opt.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            probe.recording = rank == 0                           # the GEMM launch list of one step, taken at capture
+            with torch.cuda.graph(graph):
+                static_loss = step()
+            probe.recording = False
+            graph.replay()                                        # one untimed replay
+            torch.cuda.synchronize()
+            print("[bench] timed region = hipGraph replay of the captured step", file=sys.stderr)
+        except Exception as e:                                    # capture unsupported here: fall back to eager timing
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr)
+            graph = None
+            probe.calls = []
+            torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        probe.recording = rank == 0 and i == args.steps - 1
-        loss = step()
+        if graph is not None:
+            graph.replay()
+            loss = static_loss
+        else:
+            probe.recording = rank == 0 and i == args.steps - 1
+            loss = step()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()

@@ -70,6 +70,24 @@ __global__ void droppath_kernel(const float* __restrict__ rates, int L, long B, 
     }
 }
 
+// seed from device memory, so that a captured hipGraph draws new masks on every replay: state[0] is read by the
+// kernel above (through `seed_dev`) and advanced by this one afterwards
+__global__ void droppath_dev_kernel(const float* __restrict__ rates, int L, long B, int T, const long* __restrict__ state,
+                                    float* __restrict__ scales)
+{
+    const uint64_t seed = (uint64_t)state[0];
+    const long total = (long)L * 2 * B * T;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long s = e / T;
+        const int l = (int)(s / (2 * B));
+        const float keep_prob = 1.f - rates[l];
+        const uint64_t r = mix64(seed * 0x100000001B3ull + (uint64_t)s);
+        const float u = (float)(r >> 40) * (1.f / 16777216.f);
+        scales[e] = floorf(keep_prob + u) / keep_prob;
+    }
+}
+__global__ void advance_state_kernel(long* state) { state[0] += 1; }
+
 }  // namespace
 
 extern "C" int editor_sgd_multi(float* const* p_ptrs, const float* const* g_ptrs, float* const* m_ptrs,
@@ -90,6 +108,17 @@ extern "C" int editor_droppath_scales(const float* rates, int L, long B, int T, 
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(droppath_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rates, L, B, T, (uint64_t)seed, scales);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_droppath_scales_dev(const float* rates, int L, long B, int T, long* state, float* scales, hipStream_t stream)
+{
+    const long total = (long)L * 2 * B * T;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(droppath_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rates, L, B, T, state, scales);
+    hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, stream, state);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

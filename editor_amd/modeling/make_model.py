@@ -265,6 +265,7 @@ class EDITOR(nn.Module):
         self.teacher_index = None            # optional (B,N) bool: force the SFTS selection (bf16 protocol)
         self._drop_rates_dev = None
         self._drop_step = 0
+        self._drop_state = None
         self.last_aux = {}
 
     # -- checkpoint compatibility (make_model.py:144-148) ---------------------------------------
@@ -301,9 +302,10 @@ class EDITOR(nn.Module):
         if self.training and max(base.drop_rates) > 0.0:                       # vit_pytorch.py:52-69: one launch for all
             if self._drop_rates_dev is None or self._drop_rates_dev.device != imgs.device:
                 self._drop_rates_dev = torch.tensor(base.drop_rates, dtype=torch.float32, device=imgs.device)
-            self._drop_step += 1
-            seed = (int(torch.initial_seed()) * 1000003 + self._drop_step) & 0x7FFFFFFFFFFFFFFF
-            scales = ops.droppath_scales(self._drop_rates_dev, btot, t, seed)
+            if self._drop_state is None or self._drop_state.device != imgs.device:      # device-resident RNG counter
+                seed0 = (int(torch.initial_seed()) * 1000003) & 0x3FFFFFFFFFFFFFFF
+                self._drop_state = torch.full((1,), seed0, dtype=torch.int64, device=imgs.device)
+            scales = ops.droppath_scales_dev(self._drop_rates_dev, btot, t, self._drop_state)
         for i, blk in enumerate(base.blocks):
             rs_a = rs_m = None
             if scales is not None and base.drop_rates[i] > 0.0:

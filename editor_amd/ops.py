@@ -476,6 +476,14 @@ def triplet_bwd(feat, idx, coef, dloss):
     return df
 
 
+def droppath_scales_dev(rates, b, t, state):
+    """droppath_scales keyed by the int64 device scalar `state`, which the call advances (hipGraph-replay safe)."""
+    l = rates.numel()
+    out = torch.empty(l, 2, b * t, dtype=torch.float32, device=rates.device)
+    call("editor_droppath_scales_dev", rates, l, b, t, state, out)
+    return out
+
+
 def droppath_scales(rates, b, t, seed):
     """(L,2,b*t) fp32 per-row drop-path scales keep/keep_prob (vit_pytorch.py:52-69) for every block and branch."""
     l = rates.numel()

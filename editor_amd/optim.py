@@ -47,11 +47,22 @@ class FusedSGD:
 
     @torch.no_grad()
     def step(self):
-        k = self._slot
-        self._slot ^= 1
-        if self._ev[k] is not None:
-            self._ev[k].synchronize()                                    # the copy issued two steps ago has executed
-        host, grads = self._g_host[k], []
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            # hipGraph capture of the whole step: the gradients live at fixed addresses of the graph's memory pool, so the
+            # pointer table is written once into a dedicated pinned buffer whose (captured) upload every replay repeats;
+            # no events, no host waits
+            if getattr(self, "_g_host_cap", None) is None:
+                self._g_host_cap = torch.zeros(len(self.params), dtype=torch.int64).pin_memory()
+                self._g_dev_cap = torch.zeros(len(self.params), dtype=torch.int64, device=self.device)
+            host, dev_tab, k = self._g_host_cap, self._g_dev_cap, None
+        else:
+            k = self._slot
+            self._slot ^= 1
+            if self._ev[k] is not None:
+                self._ev[k].synchronize()                                # the copy issued two steps ago has executed
+            host, dev_tab = self._g_host[k], self._g_dev[k]
+        grads = []
         for i, (_, p) in enumerate(self.params):
             g = p.grad
             if g is None:
@@ -61,12 +72,16 @@ class FusedSGD:
                     g = g.contiguous()
                 grads.append(g)
                 host[i] = g.data_ptr()
-        self._keep[k] = grads                                            # keep the tensors alive until the kernel ran
-        self._g_dev[k].copy_(host, non_blocking=True)
-        _lib.call("editor_sgd_multi", self.p_ptrs, self._g_dev[k], self.m_ptrs, self.chunk_t, self.chunk_o, self.numel,
+        if capturing:
+            self._keep_cap = grads
+        else:
+            self._keep[k] = grads                                        # keep the tensors alive until the kernel ran
+        dev_tab.copy_(host, non_blocking=True)
+        _lib.call("editor_sgd_multi", self.p_ptrs, dev_tab, self.m_ptrs, self.chunk_t, self.chunk_o, self.numel,
                   self.lr, self.wd, float(self.momentum), 1 if self.first else 0, self.nchunks)
-        self._ev[k] = torch.cuda.Event()
-        self._ev[k].record()
+        if not capturing:
+            self._ev[k] = torch.cuda.Event()
+            self._ev[k].record()
         self.first = False
         # the kernel wrote the parameters behind autograd's back: tell the bf16 operand cache (version counters did not move)
         from . import functional

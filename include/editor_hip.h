@@ -258,6 +258,9 @@ int editor_sgd_multi(float* const* p_ptrs, const float* const* g_ptrs, float* co
 /* per-row drop-path scales keep/keep_prob for L blocks x 2 branches x B samples, expanded over T tokens:
  * scales (L,2,B*T) fp32; rates (L) fp32 on device; counter-based RNG keyed by `seed`. */
 int editor_droppath_scales(const float* rates, int L, long B, int T, long seed, float* scales, editor_stream_t stream);
+/* the same with the seed in DEVICE memory: state[0] keys this draw and is advanced by one afterwards, so a captured
+ * hipGraph of the training step draws fresh masks on every replay */
+int editor_droppath_scales_dev(const float* rates, int L, long B, int T, long* state, float* scales, editor_stream_t stream);
 
 /* ---- bring-up probes (tests only) ------------------------------------------------------------- */
 int editor_probe_tr16(const int* addr, uint16_t* out, editor_stream_t stream);
