@@ -147,12 +147,32 @@ def main():
     ap.add_argument("--preset", default="RGBNT201")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="(experimental) time a hipGraph replay of the captured step")
+    ap.add_argument("--graph", action="store_true", help="time a hipGraph replay of the captured step in THIS process")
+    ap.add_argument("--no-graph", action="store_true", help="time the eager step (no hipGraph attempt)")
     ap.add_argument("--no-replay", action="store_true", help="skip the GEMM replay (clean rocprof per-step totals)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    # Single GPU, default: the step is timed as a hipGraph replay (one graph launch per step instead of ~1100 kernel
+    # launches issued from Python: a slow or busy host stretched the 51 ms step to 80 ms on some boxes).  The capture
+    # runs in a CHILD process, because a capture the runtime rejects can crash the process instead of raising; if the
+    # child does not deliver its JSON line, this process measures the eager step itself.  The child does the same K
+    # timed steps between the same synchronisations - every kernel of the eager step is in the graph.
+    if world == 1 and not args.graph and not args.no_graph and os.environ.get("EDITOR_FORCE_DDP") != "1":
+        import subprocess
+        try:
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--graph"],
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+            lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+            if cp.returncode == 0 and lines:
+                json.loads(lines[-1])
+                sys.stderr.write(cp.stderr[-2000:])
+                print(lines[-1], flush=True)
+                return
+            sys.stderr.write(f"[bench] hipGraph child failed (rc={cp.returncode}); timing the eager step\n")
+        except Exception as e:                                            # timeout, unparsable output ...
+            sys.stderr.write(f"[bench] hipGraph child failed ({type(e).__name__}); timing the eager step\n")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
@@ -177,8 +197,9 @@ def main():
         model = make_model(cfg, num_class, cams)
     synth.fill_state_dict_(model.state_dict(), 1111)
     model = model.to(dev).train()
-    reducer = GradReducer(model, force=use_dist)
-    reducer.broadcast_parameters()
+    reducer = GradReducer(model, force=use_dist) if use_dist else None
+    if reducer is not None:
+        reducer.broadcast_parameters()
 
     # solver/make_optimizer.py:4-29: SGD, momentum 0.9, wd 1e-4, bias lr x2 (BASE_LR 0.001) - fused HIP update
     from editor_amd.optim import FusedSGD
@@ -197,33 +218,45 @@ def main():
         out = model(img, label=label, cam_label=cam, view_label=view, img_path=None, writer=writer, epoch=1)
         loss = losses.loss_pairs(out, label)
         loss.backward()
-        reducer.finalize()
+        if reducer is not None:
+            reducer.finalize()
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
-        step()
+    want_graph = not use_dist and args.graph
+    side = torch.cuda.Stream() if want_graph else None
+    if want_graph:
+        # every eager step before the capture runs on a SIDE stream: AccumulateGrad nodes remember the stream they were
+        # created on, and one created on the default stream invalidates a later capture (torch warns; ROCm then crashes
+        # in hipStreamEndCapture)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(args.warmup):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+    else:
+        for _ in range(args.warmup):
+            step()
     probe = _GemmProbe()
     probe.install()
-    # --graph (experimental, single GPU): the whole step (forward, loss, backward, fused SGD: ~1100 launches) is captured
-    # once into a hipGraph and the timed region replays it; the drop-path generator and the SGD pointer table are
-    # replay-safe (device-resident counter, captured upload).  Off by default: on ROCm 7.2 the capture of this step
-    # crashed intermittently inside the runtime.
+    # --graph: the whole step (forward, loss, backward, fused SGD: ~1100 launches) is captured once into a hipGraph and
+    # the timed region replays it; the drop-path generator and the SGD pointer table are replay-safe (device-resident
+    # counter, captured upload).
     graph = None
-    if not use_dist and args.graph:
+    if want_graph:
         try:
-            side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 step()                                            # allocator / lazy-attribute warm-up on the capture stream
+                probe.recording = rank == 0                       # the GEMM launch list of one (eager) step
+                step()
+                probe.recording = False
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             opt.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
-            probe.recording = rank == 0                           # the GEMM launch list of one step, taken at capture
             with torch.cuda.graph(graph):
                 static_loss = step()
-            probe.recording = False
             graph.replay()                                        # one untimed replay
             torch.cuda.synchronize()
             print("[bench] timed region = hipGraph replay of the captured step", file=sys.stderr)
@@ -272,7 +305,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.preset} 3-modal ViT-B/16 {h}x{w}, batch {b}/GPU, fwd+bwd+SGD step, "
                                    f"drop_path 0.1, SFTS+HMA HIP kernels",
-                       "global_batch": world * b, "parallelism": f"dp{world}", "loss": round(lossv, 4)},
+                       "global_batch": world * b, "parallelism": f"dp{world}", "loss": round(lossv, 4),
+                       "launch": "hipGraph replay" if graph is not None else "eager"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "kernel": "bf16 GEMM family: gemm_bf16_pp_kernel (256x256x64 ping-pong, fwd + dgrad) and gemm_bf16_pipe_kernel "

@@ -37,6 +37,8 @@ class FusedSGD:
         # (an event per buffer keeps the host from overwriting a table whose async copy has not executed yet)
         self._g_host = [torch.zeros(len(self.params), dtype=torch.int64).pin_memory() for _ in range(2)]
         self._g_dev = [torch.zeros(len(self.params), dtype=torch.int64, device=dev) for _ in range(2)]
+        self._g_host_cap = torch.zeros(len(self.params), dtype=torch.int64).pin_memory()   # table of a captured step
+        self._g_dev_cap = torch.zeros(len(self.params), dtype=torch.int64, device=dev)
         self._ev = [None, None]
         self._slot = 0
         self._keep = [None, None]
@@ -52,10 +54,7 @@ class FusedSGD:
             # hipGraph capture of the whole step: the gradients live at fixed addresses of the graph's memory pool, so the
             # pointer table is written once into a dedicated pinned buffer whose (captured) upload every replay repeats;
             # no events, no host waits
-            if getattr(self, "_g_host_cap", None) is None:
-                self._g_host_cap = torch.zeros(len(self.params), dtype=torch.int64).pin_memory()
-                self._g_dev_cap = torch.zeros(len(self.params), dtype=torch.int64, device=self.device)
-            host, dev_tab, k = self._g_host_cap, self._g_dev_cap, None
+            host, dev_tab, k = self._g_host_cap, self._g_dev_cap, None    # (allocated up front: pinning is not capturable)
         else:
             k = self._slot
             self._slot ^= 1

@@ -3,7 +3,7 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline "$@" > /tmp/bench_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph "$@" > /tmp/bench_$tag.log 2>&1
 tail -1 /tmp/bench_$tag.log | cut -c1-1400
 mkdir -p gpurun_out/prof_$tag
 cp /tmp/prof_$tag/${tag}_kernel_stats.csv gpurun_out/prof_$tag/kernel_stats.csv
