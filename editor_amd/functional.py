@@ -26,6 +26,12 @@ def invalidate_weight_cache():
     _WEIGHT_EPOCH += 1
 
 
+def install_weight_copies(pairs):
+    """(parameter, bf16 tensor holding its current value) pairs -> entries of the operand cache for the current epoch."""
+    for w, h in pairs:
+        _BF16_CACHE[id(w)] = (weakref.ref(w), w._version, h, w.data_ptr(), _WEIGHT_EPOCH)
+
+
 def act_weight(w, dtype):
     """fp32 master parameter -> GEMM operand dtype.  bf16 copies are cached per parameter OBJECT and re-cast when
     the parameter's version counter moves (optimizer step, load_state_dict).  The entry holds a weak reference so

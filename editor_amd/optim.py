@@ -8,7 +8,7 @@ from . import _lib
 
 class FusedSGD:
     def __init__(self, named_params, base_lr=1e-3, weight_decay=1e-4, bias_lr_factor=2.0, weight_decay_bias=1e-4,
-                 momentum=0.9):
+                 momentum=0.9, shadow_bf16=True):
         self.params = [(n, p) for n, p in named_params if p.requires_grad]
         dev = self.params[0][1].device
         self.device = dev
@@ -31,6 +31,11 @@ class FusedSGD:
         self.chunk_t = torch.tensor(chunk_t, dtype=torch.int32, device=dev)
         self.chunk_o = torch.tensor(chunk_o, dtype=torch.int64, device=dev)
         self.nchunks = len(chunk_t)
+        # bf16 shadows of the GEMM weights (>= 2-D parameters): written by the update kernel itself and handed to the
+        # operand cache of editor_amd.functional, instead of one cast launch per weight at the next forward
+        self.shadows = [torch.empty(p.shape, dtype=torch.bfloat16, device=dev) if (shadow_bf16 and p.dim() >= 2) else None
+                        for _, p in self.params]
+        self.h_ptrs = torch.tensor([0 if h is None else h.data_ptr() for h in self.shadows], dtype=torch.int64, device=dev)
         self.p_ptrs = torch.tensor([p.data_ptr() for _, p in self.params], dtype=torch.int64, device=dev)
         self.m_ptrs = torch.tensor([b.data_ptr() for b in self.bufs], dtype=torch.int64, device=dev)
         # gradient tensors are new every step: their addresses go to the device through double-buffered pinned staging
@@ -77,11 +82,14 @@ class FusedSGD:
             self._keep[k] = grads                                        # keep the tensors alive until the kernel ran
         dev_tab.copy_(host, non_blocking=True)
         _lib.call("editor_sgd_multi", self.p_ptrs, dev_tab, self.m_ptrs, self.chunk_t, self.chunk_o, self.numel,
-                  self.lr, self.wd, float(self.momentum), 1 if self.first else 0, self.nchunks)
+                  self.lr, self.wd, float(self.momentum), 1 if self.first else 0, self.nchunks, self.h_ptrs)
         if not capturing:
             self._ev[k] = torch.cuda.Event()
             self._ev[k].record()
         self.first = False
-        # the kernel wrote the parameters behind autograd's back: tell the bf16 operand cache (version counters did not move)
+        # the kernel wrote the parameters behind autograd's back: tell the bf16 operand cache (version counters did not
+        # move) and hand it the shadows of the weights that just got a gradient
         from . import functional
         functional.invalidate_weight_cache()
+        functional.install_weight_copies((p, h) for (_, p), h in zip(self.params, self.shadows)
+                                         if h is not None and p.grad is not None)

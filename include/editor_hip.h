@@ -251,10 +251,12 @@ int editor_augment_u8(const uint8_t* in, const int* params, int B, int H, int W,
 
 /* torch.optim.SGD(momentum, weight_decay, dampening 0) over many tensors in one launch.  Pointer tables and per-tensor
  * lr / wd live in device memory; chunk c covers elements [chunk_off[c], +editor_sgd_chunk_elems()) of tensor chunk_tensor[c].
- * g_ptrs[t] == NULL skips tensor t.  first != 0: momentum buffers are initialised with the (decayed) gradient. */
+ * g_ptrs[t] == NULL skips tensor t.  first != 0: momentum buffers are initialised with the (decayed) gradient.
+ * h_ptrs (optional table, entries may be NULL): bf16 shadow of the updated tensor - the GEMM operand copy - written in
+ * the same pass instead of by one cast launch per weight. */
 int editor_sgd_multi(float* const* p_ptrs, const float* const* g_ptrs, float* const* m_ptrs, const int* chunk_tensor,
                      const long* chunk_off, const long* numel, const float* lr, const float* wd, float momentum,
-                     int first, long nchunks, editor_stream_t stream);
+                     int first, long nchunks, uint16_t* const* h_ptrs, editor_stream_t stream);
 /* per-row drop-path scales keep/keep_prob for L blocks x 2 branches x B samples, expanded over T tokens:
  * scales (L,2,B*T) fp32; rates (L) fp32 on device; counter-based RNG keyed by `seed`. */
 int editor_droppath_scales(const float* rates, int L, long B, int T, long seed, float* scales, editor_stream_t stream);

@@ -393,6 +393,22 @@ def test_fused_sgd_matches_torch():
         topt.step()
         for p, r in zip(ps, ref):
             assert rel_err(p.detach().cpu(), r.detach().cpu()) < 1e-6
+        # the bf16 shadows written by the same launch == a cast of the updated weights, and the operand cache serves them
+        from editor_amd import functional as fnc
+        for p, h in zip(ps, fopt.shadows):
+            if h is not None and p.grad is not None:
+                assert torch.equal(h, p.detach().bfloat16())
+                assert fnc.act_weight(p, torch.bfloat16).data_ptr() == h.data_ptr()
+
+
+def test_droppath_scales_device_state(ops):
+    rates = torch.linspace(0, 0.1, 12).cuda()
+    state = torch.full((1,), 77, dtype=torch.int64, device="cuda")
+    a = ops.droppath_scales_dev(rates, 384, 129, state)
+    b = ops.droppath_scales_dev(rates, 384, 129, state)
+    assert int(state.item()) == 79                                     # advanced once per call
+    assert torch.equal(a, ops.droppath_scales(rates, 384, 129, 77)) and torch.equal(b, ops.droppath_scales(rates, 384, 129, 78))
+    assert not torch.equal(a, b)
 
 
 def test_droppath_scales(ops):
