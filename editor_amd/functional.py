@@ -9,6 +9,7 @@ Activation dtype: torch.bfloat16 (performance mode, bf16 MFMA with fp32 accumula
 (parity mode, exact-f32 MFMA).  The residual stream, LayerNorm statistics, losses and every parameter
 gradient are fp32 in both modes.
 """
+import os
 import weakref
 
 import torch
@@ -60,12 +61,37 @@ def _linear_fwd(x2d, w_act, bias, out_dtype, m_live=None):
     return y
 
 
+# Weight-gradient products run on a SIDE stream, concurrently with whatever the main stream does next (the dgrad of the
+# same layer, LayerNorm / attention backward): a dgrad into a 768-wide output is 582 tiles = 2.27 rounds of the 256 CUs
+# and a wgrad is one long round of 216-252 workgroups, so each leaves CUs idle that the other's workgroups take
+# (measured: see DESIGN.md 4.2).  Discipline: outputs are allocated on the main stream; the side stream waits for an
+# event recorded after the producer of dy; the backward function joins (main waits side) before it returns.
+_SIDE = {}
+WGRAD_SIDE_STREAM = os.environ.get("EDITOR_WGRAD_STREAM", "1") != "0"
+
+
+def _side_stream(device):
+    st = _SIDE.get(device.index)
+    if st is None:
+        st = _SIDE[device.index] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_side_stream(device):
+    """Main stream waits for every weight-gradient launch issued so far (call before handing gradients to autograd)."""
+    st = _SIDE.get(device.index)
+    if st is not None:
+        torch.cuda.current_stream(device).wait_stream(st)
+
+
 def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None):
     """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy) (or the
     caller's, when the kernel that produced dy summed its columns on the way).  dx_colsum: also return colsum(dx) - the
     bias gradient of the layer BELOW - from the dgrad's own epilogue when it can deliver it (else None)."""
     m, n = dy.shape
     k = x2d.shape[1]
+    use_side = WGRAD_SIDE_STREAM and dy.dtype == torch.bfloat16 and m >= 2048
+    dy_ready = torch.cuda.current_stream(dy.device).record_event() if use_side else None   # BEFORE the dgrad launch
     dx = torch.empty(m, k, dtype=x2d.dtype, device=dy.device)
     dxcs = None
     if dx_colsum and ops.gemm_colsum_ok(m, k, n, dx.dtype, 0, 1, m_live):
@@ -75,9 +101,22 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, 
     else:
         ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=gelu_pre, m_live=m_live, colsum=dxcs)
     dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
-    ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, splitk=_splitk_for(n, k, m), m_live=m_live)   # both stored (Kred=m, .)
     if need_bias and db is None:
-        db = ops.colsum(dy)
+        db = torch.empty(n, dtype=torch.float32, device=dy.device)
+        need_colsum = True
+    else:
+        need_colsum = False
+    if use_side:
+        side = _side_stream(dy.device)
+        side.wait_event(dy_ready)                    # dy is complete; the dgrad above runs concurrently
+        with torch.cuda.stream(side):
+            ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, splitk=_splitk_for(n, k, m), m_live=m_live)
+            if need_colsum:
+                ops.colsum(dy, out=db)
+    else:
+        ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, splitk=_splitk_for(n, k, m), m_live=m_live)   # both stored (Kred=m, .)
+        if need_colsum:
+            ops.colsum(dy, out=db)
     if dx_colsum is not None:
         return dx, dw, (db if need_bias else None), dxcs
     return dx, dw, (db if need_bias else None)
@@ -169,6 +208,7 @@ class TransformerBlockFn(torch.autograd.Function):
         dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, amask, attn_saved, ao, cu=cu)
         dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live)
         dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1, m_live=m_live)
+        join_side_stream(dx.device)                  # the four weight gradients (side stream) are complete
         return (dx.view(xshape), dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2,
                 None, None, None, None, None, None, None, None, None, None)
 

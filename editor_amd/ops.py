@@ -6,6 +6,7 @@ import torch
 from . import _lib
 
 call = _lib.call
+_raw_stream = _lib._raw_stream
 
 
 # ---------------------------------------------------------------------------------------------
@@ -75,8 +76,9 @@ _WS = {}
 
 
 def workspace(device, nfloats):
-    """Per-device fp32 scratch for partial reductions (kernels never allocate)."""
-    key = (device.type, device.index)
+    """fp32 scratch for partial reductions (kernels never allocate): one buffer per device AND stream, so that the
+    weight-gradient products running on the side stream never share partial-sum slabs with the main stream."""
+    key = (device.type, device.index, _raw_stream(device.index if device.index is not None else torch.cuda.current_device()))
     ws = _WS.get(key)
     if ws is None or ws.numel() < nfloats:
         ws = torch.empty(max(int(nfloats), 1 << 22), dtype=torch.float32, device=device)
@@ -124,9 +126,10 @@ def layernorm_bwd(dy, x2d, gamma, mean, rstd, rowmask=None, mask_period=0, dx_in
     return dx, dg, db
 
 
-def colsum(dy):
+def colsum(dy, out=None):
     m, n = dy.shape
-    out = torch.empty(n, dtype=torch.float32, device=dy.device)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=dy.device)
     ws = workspace(dy.device, WS_ROWS * n)
     call("editor_colsum", dy, _is_bf16(dy), m, n, n, out, ws, WS_ROWS)
     return out
