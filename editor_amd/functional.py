@@ -67,6 +67,7 @@ def _linear_fwd(x2d, w_act, bias, out_dtype, m_live=None):
 # (measured: see DESIGN.md 4.2).  Discipline: outputs are allocated on the main stream; the side stream waits for an
 # event recorded after the producer of dy; the backward function joins (main waits side) before it returns.
 _SIDE = {}
+_SIDE_KEEP = []
 WGRAD_SIDE_STREAM = os.environ.get("EDITOR_WGRAD_STREAM", "1") != "0"
 
 
@@ -82,6 +83,7 @@ def join_side_stream(device):
     st = _SIDE.get(device.index)
     if st is not None:
         torch.cuda.current_stream(device).wait_stream(st)
+    _SIDE_KEEP.clear()          # (main-stream work enqueued from here on is ordered after the side stream's reads)
 
 
 def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None):
@@ -109,6 +111,10 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, 
     if use_side:
         side = _side_stream(dy.device)
         side.wait_event(dy_ready)                    # dy is complete; the dgrad above runs concurrently
+        # dy may be released by the caller (and its block re-used by a main-stream allocation) before the side stream has
+        # read it: keep both operands referenced until the join (cheaper than record_stream, which made the caching
+        # allocator hold blocks back and cost 3 ms per eager step)
+        _SIDE_KEEP.append((dy, x2d))
         with torch.cuda.stream(side):
             ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, splitk=_splitk_for(n, k, m), m_live=m_live)
             if need_colsum:
