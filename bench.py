@@ -223,7 +223,25 @@ def main():
         opt.step()
         return loss
 
-    want_graph = not use_dist and args.graph
+    def fwd_bwd():                                   # the part of a multi-GPU step that is captured
+        opt.zero_grad(set_to_none=True)
+        out = model(img, label=label, cam_label=cam, view_label=view, img_path=None, writer=writer, epoch=1)
+        loss = losses.loss_pairs(out, label)
+        loss.backward()
+        return loss
+
+    # Multi-GPU: forward + backward are captured into a hipGraph as well (one rank = one process = the same ~1100
+    # launches per step, and eight Python processes share the host); the gradient exchange then runs after the replay
+    # as a few flat RCCL all-reduces and the fused SGD launch follows.  This gives up the overlap of the exchange with
+    # the backward (editor_amd.ddp.GradReducer, the eager path: EDITOR_DDP_EAGER=1 or --no-graph) for a step time that
+    # does not depend on how fast the host can issue launches.
+    dist_graph = use_dist and not args.no_graph and os.environ.get("EDITOR_DDP_EAGER") != "1"
+    flat_reduce = None
+    if dist_graph:
+        from editor_amd.ddp import FlatAllReduce
+        flat_reduce = FlatAllReduce(model)           # (the warm-up steps below still use the hook-driven reducer)
+
+    want_graph = (not use_dist and args.graph) or dist_graph
     side = torch.cuda.Stream() if want_graph else None
     if want_graph:
         # every eager step before the capture runs on a SIDE stream: AccumulateGrad nodes remember the stream they were
@@ -253,17 +271,27 @@ def main():
                 probe.recording = False
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            if dist_graph:
+                reducer.active = False               # from here on: no hooks, the exchange follows the replay
             opt.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                static_loss = step()
+                static_loss = fwd_bwd() if dist_graph else step()
             graph.replay()                                        # one untimed replay
+            if dist_graph:
+                flat_reduce()
+                opt.step()
             torch.cuda.synchronize()
-            print("[bench] timed region = hipGraph replay of the captured step", file=sys.stderr)
+            if rank == 0:
+                print("[bench] timed region = hipGraph replay of the captured " +
+                      ("forward+backward, then RCCL all-reduce + fused SGD" if dist_graph else "step"), file=sys.stderr)
         except Exception as e:                                    # capture unsupported here: fall back to eager timing
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr)
             graph = None
             probe.calls = []
+            if dist_graph:
+                dist_graph = False
+                reducer.active = True
             torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -272,6 +300,9 @@ def main():
     for i in range(args.steps):
         if graph is not None:
             graph.replay()
+            if dist_graph:
+                flat_reduce()
+                opt.step()
             loss = static_loss
         else:
             probe.recording = rank == 0 and i == args.steps - 1
@@ -306,7 +337,8 @@ def main():
             "config": {"workload": f"{args.preset} 3-modal ViT-B/16 {h}x{w}, batch {b}/GPU, fwd+bwd+SGD step, "
                                    f"drop_path 0.1, SFTS+HMA HIP kernels",
                        "global_batch": world * b, "parallelism": f"dp{world}", "loss": round(lossv, 4),
-                       "launch": "hipGraph replay" if graph is not None else "eager"},
+                       "launch": ("hipGraph replay" + (" (fwd+bwd) + flat RCCL all-reduce + fused SGD" if dist_graph else ""))
+                       if graph is not None else "eager"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "kernel": "bf16 GEMM family: gemm_bf16_pp_kernel (256x256x64 ping-pong, fwd + dgrad) and gemm_bf16_pipe_kernel "

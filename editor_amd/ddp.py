@@ -107,3 +107,50 @@ class GradReducer:
             return
         for t in list(self.module.parameters()) + list(self.module.buffers()):
             dist.broadcast(t.data, src=src, group=self.group)
+
+
+class FlatAllReduce:
+    """Gradient exchange for a step whose forward + backward were captured into a hipGraph (bench.py, N > 1): the
+    gradients then live at fixed addresses, so they are packed once-and-for-all into a few flat buckets (views built at
+    the first call) and every step is: gather into the buckets, all-reduce (AVG on RCCL), scatter back.  No autograd
+    hooks, hence no overlap with the backward - the price of taking the ~1100 launches of the step off the host."""
+
+    def __init__(self, module, bucket_bytes=64 << 20, process_group=None):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.bucket_bytes = bucket_bytes
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self._avg = dist.get_backend(process_group) == "nccl"
+        self._buckets = None
+
+    def _build(self):
+        live = [p for p in self.params if p.grad is not None]
+        self._buckets, cur, size = [], [], 0
+        for p in live + [None]:
+            nbytes = 0 if p is None else p.grad.numel() * p.grad.element_size()
+            if cur and (p is None or size + nbytes > self.bucket_bytes):
+                flat = torch.empty(sum(q.grad.numel() for q in cur), dtype=cur[0].grad.dtype, device=cur[0].grad.device)
+                views, off = [], 0
+                for q in cur:
+                    views.append(flat[off:off + q.grad.numel()].view_as(q.grad))
+                    off += q.grad.numel()
+                self._buckets.append((flat, views, [q.grad for q in cur]))
+                cur, size = [], 0
+            if p is not None:
+                cur.append(p)
+                size += nbytes
+
+    @torch.no_grad()
+    def __call__(self):
+        if self._buckets is None:
+            self._build()
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        works = []
+        for flat, views, grads in self._buckets:
+            torch._foreach_copy_(views, grads)
+            works.append(dist.all_reduce(flat, op=op, group=self.group, async_op=True))
+        for w, (flat, views, grads) in zip(works, self._buckets):
+            w.wait()
+            if not self._avg:
+                flat.mul_(1.0 / self.world)
+            torch._foreach_copy_(grads, views)
