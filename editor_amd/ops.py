@@ -276,6 +276,15 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
         assert b.dtype == torch.bfloat16
         if m_live is not None and (m < 256 or n < 128 or k % 64):
             raise RuntimeError("live-row GEMM needs the pipelined path (M >= 256, N >= 128, K % 64 == 0)")
+        if trans_a and trans_b and splitk > 1 and k % 64 and k > 64 and m_live is None and beta == 0.0:
+            # weight gradient whose reduction length (token rows) is not a multiple of the 64-row K-tile: the pipelined
+            # kernel (LDS-DMA, deterministic split-K slabs) takes the whole tiles and a single-split product adds the
+            # < 64-row tail - instead of the generic kernel with fp32-atomic split-K for the whole reduction
+            k0 = (k // 64) * 64
+            gemm(a, b, c, m, n, k0, lda, ldb, ldc, 1, 1, alpha=alpha, splitk=splitk, a_off=a_off, b_off=b_off, c_off=c_off)
+            gemm(a, b, c, m, n, k - k0, lda, ldb, ldc, 1, 1, alpha=alpha, beta=1.0, splitk=1, a_off=a_off + k0 * lda,
+                 b_off=b_off + k0 * ldb, c_off=c_off)
+            return
         if colsum is not None:
             # colsum (n) fp32 <- column sums of the rounded output (bias gradient of the layer this gradient feeds):
             # per-tile-row partials from the GEMM epilogue, folded in a fixed order

@@ -453,3 +453,18 @@ def test_gemm_bf16_colsum_side_output(ops):
     cs2 = torch.empty(n, device="cuda")
     ops.gemm(dy.cuda(), w.cuda(), out, m, n, k, k, n, n, 0, 1, colsum=cs2)              # plain epilogue too
     assert rel_err(cs2.cpu(), out.float().sum(0).cpu()) < 1e-5
+
+
+def test_gemm_bf16_wgrad_ragged_reduction_is_deterministic(ops):
+    """Token-row counts that are not a multiple of 64 (e.g. B = 32: 3*32*129 = 12 384): whole K-tiles through the
+    split-K slab kernel + one tail product; bit-identical run to run and equal to the fp64 reference."""
+    m, n, k = 12384, 768, 384
+    dy = (torch.randn(m, n, generator=_g(1)) * 0.1).bfloat16().cuda()
+    x = torch.randn(m, k, generator=_g(2)).bfloat16().cuda()
+    outs = []
+    for _ in range(3):
+        dw = torch.empty(n, k, device="cuda")
+        ops.gemm(dy, x, dw, n, k, m, n, k, k, 1, 1, splitk=6)
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert rel_err(outs[0].cpu(), dy.float().t().double().cpu() @ x.float().double().cpu()) < 1e-4

@@ -211,3 +211,72 @@ def test_eval_bf16_384x128_config4():
     err = rel_err(cls4t.cpu(), g["cls4t"])
     print("bf16 384x128 cls4t rel err:", err)
     assert err < 2e-2
+
+
+def test_hipgraph_replay_matches_eager_training():
+    """The whole training step (forward, HIP loss head, backward with the side-stream weight gradients, fused SGD with
+    drop-path) captured into a hipGraph and replayed == the same number of eager steps: identical kernels on identical
+    inputs, so the parameters and the drop-path generator state must come out bit-identical."""
+    from editor_amd import losses
+    from editor_amd.optim import FusedSGD
+
+    class _Quiet:
+        def add_scalar(self, *a, **k):
+            pass
+
+    def build():
+        torch.manual_seed(77)
+        m, cfg, c, cams = _model("RGBNT201", 31, "bf16", drop_path=0.1)
+        m.train()
+        opt = FusedSGD(m.named_parameters(), base_lr=1e-2, weight_decay=1e-4, bias_lr_factor=2.0, weight_decay_bias=1e-4,
+                       momentum=0.9)
+        return m, opt, cams
+
+    b = 64      # 3*b*129 token rows must be a multiple of 64: otherwise the wgrad split-K falls back to fp32 atomics
+    m1, opt1, cams = build()
+    h, w = 256, 128
+    img, label, cam, view = synth.make_batch(5, b, h, w, cams, instances=8)
+    img, label, cam, view = _cuda_batch(img, label, cam, view)
+
+    def make_step(m, opt):
+        def step():
+            opt.zero_grad(set_to_none=True)
+            out = m(img, label=label, cam_label=cam, view_label=view, img_path=None, writer=_Quiet(), epoch=1)
+            loss = losses.loss_pairs(out, label)
+            loss.backward()
+            opt.step()
+            return loss
+        return step
+
+    warm, reps = 2, 3
+    s1 = make_step(m1, opt1)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # (side stream: see bench.py on AccumulateGrad and capture)
+        for _ in range(warm + reps):
+            s1()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+
+    m2, opt2, _ = build()
+    s2 = make_step(m2, opt2)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            s2()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    opt2.zero_grad(set_to_none=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_loss = s2()
+    for _ in range(reps):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(static_loss).item()
+    assert int(m1._drop_state.item()) == int(m2._drop_state.item())
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in ("BACKBONE.base.blocks.3.attn.qkv.weight", "BACKBONE.base.blocks.11.mlp.fc2.bias", "FUSE_HEAD.weight",
+              "FUSE_block.attn1.qkv.weight", "BACKBONE.base.cls_token", "FUSE_BN.running_mean",
+              "FUSE_block.memory_cls.RGB_centers"):
+        assert torch.equal(sd1[k], sd2[k]), k
