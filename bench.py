@@ -293,6 +293,14 @@ def main():
                 dist_graph = False
                 reducer.active = True
             torch.cuda.synchronize()
+    if dist_graph or (use_dist and want_graph):
+        # all ranks must time the SAME path: the flat exchange and the hook-driven one issue different collectives
+        okf = torch.tensor([1.0 if graph is not None else 0.0], device=dev)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if okf.item() < 0.5 and graph is not None:
+            graph, dist_graph = None, False
+            reducer.active = True
+            probe.calls = []
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -360,6 +368,12 @@ def main():
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+    if use_dist:
+        # RCCL's banner sits in a C++ stream buffer that is only flushed by the static destructors at interpreter exit,
+        # i.e. AFTER the JSON line: leave without running them (everything of ours is flushed and the group is destroyed)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
