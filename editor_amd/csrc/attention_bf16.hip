@@ -109,8 +109,11 @@ __device__ __forceinline__ uint32_t nibble_of(unsigned long long lo, unsigned lo
     return (uint32_t)((t < 16 ? lo >> (4 * t) : hi >> (4 * (t - 16))) & 0xfull);
 }
 
-template <int NT, bool BWD>
-__global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
+// FULL: every sequence fills all NT key tiles (dense backbone calls): the tile loops then have compile-time trip counts,
+// so the compiler batches the LDS fragment reads of many tiles ahead of the MFMAs instead of serialising
+// "read -> wait -> MFMA" behind a branch per tile (that serialisation made the forward LDS-latency-bound).
+template <int NT, bool BWD, bool FULL = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_q_pass_kernel(AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Tp = NT * 16;
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
     const long ld = 3L * D;
     const long row0 = a.cu ? (long)a.cu[b] : (long)b * a.T;         // first packed row of this sequence
     const int T = a.cu ? a.cu[b + 1] - a.cu[b] : a.T;               // its length
-    const int nt = min(NT, ((T + 31) >> 5) << 1);                   // key tiles actually populated (even count)
+    const int nt = FULL ? NT : min(NT, ((T + 31) >> 5) << 1);       // key tiles actually populated (even count)
     const bf16_t* qbase = a.qkv + row0 * ld + hh * HD;
     load_image(kimg, qbase + D, ld, T, nt * 16);
     load_image(vimg, qbase + 2 * D, ld, T, nt * 16);
@@ -158,6 +161,28 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
             // its second sweep and pays the online-rescale exponentials on top: 9 instead of 4 per 4 keys) -----------
             float4_t sreg[NT];
             float m = -INFINITY;
+            if constexpr (FULL) {
+                // two key tiles at a time: four fragment reads in flight, then four MFMAs (two independent accumulators);
+                // the scheduling barrier keeps the compiler from hoisting ALL reads up front (163 VGPRs, half the occupancy)
+#pragma unroll
+                for (int t = 0; t < NT; t += 2) {
+                    const short8_t a0 = frag_k(kimg, t * 16, 0, lane), a1 = frag_k(kimg, t * 16, 1, lane);
+                    const short8_t b0 = frag_k(kimg, t * 16 + 16, 0, lane), b1 = frag_k(kimg, t * 16 + 16, 1, lane);
+                    float4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, qf[0], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[1], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, qf[1], acc1, 0, 0, 0);
+                    const uint32_t vb0 = nibble_of(kv0, kv1, t), vb1 = nibble_of(kv0, kv1, t + 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sreg[t][r] = (vb0 >> r) & 1u ? acc0[r] * sc : -INFINITY;
+                        sreg[t + 1][r] = (vb1 >> r) & 1u ? acc1[r] * sc : -INFINITY;
+                        m = fmaxf(m, fmaxf(sreg[t][r], sreg[t + 1][r]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 sreg[t] = float4_t{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -174,12 +199,13 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
                     }
                 }
             }
+            }
             const float M = group_max(m);
             const float Ms = M > -INFINITY ? M : 0.f;                  // (fully masked row: every exponent is -inf -> 0)
             float l = 0.f;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                if (t < nt) {
+                if (FULL || t < nt) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { sreg[t][r] = __builtin_amdgcn_exp2f(sreg[t][r] - Ms); l += sreg[t][r]; }
                 }
@@ -194,7 +220,7 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
             for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s2 = 0; s2 < NT / 2; ++s2)
-                if (2 * s2 < nt) {
+                if (FULL || 2 * s2 < nt) {
                     uint2 pk[2];
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
@@ -207,6 +233,7 @@ __global__ __launch_bounds__(256) void attn_q_pass_kernel(AttnArgs a)
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt)
                         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(vimg, s2, dt, lane), pf, o[dt], 0, 0, 0);
+                    if (FULL) __builtin_amdgcn_sched_barrier(0);
                 }
             if (q < T) {
                 bf16_t* orow = a.out + (row0 + q) * D + hh * HD + 4 * lg;
@@ -474,9 +501,16 @@ int launch_all(const AttnArgs& a, int B, int mode, hipStream_t stream)
     const dim3 grid(B * a.heads);
     int rc;
     if (mode == 0) {
-        auto k = attn_q_pass_kernel<NT, false>;
-        if ((rc = set_lds(k, img))) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(threads), img, stream, a);
+        const bool full = !a.cu && (((a.T + 31) >> 5) << 1) >= NT && NT <= 14;
+        if (full) {
+            auto k = attn_q_pass_kernel<NT, false, true>;
+            if ((rc = set_lds(k, img))) return rc;
+            hipLaunchKernelGGL(k, grid, dim3(threads), img, stream, a);
+        } else {
+            auto k = attn_q_pass_kernel<NT, false>;
+            if ((rc = set_lds(k, img))) return rc;
+            hipLaunchKernelGGL(k, grid, dim3(threads), img, stream, a);
+        }
         EDITOR_LAUNCH_CHECK();
     } else {
         auto k1 = attn_q_pass_kernel<NT, true>;
