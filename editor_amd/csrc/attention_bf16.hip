@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 const uint32_t vb = nibble_of(kv0, kv1, t);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    pv[r] = (vb >> r) & 1u ? __builtin_amdgcn_exp2f(acc[r] * sc - lse) : 0.f;
+                    pv[r] = __builtin_amdgcn_exp2f((vb >> r) & 1u ? acc[r] * sc - lse : -INFINITY);
                 if (!BWD) {
                     if (pr && 16 * t + 4 * lg < a.ldp)
                         *reinterpret_cast<float4*>(pr + 16 * t + 4 * lg) = make_float4(pv[0], pv[1], pv[2], pv[3]);
@@ -392,14 +392,18 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
                     s_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(qimg, u * 16, s, lane), kf[s], s_, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(doimg, u * 16, s, lane), vf[s], dp, 0, 0, 0);
                 }
+                // this lane's four queries are consecutive: one 16-byte LDS read each for lse and delta, and the mask goes
+                // into the exponent (exp2(-inf) = 0) - the per-element "cond ? exp2f(..) : 0" form compiled into four
+                // branch blocks, each with its own scalar LDS read and wait
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * u + 4 * lg);
+                const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 16 * u + 4 * lg);
+                const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq[4] = {d4.x, d4.y, d4.z, d4.w};
                 float pv[4], dsv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int qq = 16 * u + 4 * lg + r;
-                    const float l = lse_s[qq];
-                    const float pp = kok ? __builtin_amdgcn_exp2f(s_[r] * sc - l) : 0.f;      // l == +inf -> 0
+                    const float pp = __builtin_amdgcn_exp2f(kok ? s_[r] * sc - lq[r] : -INFINITY);   // lse == +inf -> 0
                     pv[r] = pp;
-                    dsv[r] = pp * (dp[r] - dl_s[qq]) * a.scale;
+                    dsv[r] = pp * (dp[r] - dq[r]) * a.scale;
                 }
                 pk[half] = pack4(pv[0], pv[1], pv[2], pv[3]);
                 dsk[half] = pack4(dsv[0], dsv[1], dsv[2], dsv[3]);
@@ -466,11 +470,12 @@ __global__ __launch_bounds__(256) void attn_rollout_step_kernel(const bf16_t* __
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 s_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(qimg, u * 16, s, lane), kf[s], s_, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qq = 16 * u + 4 * lg + r;
-                acc = fmaf(__builtin_amdgcn_exp2f(s_[r] * sc - lse_s[qq]), w_s[qq], acc);    // lse = +inf (pad rows) -> 0
-            }
+            const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * u + 4 * lg);
+            const float4 w4 = *reinterpret_cast<const float4*>(w_s + 16 * u + 4 * lg);
+            acc = fmaf(__builtin_amdgcn_exp2f(s_[0] * sc - l4.x), w4.x, acc);               // lse = +inf (pad rows) -> 0
+            acc = fmaf(__builtin_amdgcn_exp2f(s_[1] * sc - l4.y), w4.y, acc);
+            acc = fmaf(__builtin_amdgcn_exp2f(s_[2] * sc - l4.z), w4.z, acc);
+            acc = fmaf(__builtin_amdgcn_exp2f(s_[3] * sc - l4.w), w4.w, acc);
         }
         acc = group_sum(acc);
         if (lg == 0 && key < T) {

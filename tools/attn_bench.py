@@ -14,3 +14,7 @@ def bench(fn, n=20):
     return e0.elapsed_time(e1) / n * 1000
 print("fwd with probs  %.1f us" % bench(lambda: ops.attention_fwd(qkv, b, t, heads, hd, None, probs)))
 print("fwd no probs    %.1f us" % bench(lambda: ops.attention_fwd(qkv, b, t, heads, hd, None, None)))
+
+o, lse = ops.attention_fwd(qkv, b, t, heads, hd, None, None)
+do = torch.randn_like(o)
+print("bwd (dq + dk/dv)  %.1f us" % bench(lambda: ops.attention_bwd(qkv, do, b, t, heads, hd, None, lse, o)))
