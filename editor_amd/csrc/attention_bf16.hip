@@ -383,14 +383,25 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
 #pragma unroll 1
         for (int u2 = 0; u2 < nt / 2; ++u2) {
             uint2 pk[2], dsk[2];
+            // the eight k-major fragments of this pair of query tiles are requested together, ahead of the eight MFMAs
+            // (left to itself the compiler reads one fragment ahead: read -> wait -> MFMA, LDS latency each time)
+            short8_t fq[2][2], fd[2][2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    fq[half][s] = frag_k(qimg, (2 * u2 + half) * 16, s, lane);
+                    fd[half][s] = frag_k(doimg, (2 * u2 + half) * 16, s, lane);
+                }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int u = 2 * u2 + half;
                 float4_t s_ = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    s_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(qimg, u * 16, s, lane), kf[s], s_, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(doimg, u * 16, s, lane), vf[s], dp, 0, 0, 0);
+                    s_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[half][s], kf[s], s_, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[half][s], vf[s], dp, 0, 0, 0);
                 }
                 // this lane's four queries are consecutive: one 16-byte LDS read each for lse and delta, and the mask goes
                 // into the exponent (exp2(-inf) = 0) - the per-element "cond ? exp2f(..) : 0" form compiled into four
