@@ -264,7 +264,6 @@ class EDITOR(nn.Module):
         self.rollout_probs = bool(getattr(cfg.MODEL, "ROLLOUT_PROBS", False))
         self.teacher_index = None            # optional (B,N) bool: force the SFTS selection (bf16 protocol)
         self._drop_rates_dev = None
-        self._drop_step = 0
         self._drop_state = None
         self.last_aux = {}
 
