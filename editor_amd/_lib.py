@@ -72,13 +72,29 @@ class _Lib:
             else:
                 conv.append(a)                       # None -> NULL; ints / floats / ctypes arrays as they are
         # raw handle of the current stream of the arguments' device (the Stream-object route costs ~2 us per launch)
-        conv.append(_raw_stream(dev if dev >= 0 else torch.cuda.current_device()))
-        rc = fn(*conv)
+        cur = torch.cuda.current_device()
+        if dev < 0:
+            dev = cur
+        conv.append(_raw_stream(dev))
+        if dev != cur:                       # model on cuda:N without set_device(N): launch on the tensors' device
+            with torch.cuda.device(dev):
+                rc = fn(*conv)
+        else:
+            rc = fn(*conv)
         if rc != 0:
             raise RuntimeError(f"{name} failed: hipError {rc}")
 
 
 _LIB = None
+_PROBE = None
+
+
+def probe_lib():
+    """libeditor_probe.so (include/editor_debug.h): hardware-semantics probes for tests; never on the product path."""
+    global _PROBE
+    if _PROBE is None:
+        _PROBE = ctypes.CDLL(os.path.join(HERE, "libeditor_probe.so"))
+    return _PROBE
 
 
 def lib():

@@ -1,7 +1,11 @@
-"""Builds editor_amd/libeditor_hip.so (every HIP kernel of the hot path) for gfx950 with hipcc.
+"""Builds the HIP libraries of the hot path for gfx950 with hipcc.
 
-In-tree, explicit hipcc (no JIT cache): the .so travels to the GPU box with the repo snapshot.
-    python -m editor_amd.build [--force]
+    editor_amd/libeditor_hip.so          every kernel of the product path (csrc/*.hip except probe.hip)
+    editor_amd/libeditor_probe.so        csrc/probe.hip: hardware-semantics probes (tests only, include/editor_debug.h)
+    editor_amd/libeditor_gemm_trace.so   csrc/gemm_bf16.hip with -DEDITOR_DEBUG_TRACE (tools/gemm_bench.py; --trace only)
+
+In-tree, explicit hipcc (no JIT cache): the .so files travel to the GPU box with the repo snapshot.
+    python -m editor_amd.build [--force] [--trace]
 """
 import glob
 import os
@@ -11,9 +15,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libeditor_hip.so")
+LIB_PROBE = os.path.join(HERE, "libeditor_probe.so")
+LIB_TRACE = os.path.join(HERE, "libeditor_gemm_trace.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-munsafe-fp-atomics"]
+DEBUG_ONLY = {"probe.hip"}
 
 
 def _stale(target, deps):
@@ -23,31 +30,48 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "editor_hip.h")]
-    objs = []
+def _compile(jobs, verbose):
     procs = []
-    for s in srcs:
-        o = s[:-4] + ".o"
-        objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd))
-            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for s, p in procs:
+    for src, obj, extra in jobs:
+        cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             sys.stderr.write(out.decode())
-            raise RuntimeError("hipcc failed on " + s)
+            raise RuntimeError("hipcc failed on " + src)
         if verbose and out:
             print(out.decode())
-    if force or procs or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        subprocess.check_call(cmd)
+
+
+def _link(lib, objs):
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+
+
+def build(force=False, verbose=False, trace=False):
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    srcs = sorted(s for s in glob.glob(os.path.join(CSRC, "*.hip")) if os.path.basename(s) not in DEBUG_ONLY)
+    objs = [s[:-4] + ".o" for s in srcs]
+    jobs = [(s, o, []) for s, o in zip(srcs, objs) if force or _stale(o, [s] + hdrs)]
+    probe_src = os.path.join(CSRC, "probe.hip")
+    probe_obj = probe_src[:-4] + ".o"
+    if force or _stale(probe_obj, [probe_src] + hdrs):
+        jobs.append((probe_src, probe_obj, []))
+    trace_obj = os.path.join(CSRC, "gemm_bf16.trace.o")
+    gemm_src = os.path.join(CSRC, "gemm_bf16.hip")
+    if trace and (force or _stale(trace_obj, [gemm_src] + hdrs)):
+        jobs.append((gemm_src, trace_obj, ["-DEDITOR_DEBUG_TRACE"]))
+    _compile(jobs, verbose)
+    if force or _stale(LIB, objs):
+        _link(LIB, objs)
+    if force or _stale(LIB_PROBE, [probe_obj]):
+        _link(LIB_PROBE, [probe_obj])
+    if trace and (force or _stale(LIB_TRACE, [trace_obj])):
+        _link(LIB_TRACE, [trace_obj])
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, trace="--trace" in sys.argv))

@@ -15,7 +15,11 @@ PRESETS = {
     "RGBNT100": dict(size=(128, 256), al=0, num_class=50, cams=8),
     # configs/MSVR310/EDITOR.yml but 384x128 input (BASELINE.json config 4); C=155 chosen
     "MSVR310": dict(size=(384, 128), al=0, num_class=155, cams=8),
+    # BASELINE.json config 5 (synthetic extension, no dataset): 4 modalities, ViT-L/16, 512x256 input -> 512 patch tokens
+    "SYNTH4L": dict(size=(512, 256), al=0, num_class=171, cams=4,
+                    extra=dict(transformer_type="vit_large_patch16_224", num_modalities=4)),
 }
+MODALITY_KEYS = ("RGB", "NI", "TI", "M4")
 
 
 def make_cfg(size_train=(256, 128), al=1, transformer_type="vit_base_patch16_224",
@@ -35,12 +39,21 @@ def make_cfg(size_train=(256, 128), al=1, transformer_type="vit_base_patch16_224
     model.ROLLOUT_PROBS = extra.pop("rollout_probs", False)      # bf16 mode: keep the materialised (L,3B,h,T,T) probabilities
     for k, v in extra.items():
         setattr(model, k.upper(), v)
-    return SimpleNamespace(MODEL=model,
+    # config/defaults.py:96-138 (the keys solver/make_optimizer.py and solver/scheduler_factory.py read)
+    solver = SimpleNamespace(OPTIMIZER_NAME="SGD", MAX_EPOCHS=70, BASE_LR=0.001, LARGE_FC_LR=False, BIAS_LR_FACTOR=2,
+                             MOMENTUM=0.9, WEIGHT_DECAY=0.0001, WEIGHT_DECAY_BIAS=0.0001, WARMUP_ITERS=10,
+                             CENTER_LR=0.5, MARGIN=0.3, SEED=1111, IMS_PER_BATCH=128)
+    return SimpleNamespace(MODEL=model, SOLVER=solver,
+                           DATALOADER=SimpleNamespace(SAMPLER="softmax_triplet", NUM_INSTANCE=16, NUM_WORKERS=14),
                            INPUT=SimpleNamespace(SIZE_TRAIN=list(size_train),
                                                  SIZE_TEST=list(size_train)))
 
 
 def preset(name, **over):
     p = PRESETS[name]
-    cfg = make_cfg(size_train=p["size"], al=p["al"], **over)
+    kw = dict(p.get("extra", {}))
+    kw.update(over)
+    al = kw.pop("al", p["al"])
+    size = kw.pop("size_train", p["size"])
+    cfg = make_cfg(size_train=size, al=al, **kw)
     return cfg, p["num_class"], p["cams"]

@@ -20,7 +20,19 @@ typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((ext_vector_type(8))) short short8_t;
 typedef __attribute__((ext_vector_type(4))) float float4_t;
 
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+
 namespace {
+
+// F16 = false: bfloat16 q/k/v/P/dS operands; true: IEEE half (the reference's autocast dtype) - same instruction rate
+template <bool F16>
+__device__ __forceinline__ float4_t mfma16(short8_t a, short8_t b, float4_t c)
+{
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
 constexpr int HD = 64;                 // head dim (ViT-B/L, DeiT-S backbones)
 constexpr int ROWB = HD * 2;           // bytes per LDS image row
@@ -70,9 +82,10 @@ __device__ __forceinline__ short8_t frag_own(const bf16_t* __restrict__ base, lo
     return *reinterpret_cast<const short8_t*>(base + (long)row * ld + s * 32 + (lane >> 4) * 8);
 }
 
+template <bool F16>
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d)
 {
-    uint2 u; u.x = pack_bf16x2(a, b); u.y = pack_bf16x2(c, d); return u;
+    uint2 u; u.x = H16<F16>::pack2(a, b); u.y = H16<F16>::pack2(c, d); return u;
 }
 __device__ __forceinline__ short8_t join(uint2 lo, uint2 hi)
 {
@@ -99,20 +112,19 @@ struct AttnArgs {
 // costs 2 extra MFMAs per tile but no registers; DQ reads the value FWD saved), so a wave holds one score tile at
 // a time: ~64-90 VGPRs, 4+ waves/SIMD, instead of a full 16xT score block (256 VGPRs, one workgroup per CU).
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool bit_of(unsigned long long lo, unsigned long long hi, int bit)
+// the four validity bits of key tile t (16 tiles per 64-bit word; NT <= 38 tiles -> three words: a two-word form
+// silently aliased tiles >= 32, i.e. keys >= 512 of the 513..608-token sequences)
+struct KeyBits { unsigned long long w[3]; };
+__device__ __forceinline__ uint32_t nibble_of(const KeyBits& kb, int t)
 {
-    return bit < 64 ? (lo >> bit) & 1ull : (hi >> (bit - 64)) & 1ull;
-}
-// the four validity bits of key tile t (one 64-bit shift per tile; the per-key tests are 32-bit)
-__device__ __forceinline__ uint32_t nibble_of(unsigned long long lo, unsigned long long hi, int t)
-{
-    return (uint32_t)((t < 16 ? lo >> (4 * t) : hi >> (4 * (t - 16))) & 0xfull);
+    const unsigned long long word = t < 16 ? kb.w[0] : (t < 32 ? kb.w[1] : kb.w[2]);
+    return (uint32_t)((word >> (4 * (t & 15))) & 0xfull);
 }
 
 // FULL: every sequence fills all NT key tiles (dense backbone calls): the tile loops then have compile-time trip counts,
 // so the compiler batches the LDS fragment reads of many tiles ahead of the MFMAs instead of serialising
 // "read -> wait -> MFMA" behind a branch per tile (that serialisation made the forward LDS-latency-bound).
-template <int NT, bool BWD, bool FULL = false>
+template <int NT, bool BWD, bool FULL, bool F16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_q_pass_kernel(AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -134,15 +146,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int li = lane & 15, lg = lane >> 4;
     const uint8_t* mk = a.mask ? a.mask + (long)b * T : nullptr;
     // validity bits of this lane's keys: key(t, r) = 16t + 4g + r
-    unsigned long long kv0 = 0ull, kv1 = 0ull;
+    KeyBits kb{{0ull, 0ull, 0ull}};
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int key = 16 * t + 4 * lg + r;
             const bool ok = key < T && (!mk || mk[key]);
-            const int bit = t * 4 + r;
-            if (ok) { if (bit < 64) kv0 |= 1ull << bit; else kv1 |= 1ull << (bit - 64); }
+            if (ok) kb.w[t >> 4] |= 1ull << (4 * (t & 15) + r);
         }
     const float sc = a.scale * kLog2e;
     const long row_idx0 = (long)hh * a.Mtot + row0;                // lse / delta index of row 0
@@ -169,11 +180,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     const short8_t a0 = frag_k(kimg, t * 16, 0, lane), a1 = frag_k(kimg, t * 16, 1, lane);
                     const short8_t b0 = frag_k(kimg, t * 16 + 16, 0, lane), b1 = frag_k(kimg, t * 16 + 16, 1, lane);
                     float4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, qf[0], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[1], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, qf[1], acc1, 0, 0, 0);
-                    const uint32_t vb0 = nibble_of(kv0, kv1, t), vb1 = nibble_of(kv0, kv1, t + 1);
+                    acc0 = mfma16<F16>(a0, qf[0], acc0);
+                    acc1 = mfma16<F16>(b0, qf[0], acc1);
+                    acc0 = mfma16<F16>(a1, qf[1], acc0);
+                    acc1 = mfma16<F16>(b1, qf[1], acc1);
+                    const uint32_t vb0 = nibble_of(kb, t), vb1 = nibble_of(kb, t + 1);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         sreg[t][r] = (vb0 >> r) & 1u ? acc0[r] * sc : -INFINITY;
@@ -190,8 +201,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(kimg, t * 16, s, lane), qf[s], acc, 0, 0, 0);
-                    const uint32_t vb = nibble_of(kv0, kv1, t);
+                        acc = mfma16<F16>(frag_k(kimg, t * 16, s, lane), qf[s], acc);
+                    const uint32_t vb = nibble_of(kb, t);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         sreg[t][r] = (vb >> r) & 1u ? acc[r] * sc : -INFINITY;
@@ -227,19 +238,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                         const int t = 2 * s2 + half;
                         const float p0 = sreg[t][0] * inv, p1 = sreg[t][1] * inv, p2 = sreg[t][2] * inv, p3 = sreg[t][3] * inv;
                         if (pr && 16 * t + 4 * lg < a.ldp) *reinterpret_cast<float4*>(pr + 16 * t + 4 * lg) = make_float4(p0, p1, p2, p3);
-                        pk[half] = pack4(p0, p1, p2, p3);
+                        pk[half] = pack4<F16>(p0, p1, p2, p3);
                     }
                     const short8_t pf = join(pk[0], pk[1]);
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt)
-                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(vimg, s2, dt, lane), pf, o[dt], 0, 0, 0);
+                        o[dt] = mfma16<F16>(frag_t(vimg, s2, dt, lane), pf, o[dt]);
                     if (FULL) __builtin_amdgcn_sched_barrier(0);
                 }
             if (q < T) {
                 bf16_t* orow = a.out + (row0 + q) * D + hh * HD + 4 * lg;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
-                    *reinterpret_cast<uint2*>(orow + dt * 16) = pack4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+                    *reinterpret_cast<uint2*>(orow + dt * 16) = pack4<F16>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
             }
             continue;
         }
@@ -251,9 +262,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(kimg, t * 16, s, lane), qf[s], acc, 0, 0, 0);
+                    acc = mfma16<F16>(frag_k(kimg, t * 16, s, lane), qf[s], acc);
                 float sv[4], tm = -INFINITY;
-                const uint32_t vb = nibble_of(kv0, kv1, t);
+                const uint32_t vb = nibble_of(kb, t);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     sv[r] = (vb >> r) & 1u ? acc[r] * sc : -INFINITY;
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 dof[s] = frag_own(dobase, D, q0, T, s, lane);
                 const short8_t of = frag_own(obase, D, q0, T, s, lane);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dl += bf16_to_f32((bf16_t)dof[s][e]) * bf16_to_f32((bf16_t)of[e]);
+                for (int e = 0; e < 8; ++e) dl += H16<F16>::to_f32((uint16_t)dof[s][e]) * H16<F16>::to_f32((uint16_t)of[e]);
             }
             dl = group_sum(dl);
             if (lg == 0 && q < T) a.delta[row_idx0 + q] = dl;
@@ -301,20 +312,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 float4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(kimg, t * 16, s, lane), qf[s], acc, 0, 0, 0);
-                    if (BWD) dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(vimg, t * 16, s, lane), dof[s], dp, 0, 0, 0);
+                    acc = mfma16<F16>(frag_k(kimg, t * 16, s, lane), qf[s], acc);
+                    if (BWD) dp = mfma16<F16>(frag_k(vimg, t * 16, s, lane), dof[s], dp);
                 }
                 float pv[4];
-                const uint32_t vb = nibble_of(kv0, kv1, t);
+                const uint32_t vb = nibble_of(kb, t);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     pv[r] = __builtin_amdgcn_exp2f((vb >> r) & 1u ? acc[r] * sc - lse : -INFINITY);
                 if (!BWD) {
                     if (pr && 16 * t + 4 * lg < a.ldp)
                         *reinterpret_cast<float4*>(pr + 16 * t + 4 * lg) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-                    pk[half] = pack4(pv[0], pv[1], pv[2], pv[3]);
+                    pk[half] = pack4<F16>(pv[0], pv[1], pv[2], pv[3]);
                 } else {
-                    pk[half] = pack4(pv[0] * (dp[0] - dl) * a.scale, pv[1] * (dp[1] - dl) * a.scale,
+                    pk[half] = pack4<F16>(pv[0] * (dp[0] - dl) * a.scale, pv[1] * (dp[1] - dl) * a.scale,
                                      pv[2] * (dp[2] - dl) * a.scale, pv[3] * (dp[3] - dl) * a.scale);
                 }
             }
@@ -322,14 +333,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const char* timg = BWD ? kimg : vimg;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(timg, s2, dt, lane), pf, o[dt], 0, 0, 0);
+                o[dt] = mfma16<F16>(frag_t(timg, s2, dt, lane), pf, o[dt]);
         }
         if (q < T) {
             bf16_t* orow = BWD ? a.dqkv + (row0 + q) * ld + hh * HD + 4 * lg
                                : a.out + (row0 + q) * D + hh * HD + 4 * lg;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<uint2*>(orow + dt * 16) = pack4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+                *reinterpret_cast<uint2*>(orow + dt * 16) = pack4<F16>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
         }
     }
 }
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // ---------------------------------------------------------------------------------------------------------
 // DKV pass (own = keys; LDS holds the Q and dO images + lse/delta of every query)
 // ---------------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool F16>
 __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -400,8 +411,8 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
                 float4_t s_ = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    s_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[half][s], kf[s], s_, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[half][s], vf[s], dp, 0, 0, 0);
+                    s_ = mfma16<F16>(fq[half][s], kf[s], s_);
+                    dp = mfma16<F16>(fd[half][s], vf[s], dp);
                 }
                 // this lane's four queries are consecutive: one 16-byte LDS read each for lse and delta, and the mask goes
                 // into the exponent (exp2(-inf) = 0) - the per-element "cond ? exp2f(..) : 0" form compiled into four
@@ -416,22 +427,22 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
                     pv[r] = pp;
                     dsv[r] = pp * (dp[r] - dq[r]) * a.scale;
                 }
-                pk[half] = pack4(pv[0], pv[1], pv[2], pv[3]);
-                dsk[half] = pack4(dsv[0], dsv[1], dsv[2], dsv[3]);
+                pk[half] = pack4<F16>(pv[0], pv[1], pv[2], pv[3]);
+                dsk[half] = pack4<F16>(dsv[0], dsv[1], dsv[2], dsv[3]);
             }
             const short8_t pf = join(pk[0], pk[1]), df = join(dsk[0], dsk[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(doimg, u2, dt, lane), pf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(qimg, u2, dt, lane), df, dk[dt], 0, 0, 0);
+                dv[dt] = mfma16<F16>(frag_t(doimg, u2, dt, lane), pf, dv[dt]);
+                dk[dt] = mfma16<F16>(frag_t(qimg, u2, dt, lane), df, dk[dt]);
             }
         }
         if (key < T) {
             bf16_t* krow = a.dqkv + (row0 + key) * ld + D + hh * HD + 4 * lg;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                *reinterpret_cast<uint2*>(krow + dt * 16) = pack4(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
-                *reinterpret_cast<uint2*>(krow + D + dt * 16) = pack4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+                *reinterpret_cast<uint2*>(krow + dt * 16) = pack4<F16>(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
+                *reinterpret_cast<uint2*>(krow + D + dt * 16) = pack4<F16>(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
             }
         }
     }
@@ -445,7 +456,7 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
 // pass: own = keys, LDS holds the Q image, lse and r_in; the weighted sum over queries is fp32 VALU work.
 // r_in == NULL: one-hot CLS row (the first step, l = L-1).  final: write r_out[1:] to a (BH, T-1) score tensor.
 // ---------------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool F16>
 __global__ __launch_bounds__(256) void attn_rollout_step_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
     const float* __restrict__ r_in, int T, int heads, float scale, long Mtot, float* __restrict__ r_out, int final_step)
 {
@@ -480,7 +491,7 @@ __global__ __launch_bounds__(256) void attn_rollout_step_kernel(const bf16_t* __
             float4_t s_ = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 2; ++s)
-                s_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(qimg, u * 16, s, lane), kf[s], s_, 0, 0, 0);
+                s_ = mfma16<F16>(frag_k(qimg, u * 16, s, lane), kf[s], s_);
             const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * u + 4 * lg);
             const float4 w4 = *reinterpret_cast<const float4*>(w_s + 16 * u + 4 * lg);
             acc = fmaf(__builtin_amdgcn_exp2f(s_[0] * sc - l4.x), w4.x, acc);               // lse = +inf (pad rows) -> 0
@@ -492,6 +503,221 @@ __global__ __launch_bounds__(256) void attn_rollout_step_kernel(const bf16_t* __
         if (lg == 0 && key < T) {
             if (final_step) { if (key >= 1) r_out[(long)blockIdx.x * (T - 1) + key - 1] = acc; }
             else r_out[(long)blockIdx.x * T + key] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Long sequences (T > 608: the joint HMA block of the 4-modal 512-token configuration, up to 4 x 513 = 2052 tokens).
+// The key range no longer fits the CU's LDS, so a workgroup owns 64 "own" rows (one 16-row tile per wave) and streams the
+// "other" side through LDS in chunks of 256 rows (K,V or Q,dO: 64 KiB -> two workgroups per CU); grid = (B*heads,
+// ceil(Tmax/64)).  Same tile algebra as the whole-sequence kernels above; key validity is computed per tile (no masks:
+// long sequences are the dense backbone or packed live tokens).  FWD sweeps the chunks twice (row statistics, then
+// P V with the final log-sum-exp - no running rescale of the output accumulators); DQ and DKV sweep once.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LCH = 256;
+
+template <bool BWD, bool F16>
+__global__ __launch_bounds__(256) void attn_q_long_kernel(AttnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* kimg = smem;
+    char* vimg = smem + LCH * ROWB;
+    const int D = a.heads * HD;
+    const int b = blockIdx.x / a.heads, hh = blockIdx.x % a.heads;
+    const long ld = 3L * D;
+    const long row0 = a.cu ? (long)a.cu[b] : (long)b * a.T;
+    const int T = a.cu ? a.cu[b + 1] - a.cu[b] : a.T;
+    const int qb0 = blockIdx.y * 64;
+    if (qb0 >= T) return;                                             // (whole workgroup: before any barrier)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const bf16_t* qbase = a.qkv + row0 * ld + hh * HD;
+    const int q0 = qb0 + w * 16, q = q0 + li;
+    const bool qok = q < T;
+    short8_t qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) qf[s] = frag_own(qbase, ld, q0, T, s, lane);
+    const float sc = a.scale * kLog2e;
+    const long row_idx0 = (long)hh * a.Mtot + row0;
+    float lse;
+    if (!BWD) {
+        float m = -INFINITY, l = 0.f;
+        for (int c0 = 0; c0 < T; c0 += LCH) {
+            const int len = min(LCH, T - c0), ntc = ((len + 31) >> 5) << 1;
+            __syncthreads();
+            load_image(kimg, qbase + D + (long)c0 * ld, ld, len, ntc * 16);
+            __syncthreads();
+#pragma unroll 2
+            for (int t = 0; t < ntc; ++t) {
+                float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) acc = mfma16<F16>(frag_k(kimg, t * 16, s, lane), qf[s], acc);
+                float sv[4], tm = -INFINITY;
+                const int key0 = c0 + 16 * t + 4 * lg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sv[r] = key0 + r < T ? acc[r] * sc : -INFINITY;
+                    tm = fmaxf(tm, sv[r]);
+                }
+                if (tm > m) { l *= __builtin_amdgcn_exp2f(m - tm); m = tm; }
+                if (m > -INFINITY) l += (__builtin_amdgcn_exp2f(sv[0] - m) + __builtin_amdgcn_exp2f(sv[1] - m)) + (__builtin_amdgcn_exp2f(sv[2] - m) + __builtin_amdgcn_exp2f(sv[3] - m));
+            }
+        }
+        const float M = group_max(m);
+        const float L = group_sum(m > -INFINITY ? l * __builtin_amdgcn_exp2f(m - M) : 0.f);
+        lse = (qok && L > 0.f) ? M + __builtin_amdgcn_logf(L) : INFINITY;
+        if (a.lse && lg == 0 && qok) a.lse[row_idx0 + q] = lse;
+    } else {
+        lse = qok ? a.lse[row_idx0 + q] : INFINITY;
+    }
+    float dl = 0.f;
+    short8_t dof[2];
+    if (BWD) {
+        const bf16_t* dobase = a.dout + row0 * D + hh * HD;
+        const bf16_t* obase = a.out_fwd + row0 * D + hh * HD;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            dof[s] = frag_own(dobase, D, q0, T, s, lane);
+            const short8_t of = frag_own(obase, D, q0, T, s, lane);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += H16<F16>::to_f32((uint16_t)dof[s][e]) * H16<F16>::to_f32((uint16_t)of[e]);
+        }
+        dl = group_sum(dl);
+        if (lg == 0 && qok) a.delta[row_idx0 + q] = dl;
+    }
+    float4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < T; c0 += LCH) {
+        const int len = min(LCH, T - c0), ntc = ((len + 31) >> 5) << 1;
+        __syncthreads();
+        load_image(kimg, qbase + D + (long)c0 * ld, ld, len, ntc * 16);
+        load_image(vimg, qbase + 2 * D + (long)c0 * ld, ld, len, ntc * 16);
+        __syncthreads();
+#pragma unroll 1
+        for (int s2 = 0; s2 < ntc / 2; ++s2) {
+            uint2 pk[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int t = 2 * s2 + half;
+                float4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    acc = mfma16<F16>(frag_k(kimg, t * 16, s, lane), qf[s], acc);
+                    if (BWD) dp = mfma16<F16>(frag_k(vimg, t * 16, s, lane), dof[s], dp);
+                }
+                float pv[4];
+                const int key0 = c0 + 16 * t + 4 * lg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(key0 + r < T ? acc[r] * sc - lse : -INFINITY);
+                if (!BWD) pk[half] = pack4<F16>(pv[0], pv[1], pv[2], pv[3]);
+                else pk[half] = pack4<F16>(pv[0] * (dp[0] - dl) * a.scale, pv[1] * (dp[1] - dl) * a.scale,
+                                           pv[2] * (dp[2] - dl) * a.scale, pv[3] * (dp[3] - dl) * a.scale);
+            }
+            const short8_t pf = join(pk[0], pk[1]);
+            const char* timg = BWD ? kimg : vimg;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16<F16>(frag_t(timg, s2, dt, lane), pf, o[dt]);
+        }
+    }
+    if (qok) {
+        bf16_t* orow = BWD ? a.dqkv + (row0 + q) * ld + hh * HD + 4 * lg : a.out + (row0 + q) * D + hh * HD + 4 * lg;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<uint2*>(orow + dt * 16) = pack4<F16>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+    }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void attn_kv_long_kernel(AttnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* qimg = smem;
+    char* doimg = smem + LCH * ROWB;
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * LCH * ROWB);
+    float* dl_s = lse_s + LCH;
+    const int D = a.heads * HD;
+    const int b = blockIdx.x / a.heads, hh = blockIdx.x % a.heads;
+    const long ld = 3L * D;
+    const long row0 = a.cu ? (long)a.cu[b] : (long)b * a.T;
+    const int T = a.cu ? a.cu[b + 1] - a.cu[b] : a.T;
+    const int kb0 = blockIdx.y * 64;
+    if (kb0 >= T) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const bf16_t* qbase = a.qkv + row0 * ld + hh * HD;
+    const int k0 = kb0 + w * 16, key = k0 + li;
+    const bool kok = key < T;
+    const float sc = a.scale * kLog2e;
+    short8_t kf[2], vf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        kf[s] = frag_own(qbase + D, ld, k0, T, s, lane);
+        vf[s] = frag_own(qbase + 2 * D, ld, k0, T, s, lane);
+    }
+    float4_t dv[4], dk[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dv[dt] = float4_t{0.f, 0.f, 0.f, 0.f}; dk[dt] = dv[dt]; }
+    for (int c0 = 0; c0 < T; c0 += LCH) {
+        const int len = min(LCH, T - c0), ntc = ((len + 31) >> 5) << 1;
+        __syncthreads();
+        load_image(qimg, qbase + (long)c0 * ld, ld, len, ntc * 16);
+        load_image(doimg, a.dout + (row0 + c0) * D + hh * HD, D, len, ntc * 16);
+        for (int t = threadIdx.x; t < ntc * 16; t += blockDim.x) {
+            const long idx = (long)hh * a.Mtot + row0 + c0 + t;
+            lse_s[t] = t < len ? a.lse[idx] : INFINITY;
+            dl_s[t] = t < len ? a.delta[idx] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int u2 = 0; u2 < ntc / 2; ++u2) {
+            uint2 pk[2], dsk[2];
+            short8_t fq[2][2], fd[2][2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    fq[half][s] = frag_k(qimg, (2 * u2 + half) * 16, s, lane);
+                    fd[half][s] = frag_k(doimg, (2 * u2 + half) * 16, s, lane);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int u = 2 * u2 + half;
+                float4_t s_ = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    s_ = mfma16<F16>(fq[half][s], kf[s], s_);
+                    dp = mfma16<F16>(fd[half][s], vf[s], dp);
+                }
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * u + 4 * lg);
+                const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 16 * u + 4 * lg);
+                const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq[4] = {d4.x, d4.y, d4.z, d4.w};
+                float pv[4], dsv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pp = __builtin_amdgcn_exp2f(kok ? s_[r] * sc - lq[r] : -INFINITY);
+                    pv[r] = pp;
+                    dsv[r] = pp * (dp[r] - dq[r]) * a.scale;
+                }
+                pk[half] = pack4<F16>(pv[0], pv[1], pv[2], pv[3]);
+                dsk[half] = pack4<F16>(dsv[0], dsv[1], dsv[2], dsv[3]);
+            }
+            const short8_t pf = join(pk[0], pk[1]), df = join(dsk[0], dsk[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = mfma16<F16>(frag_t(doimg, u2, dt, lane), pf, dv[dt]);
+                dk[dt] = mfma16<F16>(frag_t(qimg, u2, dt, lane), df, dk[dt]);
+            }
+        }
+    }
+    if (kok) {
+        bf16_t* krow = a.dqkv + (row0 + key) * ld + D + hh * HD + 4 * lg;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            *reinterpret_cast<uint2*>(krow + dt * 16) = pack4<F16>(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
+            *reinterpret_cast<uint2*>(krow + D + dt * 16) = pack4<F16>(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
         }
     }
 }
@@ -509,7 +735,7 @@ int set_lds(K kern, size_t bytes)
 inline int pick_nt(int T) { return T <= 160 ? 10 : (T <= 224 ? 14 : (T <= 416 ? 26 : (T <= 608 ? 38 : 0))); }
 inline int pick_threads(int T) { const int tiles = (T + 15) / 16; return (tiles % 3 == 0) ? 192 : 256; }
 
-template <int NT>
+template <int NT, bool F16>
 int launch_all(const AttnArgs& a, int B, int mode, hipStream_t stream)
 {
     const int threads = pick_threads(a.T);
@@ -519,21 +745,21 @@ int launch_all(const AttnArgs& a, int B, int mode, hipStream_t stream)
     if (mode == 0) {
         const bool full = !a.cu && (((a.T + 31) >> 5) << 1) >= NT && NT <= 14;
         if (full) {
-            auto k = attn_q_pass_kernel<NT, false, true>;
+            auto k = attn_q_pass_kernel<NT, false, true, F16>;
             if ((rc = set_lds(k, img))) return rc;
             hipLaunchKernelGGL(k, grid, dim3(threads), img, stream, a);
         } else {
-            auto k = attn_q_pass_kernel<NT, false>;
+            auto k = attn_q_pass_kernel<NT, false, false, F16>;
             if ((rc = set_lds(k, img))) return rc;
             hipLaunchKernelGGL(k, grid, dim3(threads), img, stream, a);
         }
         EDITOR_LAUNCH_CHECK();
     } else {
-        auto k1 = attn_q_pass_kernel<NT, true>;
+        auto k1 = attn_q_pass_kernel<NT, true, false, F16>;
         if ((rc = set_lds(k1, img))) return rc;
         hipLaunchKernelGGL(k1, grid, dim3(threads), img, stream, a);
         EDITOR_LAUNCH_CHECK();
-        auto k2 = attn_kv_pass_kernel<NT>;
+        auto k2 = attn_kv_pass_kernel<NT, F16>;
         const size_t lds2 = img + (size_t)2 * NT * 16 * sizeof(float);
         if ((rc = set_lds(k2, lds2))) return rc;
         hipLaunchKernelGGL(k2, grid, dim3(threads), lds2, stream, a);
@@ -542,15 +768,88 @@ int launch_all(const AttnArgs& a, int B, int mode, hipStream_t stream)
     return 0;
 }
 
+template <bool F16>
+int launch_long(const AttnArgs& a, int B, int mode, hipStream_t stream)
+{
+    if (a.mask || a.probs) return (int)hipErrorInvalidValue;       // long form: dense unmasked or packed live tokens
+    const dim3 grid(B * a.heads, (a.T + 63) / 64);
+    const size_t img = (size_t)2 * LCH * ROWB;
+    int rc;
+    if (mode == 0) {
+        auto k = attn_q_long_kernel<false, F16>;
+        if ((rc = set_lds(k, img))) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(256), img, stream, a);
+        EDITOR_LAUNCH_CHECK();
+    } else {
+        auto k1 = attn_q_long_kernel<true, F16>;
+        if ((rc = set_lds(k1, img))) return rc;
+        hipLaunchKernelGGL(k1, grid, dim3(256), img, stream, a);
+        EDITOR_LAUNCH_CHECK();
+        auto k2 = attn_kv_long_kernel<F16>;
+        const size_t lds2 = img + (size_t)2 * LCH * sizeof(float);
+        if ((rc = set_lds(k2, lds2))) return rc;
+        hipLaunchKernelGGL(k2, grid, dim3(256), lds2, stream, a);
+        EDITOR_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+template <bool F16>
 int dispatch(const AttnArgs& a, int B, int mode, hipStream_t stream)
 {
     switch (pick_nt(a.T)) {
-        case 10: return launch_all<10>(a, B, mode, stream);
-        case 14: return launch_all<14>(a, B, mode, stream);
-        case 26: return launch_all<26>(a, B, mode, stream);
-        case 38: return launch_all<38>(a, B, mode, stream);      // 3 x 193 tokens: joint HMA block of the 384x128 configs
-        default: return (int)hipErrorInvalidValue;
+        case 10: return launch_all<10, F16>(a, B, mode, stream);
+        case 14: return launch_all<14, F16>(a, B, mode, stream);
+        case 26: return launch_all<26, F16>(a, B, mode, stream);
+        case 38: return launch_all<38, F16>(a, B, mode, stream);      // 3 x 193 tokens: joint HMA block of the 384x128 configs
+        default: return launch_long<F16>(a, B, mode, stream);         // > 608 tokens: chunked form
     }
+}
+
+template <bool F16>
+int attention_fwd_h16(const uint16_t* qkv, int B, int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* out,
+                      float* probs, int ldp, float* lse, const int* cu, long Mtot, hipStream_t stream)
+{
+    if (hd != HD || T < 1 || B < 1) return (int)hipErrorInvalidValue;
+    if (probs && (ldp < T || (ldp & 3) || (reinterpret_cast<uintptr_t>(probs) & 15) || cu)) return (int)hipErrorInvalidValue;
+    if (cu && mask) return (int)hipErrorInvalidValue;             // packed sequences hold only live tokens
+    if (!cu) Mtot = (long)B * T;
+    AttnArgs a{qkv, nullptr, nullptr, out, nullptr, probs, lse, nullptr, mask, T, heads, scale, ldp, cu, Mtot};
+    return dispatch<F16>(a, B, 0, stream);
+}
+
+template <bool F16>
+int attention_bwd_h16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, int B, int T, int heads,
+                      int hd, float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace, const int* cu, long Mtot,
+                      hipStream_t stream)
+{
+    if (hd != HD || T < 1 || B < 1 || !workspace || !lse || (cu && mask)) return (int)hipErrorInvalidValue;
+    if (!cu) Mtot = (long)B * T;
+    AttnArgs a{qkv, dout, out, nullptr, dqkv, nullptr, const_cast<float*>(lse), workspace, mask, T, heads, scale, 0, cu, Mtot};
+    return dispatch<F16>(a, B, 1, stream);
+}
+
+template <bool F16>
+int rollout_step_h16(const uint16_t* qkv, const float* lse, const float* r_in, int B, int T, int heads, int hd, float scale,
+                     float* r_out, int final_step, hipStream_t stream)
+{
+    if (hd != HD || T < 2 || B < 1 || !qkv || !lse || !r_out) return (int)hipErrorInvalidValue;
+    const int threads = pick_threads(T);
+    const dim3 grid(B * heads);
+    const long Mtot = (long)B * T;
+#define ROLL_CASE(NTV) case NTV: {                                                                                   \
+        auto k = attn_rollout_step_kernel<NTV, F16>;                                                                     \
+        const size_t lds = (size_t)NTV * 16 * ROWB + (size_t)2 * NTV * 16 * sizeof(float);                              \
+        int rc = set_lds(k, lds); if (rc) return rc;                                                                     \
+        hipLaunchKernelGGL(k, grid, dim3(threads), lds, stream, qkv, lse, r_in, T, heads, scale, Mtot, r_out, final_step); \
+        break; }
+    switch (pick_nt(T)) {
+        ROLL_CASE(10) ROLL_CASE(14) ROLL_CASE(26) ROLL_CASE(38)
+        default: return (int)hipErrorInvalidValue;                     // the backbone's sequences are <= 608 tokens
+    }
+#undef ROLL_CASE
+    EDITOR_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace
@@ -559,42 +858,35 @@ extern "C" int editor_attention_fwd_bf16(const uint16_t* qkv, int B, int T, int 
                                          const uint8_t* mask, uint16_t* out, float* probs, int ldp, float* lse,
                                          const int* cu, long Mtot, hipStream_t stream)
 {
-    if (hd != HD || T < 1 || B < 1) return (int)hipErrorInvalidValue;
-    if (probs && (ldp < T || (ldp & 3) || (reinterpret_cast<uintptr_t>(probs) & 15) || cu)) return (int)hipErrorInvalidValue;
-    if (cu && mask) return (int)hipErrorInvalidValue;             // packed sequences hold only live tokens
-    if (!cu) Mtot = (long)B * T;
-    AttnArgs a{qkv, nullptr, nullptr, out, nullptr, probs, lse, nullptr, mask, T, heads, scale, ldp, cu, Mtot};
-    return dispatch(a, B, 0, stream);
+    return attention_fwd_h16<false>(qkv, B, T, heads, hd, scale, mask, out, probs, ldp, lse, cu, Mtot, stream);
+}
+extern "C" int editor_attention_fwd_f16(const uint16_t* qkv, int B, int T, int heads, int hd, float scale,
+                                        const uint8_t* mask, uint16_t* out, float* probs, int ldp, float* lse,
+                                        const int* cu, long Mtot, hipStream_t stream)
+{
+    return attention_fwd_h16<true>(qkv, B, T, heads, hd, scale, mask, out, probs, ldp, lse, cu, Mtot, stream);
 }
 
 extern "C" int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse,
     int B, int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace, const int* cu,
     long Mtot, hipStream_t stream)
 {
-    if (hd != HD || T < 1 || B < 1 || !workspace || !lse || (cu && mask)) return (int)hipErrorInvalidValue;
-    if (!cu) Mtot = (long)B * T;
-    AttnArgs a{qkv, dout, out, nullptr, dqkv, nullptr, const_cast<float*>(lse), workspace, mask, T, heads, scale, 0, cu, Mtot};
-    return dispatch(a, B, 1, stream);
+    return attention_bwd_h16<false>(qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, stream);
+}
+extern "C" int editor_attention_bwd_f16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse,
+    int B, int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace, const int* cu,
+    long Mtot, hipStream_t stream)
+{
+    return attention_bwd_h16<true>(qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, stream);
 }
 
 extern "C" int editor_attn_rollout_step_bf16(const uint16_t* qkv, const float* lse, const float* r_in, int B, int T, int heads,
                                              int hd, float scale, float* r_out, int final_step, hipStream_t stream)
 {
-    if (hd != HD || T < 2 || B < 1 || !qkv || !lse || !r_out) return (int)hipErrorInvalidValue;
-    const int threads = pick_threads(T);
-    const dim3 grid(B * heads);
-    const long Mtot = (long)B * T;
-#define ROLL_CASE(NTV) case NTV: {                                                                                   \
-        auto k = attn_rollout_step_kernel<NTV>;                                                                          \
-        const size_t lds = (size_t)NTV * 16 * ROWB + (size_t)2 * NTV * 16 * sizeof(float);                              \
-        int rc = set_lds(k, lds); if (rc) return rc;                                                                     \
-        hipLaunchKernelGGL(k, grid, dim3(threads), lds, stream, qkv, lse, r_in, T, heads, scale, Mtot, r_out, final_step); \
-        break; }
-    switch (pick_nt(T)) {
-        ROLL_CASE(10) ROLL_CASE(14) ROLL_CASE(26) ROLL_CASE(38)
-        default: return (int)hipErrorInvalidValue;
-    }
-#undef ROLL_CASE
-    EDITOR_LAUNCH_CHECK();
-    return 0;
+    return rollout_step_h16<false>(qkv, lse, r_in, B, T, heads, hd, scale, r_out, final_step, stream);
+}
+extern "C" int editor_attn_rollout_step_f16(const uint16_t* qkv, const float* lse, const float* r_in, int B, int T, int heads,
+                                            int hd, float scale, float* r_out, int final_step, hipStream_t stream)
+{
+    return rollout_step_h16<true>(qkv, lse, r_in, B, T, heads, hd, scale, r_out, final_step, stream);
 }

@@ -11,6 +11,7 @@ namespace {
 
 // One wave per (b, h, q) row of S [B,h,T,T].  mask (B,T) uint8 or NULL:
 //   s = (mask[b,q] && mask[b,key]) ? s : -65504 ; p = softmax(s) * mask[b,q]      (vit_pytorch.py:250-253)
+template <int NI>            // 64*NI >= T keys per row, NI values per lane in registers
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S, long rows, int T, int heads,
                                                            const uint8_t* __restrict__ mask)
 {
@@ -22,10 +23,10 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S
     float* s = S + row * T;
     const uint8_t* mk = mask ? mask + b * T : nullptr;
     const bool qkeep = !mk || mk[q];
-    float v[16];
+    float v[NI];
     float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int k = i * 64 + lane;
         if (k < T) {
             float x = s[k];
@@ -37,20 +38,21 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S
     mx = wave_max(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int k = i * 64 + lane;
         if (k < T) { v[i] = expf(v[i] - mx); sum += v[i]; }
     }
     sum = wave_sum(sum);
     const float inv = qkeep ? 1.f / sum : 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int k = i * 64 + lane;
         if (k < T) s[k] = v[i] * inv;
     }
 }
 
 // dS = P * (dP - rowsum(dP * P)), in place on dP
+template <int NI>
 __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dP,
                                                                long rows, int T)
 {
@@ -59,16 +61,16 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
     if (row >= rows) return;
     const float* p = P + row * T;
     float* d = dP + row * T;
-    float pv[16], dv[16];
+    float pv[NI], dv[NI];
     float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int k = i * 64 + lane;
         if (k < T) { pv[i] = p[k]; dv[i] = d[k]; dot += pv[i] * dv[i]; }
     }
     dot = wave_sum(dot);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int k = i * 64 + lane;
         if (k < T) d[k] = pv[i] * (dv[i] - dot);
     }
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
 extern "C" int editor_attention_fwd_f32(const float* qkv, int B, int T, int heads, int hd, float scale,
                                         const uint8_t* mask, float* out, float* probs, hipStream_t stream)
 {
-    if (!probs || T > 1024) return (int)hipErrorInvalidValue;
+    if (!probs || T > 4096) return (int)hipErrorInvalidValue;
     const int D = heads * hd;
     const long TT = (long)T * T;
     // S[b,h] = scale * Q K^T       Q rows at qkv + h*hd, K rows at qkv + D + h*hd, row stride 3D
@@ -88,7 +90,10 @@ extern "C" int editor_attention_fwd_f32(const float* qkv, int B, int T, int head
                              scale, 0.f, nullptr, nullptr, 1, EDITOR_EPI_NONE, nullptr, 0, stream);
     if (rc) return rc;
     const long rows = (long)B * heads * T;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, probs, rows, T, heads, mask);
+    const dim3 sgrid((unsigned)((rows + 3) / 4));
+    if (T <= 1024) hipLaunchKernelGGL(softmax_rows_kernel<16>, sgrid, dim3(256), 0, stream, probs, rows, T, heads, mask);
+    else if (T <= 2304) hipLaunchKernelGGL(softmax_rows_kernel<36>, sgrid, dim3(256), 0, stream, probs, rows, T, heads, mask);
+    else hipLaunchKernelGGL(softmax_rows_kernel<64>, sgrid, dim3(256), 0, stream, probs, rows, T, heads, mask);
     EDITOR_LAUNCH_CHECK();
     // O[b,:,h] = P V               V stored [key][hd] -> transB = 1
     return editor_gemm_f32(probs, qkv + 2 * D, out, T, hd, T, T, 3L * D, D, 0, 1,
@@ -111,7 +116,11 @@ extern "C" int editor_attention_bwd_f32(const float* qkv, const float* dout, con
                          B, (long)T * D, sq, heads * TT, heads, hd, hd, TT, 1.f, 0.f, nullptr, nullptr, 1, EDITOR_EPI_NONE, nullptr, 0, stream);
     if (rc) return rc;
     const long rows = (long)B * heads * T;
-    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, probs, workspace, rows, T);
+    if (T > 4096) return (int)hipErrorInvalidValue;
+    const dim3 sgrid((unsigned)((rows + 3) / 4));
+    if (T <= 1024) hipLaunchKernelGGL(softmax_bwd_rows_kernel<16>, sgrid, dim3(256), 0, stream, probs, workspace, rows, T);
+    else if (T <= 2304) hipLaunchKernelGGL(softmax_bwd_rows_kernel<36>, sgrid, dim3(256), 0, stream, probs, workspace, rows, T);
+    else hipLaunchKernelGGL(softmax_bwd_rows_kernel<64>, sgrid, dim3(256), 0, stream, probs, workspace, rows, T);
     EDITOR_LAUNCH_CHECK();
     // dQ = scale * dS K     (K stored [key][hd] = [K][N] -> transB = 1)
     rc = editor_gemm_f32(workspace, qkv + D, dqkv, T, hd, T, T, 3L * D, 3L * D, 0, 1,

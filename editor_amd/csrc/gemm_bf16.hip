@@ -25,7 +25,20 @@ typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((ext_vector_type(8))) short short8_t;
 typedef __attribute__((ext_vector_type(4))) float float4_t;
 
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+
 namespace {
+
+// F16 = false: bfloat16 operands (v_mfma_f32_16x16x32_bf16); true: IEEE half (v_mfma_f32_16x16x32_f16, same rate, 3 more
+// mantissa bits - the reference's own autocast dtype, engine/processor.py:79).  Fragments travel as raw 16-bit lanes.
+template <bool F16>
+__device__ __forceinline__ float4_t mfma16(short8_t a, short8_t b, float4_t c)
+{
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;          // 16 KiB per operand tile per stage
@@ -44,6 +57,7 @@ struct GemmB16Args {
     int pp_staged;                           // 256x256 kernel: LDS-staged epilogue (full-line stores) instead of the direct one
     float* colsum;                           // EDITOR_EPI_COLSUM: [tiles_m][N] column sums of the rounded output tile rows
     unsigned long long* trace;               // debug (EDITOR_GEMM_TRACE): per-workgroup s_memtime stamps
+    int force_pp;                            // EDITOR_EPI_FORCE_PP: the 256x256 kernel whatever the heuristic says
 };
 
 // exact-erf GELU (nn.GELU default) for bf16 outputs, two values per instruction (v_pk_fma_f32 / v_pk_mul_f32):
@@ -67,7 +81,6 @@ __device__ __forceinline__ v2f_t phi2(v2f_t a)
     r.x = a.x > 0.f ? 1.f - h.x : h.x; r.y = a.y > 0.f ? 1.f - h.y : h.y;
     return r;
 }
-__device__ __forceinline__ v2f_t unpack_bf16x2(uint32_t w) { return v2f_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
 __device__ __forceinline__ v2f_t gelu2(v2f_t a) { return a * phi2(a); }
 // d/da gelu = Phi(a) + a phi(a), phi(a) = exp(-a^2/2)/sqrt(2 pi)
 __device__ __forceinline__ v2f_t gelu_grad2(v2f_t a)
@@ -177,7 +190,7 @@ __device__ __forceinline__ short8_t load_frag(const char* lds, int base16, int s
     }
 }
 
-template <bool C_F32, int MT>
+template <bool F16, bool C_F32, int MT>
 __device__ __forceinline__ void epilogue_store(const GemmB16Args& g, float4_t (&acc)[MT][4], int mbase, int nbase, int lane,
                                                bool first_split)
 {
@@ -203,13 +216,13 @@ __device__ __forceinline__ void epilogue_store(const GemmB16Args& g, float4_t (&
                 const float4 o = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + (long)m * g.ldaux + n);
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             } else if (g.epilogue == EDITOR_EPI_GELU) {       // aux = v (pre-activation, bf16), C = gelu(v)
-                uint2 pre; pre.x = pack_bf16x2(v.x, v.y); pre.y = pack_bf16x2(v.z, v.w);
+                uint2 pre; pre.x = H16<F16>::pack2(v.x, v.y); pre.y = H16<F16>::pack2(v.z, v.w);
                 *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = pre;
-                const v2f_t g0 = gelu2(unpack_bf16x2(pre.x)), g1 = gelu2(unpack_bf16x2(pre.y));
+                const v2f_t g0 = gelu2(H16<F16>::unpack2(pre.x)), g1 = gelu2(H16<F16>::unpack2(pre.y));
                 v.x = g0.x; v.y = g0.y; v.z = g1.x; v.w = g1.y;
             } else if (g.epilogue == EDITOR_EPI_GELU_BWD) {   // C = v * gelu'(aux), aux = saved pre-activation
                 const uint2 pre = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ldaux + n);
-                const v2f_t g0 = gelu_grad2(unpack_bf16x2(pre.x)), g1 = gelu_grad2(unpack_bf16x2(pre.y));
+                const v2f_t g0 = gelu_grad2(H16<F16>::unpack2(pre.x)), g1 = gelu_grad2(H16<F16>::unpack2(pre.y));
                 v.x *= g0.x; v.y *= g0.y; v.z *= g1.x; v.w *= g1.y;
             }
             if (C_F32) {
@@ -227,17 +240,17 @@ __device__ __forceinline__ void epilogue_store(const GemmB16Args& g, float4_t (&
                 bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n;
                 if (g.beta != 0.f) {
                     const uint2 o = *reinterpret_cast<const uint2*>(c);
-                    v.x += g.beta * __uint_as_float(o.x << 16); v.y += g.beta * __uint_as_float(o.x & 0xffff0000u);
-                    v.z += g.beta * __uint_as_float(o.y << 16); v.w += g.beta * __uint_as_float(o.y & 0xffff0000u);
+                    const v2f_t o0 = H16<F16>::unpack2(o.x), o1 = H16<F16>::unpack2(o.y);
+                    v.x += g.beta * o0.x; v.y += g.beta * o0.y; v.z += g.beta * o1.x; v.w += g.beta * o1.y;
                 }
-                uint2 o; o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
+                uint2 o; o.x = H16<F16>::pack2(v.x, v.y); o.y = H16<F16>::pack2(v.z, v.w);
                 *reinterpret_cast<uint2*>(c) = o;
             }
         }
     }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool C_F32, bool GLDS>
+template <bool F16, bool A_KMAJOR, bool B_KMAJOR, bool C_F32, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB16Args g)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile | B tile]
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB16Args g)
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)   // operands swapped: D^T tile, lane owns 4 consecutive n
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<F16>(fb[j], fa[i], acc[i][j]);
         }
         if (more && !GLDS) {
             char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
@@ -310,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB16Args g)
         }
         __syncthreads();                               // (GLDS: also drains the in-flight LDS-DMA, vmcnt(0))
     }
-    epilogue_store<C_F32, 4>(g, acc, m0 + wm, n0 + wn, lane, blockIdx.y == 0);
+    epilogue_store<F16, C_F32, 4>(g, acc, m0 + wm, n0 + wn, lane, blockIdx.y == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -327,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB16Args g)
 // the 16 lanes of a tile row covering 256 / 512 contiguous bytes.  Keeping the math in a rolled loop matters: the fully
 // unrolled per-fragment epilogue is ~10k straight-line instructions executed once per tile, i.e. always instruction-cache
 // cold (measured: ~5.5 us per tile even with the global stores removed).
-template <bool C_F32, int EPI, int PBM, int PBN, int NTHREADS>
+template <bool F16, bool C_F32, int EPI, int PBM, int PBN, int NTHREADS>
 __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const char* lds, int m0, int n0, int split)
 {
     constexpr int RBP = PBN * 4 + 16;
@@ -385,12 +398,12 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
                 x[0] += r0.x; x[1] += r0.y; x[2] += r0.z; x[3] += r0.w; x[4] += r1.x; x[5] += r1.y; x[6] += r1.z; x[7] += r1.w;
             } else if (EPI == EDITOR_EPI_GELU) {                 // aux <- pre-activation (bf16), C <- gelu(rounded pre-activation)
                 uint4 p;
-                p.x = pack_bf16x2(x[0], x[1]); p.y = pack_bf16x2(x[2], x[3]); p.z = pack_bf16x2(x[4], x[5]); p.w = pack_bf16x2(x[6], x[7]);
+                p.x = H16<F16>::pack2(x[0], x[1]); p.y = H16<F16>::pack2(x[2], x[3]); p.z = H16<F16>::pack2(x[4], x[5]); p.w = H16<F16>::pack2(x[6], x[7]);
                 *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = p;
                 const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const v2f_t gv = gelu2(unpack_bf16x2(pw[e]));
+                    const v2f_t gv = gelu2(H16<F16>::unpack2(pw[e]));
                     x[2 * e] = gv.x; x[2 * e + 1] = gv.y;
                 }
             } else if (EPI == EDITOR_EPI_GELU_BWD) {
@@ -398,7 +411,7 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
                 const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const v2f_t gv = gelu_grad2(unpack_bf16x2(pw[e]));
+                    const v2f_t gv = gelu_grad2(H16<F16>::unpack2(pw[e]));
                     x[2 * e] *= gv.x; x[2 * e + 1] *= gv.y;
                 }
             }
@@ -408,14 +421,14 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
                 *reinterpret_cast<float4*>(o + 4) = make_float4(x[4], x[5], x[6], x[7]);
             } else {
                 uint4 o;
-                o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]); o.z = pack_bf16x2(x[4], x[5]); o.w = pack_bf16x2(x[6], x[7]);
+                o.x = H16<F16>::pack2(x[0], x[1]); o.y = H16<F16>::pack2(x[2], x[3]); o.z = H16<F16>::pack2(x[4], x[5]); o.w = H16<F16>::pack2(x[6], x[7]);
                 *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = o;
             }
         }
     }
 }
 
-template <bool C_F32, int MT, int PBM, int PBN, int NTHREADS>
+template <bool F16, bool C_F32, int MT, int PBM, int PBN, int NTHREADS>
 __device__ __forceinline__ void epilogue_staged(const GemmB16Args& g, float4_t (&acc)[MT][4], char* lds, int m0, int n0,
                                                 int wm, int wn, int lane, int split)
 {
@@ -429,10 +442,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmB16Args& g, float4_t (
             *reinterpret_cast<float4_t*>(lds + (wm + i * 16 + li) * RBP + (wn + j * 16 + lg * 4) * 4) = acc[i][j];
     __syncthreads();
     switch (g.epilogue) {
-        case EDITOR_EPI_RESIDUAL: epilogue_copy_out<C_F32, EDITOR_EPI_RESIDUAL, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
-        case EDITOR_EPI_GELU:     epilogue_copy_out<C_F32, EDITOR_EPI_GELU, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
-        case EDITOR_EPI_GELU_BWD: epilogue_copy_out<C_F32, EDITOR_EPI_GELU_BWD, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
-        default:                  epilogue_copy_out<C_F32, EDITOR_EPI_NONE, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
+        case EDITOR_EPI_RESIDUAL: epilogue_copy_out<F16, C_F32, EDITOR_EPI_RESIDUAL, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
+        case EDITOR_EPI_GELU:     epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
+        case EDITOR_EPI_GELU_BWD: epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU_BWD, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
+        default:                  epilogue_copy_out<F16, C_F32, EDITOR_EPI_NONE, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
     }
 }
 
@@ -493,7 +506,7 @@ __device__ __forceinline__ short8_t pload_frag(const char* lds, int base16, int 
     }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool C_F32, int PBM, int PBN, int STAGES, int NWAVES>
+template <bool F16, bool A_KMAJOR, bool B_KMAJOR, bool C_F32, int PBM, int PBN, int STAGES, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64, 2) void gemm_bf16_pipe_kernel(GemmB16Args g)
 {
     constexpr int PA_BYTES = PBM * BK * 2, PB_BYTES = PBN * BK * 2, PSTAGE = PA_BYTES + PB_BYTES;
@@ -598,7 +611,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void gemm_bf16_pipe_kernel(GemmB16A
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma16<F16>(fb[j], fa[i], acc[i][j]);
     };
     // one LDS-DMA piece of tile t (j < A_PIECES: A, else B), used to spread the DMA issue slots between MFMAs
     auto issue_piece = [&](int t, int j) {
@@ -616,7 +629,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void gemm_bf16_pipe_kernel(GemmB16A
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma16<F16>(fb[j], fa[i], acc[i][j]);
                 if ((n & 1) == 1 && (n >> 1) < PIECES) {
                     __builtin_amdgcn_sched_barrier(0);
                     issue_piece(t_issue, n >> 1);
@@ -673,9 +686,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void gemm_bf16_pipe_kernel(GemmB16A
     // wgrad (split-K slabs) with the LDS-staged one (252 vs 262 us; 170 vs 247 us).
     constexpr bool kStaged = PBM * (PBN * 4 + 16) <= STAGES * PSTAGE && !(A_KMAJOR && B_KMAJOR);
     if (kStaged && g.beta == 0.f && (g.splitk == 1 || g.slabs) && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (g.ldaux & 7) == 0)
-        epilogue_staged<C_F32, MT, PBM, PBN, NWAVES * 64>(g, acc, smem, m0, n0, wm, wn, lane, blockIdx.y);
+        epilogue_staged<F16, C_F32, MT, PBM, PBN, NWAVES * 64>(g, acc, smem, m0, n0, wm, wn, lane, blockIdx.y);
     else
-        epilogue_store<C_F32, MT>(g, acc, m0 + wm, n0 + wn, lane, blockIdx.y == 0);
+        epilogue_store<F16, C_F32, MT>(g, acc, m0 + wm, n0 + wn, lane, blockIdx.y == 0);
 }
 
 // =====================================================================================================
@@ -741,7 +754,7 @@ __device__ __forceinline__ void pp_unit_offsets(long ld, int r0, int R, int sub,
     }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool C_F32>
+template <bool F16, bool A_KMAJOR, bool B_KMAJOR, bool C_F32>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
 {
     constexpr int UNIT = 16384, KTB = 4 * UNIT;                 // per K-tile buffer: A0 | A1 | B0 | B1
@@ -844,7 +857,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[mi * 4 + i][nj * 2 + j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbv[j][s], fa[i][s], acc[mi * 4 + i][nj * 2 + j], 0, 0, 0);
+                        mfma16<F16>(fbv[j][s], fa[i][s], acc[mi * 4 + i][nj * 2 + j]);
     };
     auto dma2 = [&](const char* src, const uint32_t (&vo)[2], char* unit) {
 #pragma unroll
@@ -966,10 +979,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int nl = wc * 64 + j * 16 + lg * 4;
-                    const v2f_t g0 = gelu_grad2(unpack_bf16x2(pre[i][j].x)), g1 = gelu_grad2(unpack_bf16x2(pre[i][j].y));
+                    const v2f_t g0 = gelu_grad2(H16<F16>::unpack2(pre[i][j].x)), g1 = gelu_grad2(H16<F16>::unpack2(pre[i][j].y));
                     uint2 o;
-                    o.x = pack_bf16x2((acc[i][j][0] * g.alpha + bv[j].x) * rs * g0.x, (acc[i][j][1] * g.alpha + bv[j].y) * rs * g0.y);
-                    o.y = pack_bf16x2((acc[i][j][2] * g.alpha + bv[j].z) * rs * g1.x, (acc[i][j][3] * g.alpha + bv[j].w) * rs * g1.y);
+                    o.x = H16<F16>::pack2((acc[i][j][0] * g.alpha + bv[j].x) * rs * g0.x, (acc[i][j][1] * g.alpha + bv[j].y) * rs * g0.y);
+                    o.y = H16<F16>::pack2((acc[i][j][2] * g.alpha + bv[j].z) * rs * g1.x, (acc[i][j][3] * g.alpha + bv[j].w) * rs * g1.y);
                     *reinterpret_cast<uint2*>(smem + ml * RB + nl * 2) = o;
                 }
             }
@@ -982,8 +995,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
                 for (int j = 0; j < 4; ++j) {
                     const int nl = wc * 64 + j * 16 + lg * 4;
                     uint2 o;
-                    o.x = pack_bf16x2((acc[i][j][0] * g.alpha + bv[j].x) * rs, (acc[i][j][1] * g.alpha + bv[j].y) * rs);
-                    o.y = pack_bf16x2((acc[i][j][2] * g.alpha + bv[j].z) * rs, (acc[i][j][3] * g.alpha + bv[j].w) * rs);
+                    o.x = H16<F16>::pack2((acc[i][j][0] * g.alpha + bv[j].x) * rs, (acc[i][j][1] * g.alpha + bv[j].y) * rs);
+                    o.y = H16<F16>::pack2((acc[i][j][2] * g.alpha + bv[j].z) * rs, (acc[i][j][3] * g.alpha + bv[j].w) * rs);
                     *reinterpret_cast<uint2*>(smem + ml * RB + nl * 2) = o;
                 }
             }
@@ -1006,13 +1019,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
                 uint32_t pw[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                { const v2f_t gv = gelu2(unpack_bf16x2(pw[e])); pw[e] = pack_bf16x2(gv.x, gv.y); }
+                { const v2f_t gv = gelu2(H16<F16>::unpack2(pw[e])); pw[e] = H16<F16>::pack2(gv.x, gv.y); }
                 p = make_uint4(pw[0], pw[1], pw[2], pw[3]);
             }
             if (g.colsum) {
                 const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const v2f_t u = unpack_bf16x2(pw[e]); cs[2 * e] += u.x; cs[2 * e + 1] += u.y; }
+                for (int e = 0; e < 4; ++e) { const v2f_t u = H16<F16>::unpack2(pw[e]); cs[2 * e] += u.x; cs[2 * e + 1] += u.y; }
             }
             *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = p;
         }
@@ -1046,15 +1059,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
             PP_BAR();
             const int mp = m0 + pass * 128;
             switch (g.epilogue) {
-                case EDITOR_EPI_RESIDUAL: epilogue_copy_out<C_F32, EDITOR_EPI_RESIDUAL, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
-                case EDITOR_EPI_GELU:     epilogue_copy_out<C_F32, EDITOR_EPI_GELU, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
-                case EDITOR_EPI_GELU_BWD: epilogue_copy_out<C_F32, EDITOR_EPI_GELU_BWD, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
-                default:                  epilogue_copy_out<C_F32, EDITOR_EPI_NONE, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
+                case EDITOR_EPI_RESIDUAL: epilogue_copy_out<F16, C_F32, EDITOR_EPI_RESIDUAL, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
+                case EDITOR_EPI_GELU:     epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
+                case EDITOR_EPI_GELU_BWD: epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU_BWD, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
+                default:                  epilogue_copy_out<F16, C_F32, EDITOR_EPI_NONE, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
             }
             PP_STAMP(3 + pass);
         }
     } else {
-        epilogue_store<C_F32, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, blockIdx.y == 0);
+        epilogue_store<F16, C_F32, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, blockIdx.y == 0);
     }
     if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(5); }
 #undef PP_STAMP
@@ -1069,10 +1082,10 @@ __global__ void scale_c_kernel(float* C, long rows, int cols, long ld, float bet
     *c = beta == 0.f ? 0.f : *c * beta;
 }
 
-template <bool AK, bool BK_, bool CF, bool GL>
+template <bool F16, bool AK, bool BK_, bool CF, bool GL>
 int launch(const GemmB16Args& g, hipStream_t stream)
 {
-    auto kern = gemm_bf16_kernel<AK, BK_, CF, GL>;
+    auto kern = gemm_bf16_kernel<F16, AK, BK_, CF, GL>;
     static bool attr_done = false;                       // per-instantiation; idempotent
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
@@ -1101,11 +1114,11 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, 
     }
 }
 
-template <bool AK, bool BK_, bool CF, int PBM, int PBN, int STAGES, int NWAVES>
+template <bool F16, bool AK, bool BK_, bool CF, int PBM, int PBN, int STAGES, int NWAVES>
 int launch_pipe_t(GemmB16Args g, hipStream_t stream)
 {
     constexpr int LDS = STAGES * (PBM + PBN) * BK * 2;
-    auto kern = gemm_bf16_pipe_kernel<AK, BK_, CF, PBM, PBN, STAGES, NWAVES>;
+    auto kern = gemm_bf16_pipe_kernel<F16, AK, BK_, CF, PBM, PBN, STAGES, NWAVES>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1119,11 +1132,11 @@ int launch_pipe_t(GemmB16Args g, hipStream_t stream)
     return 0;
 }
 
-template <bool AK, bool BK_, bool CF>
+template <bool F16, bool AK, bool BK_, bool CF>
 int launch_pp(GemmB16Args g, hipStream_t stream)
 {
     constexpr int LDS = 256 * (256 * 2 + 16);                   // >= 2 K-tile buffers, the fp32 half-tile image and the bf16 tile image
-    auto kern = gemm_bf16_pp_kernel<AK, BK_, CF>;
+    auto kern = gemm_bf16_pp_kernel<F16, AK, BK_, CF>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1134,20 +1147,23 @@ int launch_pp(GemmB16Args g, hipStream_t stream)
     g.tiles_n = (g.N + 255) / 256;
     // measured: the LDS-staged epilogue (full-line 16-byte stores) beats the direct one on every layout here
     // (fwd N=2304,K=768: 701 vs 530 TFLOP/s; dgrad 974 vs 905)
-    static const int staged_mode = getenv("EDITOR_GEMM_PP_STAGED") ? atoi(getenv("EDITOR_GEMM_PP_STAGED")) : 1;
-    g.pp_staged = staged_mode;
-    static const bool trace = getenv("EDITOR_GEMM_TRACE") != nullptr;
-    if (trace) {                                                   // debug: per-workgroup phase timeline, printed per launch
+    g.pp_staged = 1;
+#ifdef EDITOR_DEBUG_TRACE
+    // Debug build only (libeditor_debug.so, tools/gemm_bench.py): experiment switches and the per-workgroup phase
+    // timeline.  The product library has no environment lookups, allocations or synchronisation in its entry points.
+    if (const char* e = getenv("EDITOR_GEMM_PP_STAGED")) g.pp_staged = atoi(e);
+    if (getenv("EDITOR_GEMM_TRACE")) {
         const int nwg = g.tiles_m * g.tiles_n * g.splitk;
         static unsigned long long* buf = nullptr;
         if (!buf && hipMalloc(&buf, sizeof(unsigned long long) * 8 * 65536) != hipSuccess) return 1;
         if (nwg <= 65536) {
-            hipMemsetAsync(buf, 0, sizeof(unsigned long long) * 8 * nwg, stream);
+            hipError_t e1 = hipMemsetAsync(buf, 0, sizeof(unsigned long long) * 8 * nwg, stream);
+            if (e1 != hipSuccess) return (int)e1;
             g.trace = buf;
             hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(512), LDS, stream, g);
-            hipStreamSynchronize(stream);
+            if ((e1 = hipStreamSynchronize(stream)) != hipSuccess) return (int)e1;
             static unsigned long long host[8 * 65536];
-            hipMemcpy(host, buf, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost);
+            if ((e1 = hipMemcpy(host, buf, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost)) != hipSuccess) return (int)e1;
             double seg[5] = {0, 0, 0, 0, 0};
             unsigned long long t_min = ~0ull, t_max = 0;
             for (int i = 0; i < nwg; ++i) {
@@ -1162,12 +1178,13 @@ int launch_pp(GemmB16Args g, hipStream_t stream)
             return 0;
         }
     }
+#endif
     hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(512), LDS, stream, g);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }
 
-template <bool AK, bool BK_, bool CF>
+template <bool F16, bool AK, bool BK_, bool CF>
 int launch_pipe(const GemmB16Args& g, hipStream_t stream)
 {
     // 256x256 ping-pong kernel where it measures faster (tools/gemm_bench.py with GEMM_EPI=1, M = 49 536 token rows,
@@ -1175,15 +1192,17 @@ int launch_pipe(const GemmB16Args& g, hipStream_t stream)
     // 702 -> 865, dgrads 777 -> 896, 850 -> 974, 604 -> 624, 649 -> 747, fc2 dgrad+GELU' 460 -> 507.  wgrad (both operands
     // through ds_read_b64_tr_b16, twice the LDS instructions per phase, and few output tiles) is slower (742 vs 792) and
     // stays on 256x128 with split-K slabs.
-    static const int pp_mode = getenv("EDITOR_GEMM_PP") ? atoi(getenv("EDITOR_GEMM_PP")) : -1;   // 1 force, 0 off
+    int pp_mode = g.force_pp ? 1 : -1;                                   // 1 force, 0 off (debug build only)
+#ifdef EDITOR_DEBUG_TRACE
+    if (const char* e = getenv("EDITOR_GEMM_PP")) pp_mode = atoi(e);
+#endif
     const bool pp_auto = g.M >= 2048 && g.splitk == 1 && AK && g.N >= 512;
-    if (g.N >= 256 && (pp_mode == 1 || g.colsum || (pp_mode < 0 && pp_auto))) return launch_pp<AK, BK_, CF>(g, stream);
-    return launch_pipe_t<AK, BK_, CF, 256, 128, 3, 8>(g, stream);
+    if (g.N >= 256 && (pp_mode == 1 || g.colsum || (pp_mode < 0 && pp_auto))) return launch_pp<F16, AK, BK_, CF>(g, stream);
+    return launch_pipe_t<F16, AK, BK_, CF, 256, 128, 3, 8>(g, stream);
 }
 
-}  // namespace
-
-extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda,
+template <bool F16>
+int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda,
     long ldb, long ldc, int transA, int transB, float alpha, float beta, const float* bias, const float* rowscale,
     int splitk, int epilogue, void* aux, long ldaux, float* splitk_ws, const int* m_live, hipStream_t stream)
 {
@@ -1197,7 +1216,8 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15)
         return (int)hipErrorInvalidValue;
     const bool want_colsum = (epilogue & EDITOR_EPI_COLSUM) != 0;
-    epilogue &= ~EDITOR_EPI_COLSUM;
+    const bool force_pp = (epilogue & EDITOR_EPI_FORCE_PP) != 0;
+    epilogue &= ~(EDITOR_EPI_COLSUM | EDITOR_EPI_FORCE_PP);
     if (want_colsum && (c_f32 || epilogue == EDITOR_EPI_RESIDUAL || splitk > 1 || !splitk_ws || transA || M < 2048 || N < 512 ||
                         (N & 7) || (ldc & 7) || (ldaux & 7) || (K % BK) || beta != 0.f || m_live))
         return (int)hipErrorInvalidValue;                        // the column sums exist in the one-pass 256x256 epilogue only
@@ -1221,20 +1241,20 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
     GemmB16Args g{(const bf16_t*)A, (const bf16_t*)B, slabs ? (void*)splitk_ws : C, M, N, K, lda, ldb, ldc, alpha,
                   slabs ? 0.f : beta, bias, rowscale, splitk, (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux,
                   slabs ? 1 : 0,
-                  m_live, transA ? 1 : 0, 0, want_colsum ? splitk_ws : nullptr, nullptr};
+                  m_live, transA ? 1 : 0, 0, want_colsum ? splitk_ws : nullptr, nullptr, force_pp ? 1 : 0};
     if (m_live && (!pipe || (splitk > 1 && !slabs))) return (int)hipErrorInvalidValue;   // live-row form: pipelined path only
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
     int rc;
     if (pipe) {
         switch (sel) {
-            case 7: rc = launch_pipe<true, true, true>(g, stream); break;
-            case 6: rc = launch_pipe<true, true, false>(g, stream); break;
-            case 5: rc = launch_pipe<true, false, true>(g, stream); break;
-            case 4: rc = launch_pipe<true, false, false>(g, stream); break;
-            case 3: rc = launch_pipe<false, true, true>(g, stream); break;
-            case 2: rc = launch_pipe<false, true, false>(g, stream); break;
-            case 1: rc = launch_pipe<false, false, true>(g, stream); break;
-            default: rc = launch_pipe<false, false, false>(g, stream); break;
+            case 7: rc = launch_pipe<F16, true, true, true>(g, stream); break;
+            case 6: rc = launch_pipe<F16, true, true, false>(g, stream); break;
+            case 5: rc = launch_pipe<F16, true, false, true>(g, stream); break;
+            case 4: rc = launch_pipe<F16, true, false, false>(g, stream); break;
+            case 3: rc = launch_pipe<F16, false, true, true>(g, stream); break;
+            case 2: rc = launch_pipe<F16, false, true, false>(g, stream); break;
+            case 1: rc = launch_pipe<F16, false, false, true>(g, stream); break;
+            default: rc = launch_pipe<F16, false, false, false>(g, stream); break;
         }
         if (rc) return rc;
         if (slabs) {
@@ -1247,7 +1267,7 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
         }
         return 0;
     }
-#define GEMM_CASE(n, a, b, c) case n: return glds ? launch<a, b, c, true>(g, stream) : launch<a, b, c, false>(g, stream)
+#define GEMM_CASE(n, a, b, c) case n: return glds ? launch<F16, a, b, c, true>(g, stream) : launch<F16, a, b, c, false>(g, stream)
     switch (sel) {
         GEMM_CASE(7, true, true, true);
         GEMM_CASE(6, true, true, false);
@@ -1256,7 +1276,26 @@ extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, i
         GEMM_CASE(3, false, true, true);
         GEMM_CASE(2, false, true, false);
         GEMM_CASE(1, false, false, true);
-        default: return glds ? launch<false, false, false, true>(g, stream) : launch<false, false, false, false>(g, stream);
+        default: return glds ? launch<F16, false, false, false, true>(g, stream) : launch<F16, false, false, false, false>(g, stream);
     }
 #undef GEMM_CASE
+}
+
+}  // namespace
+
+extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda,
+    long ldb, long ldc, int transA, int transB, float alpha, float beta, const float* bias, const float* rowscale,
+    int splitk, int epilogue, void* aux, long ldaux, float* splitk_ws, const int* m_live, hipStream_t stream)
+{
+    return gemm_h16<false>(A, B, C, c_f32, M, N, K, lda, ldb, ldc, transA, transB, alpha, beta, bias, rowscale, splitk, epilogue,
+                           aux, ldaux, splitk_ws, m_live, stream);
+}
+
+// IEEE-half operands (cfg.MODEL.COMPUTE_DTYPE = 'f16'): same kernels, v_mfma_f32_16x16x32_f16, half outputs
+extern "C" int editor_gemm_f16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda,
+    long ldb, long ldc, int transA, int transB, float alpha, float beta, const float* bias, const float* rowscale,
+    int splitk, int epilogue, void* aux, long ldaux, float* splitk_ws, const int* m_live, hipStream_t stream)
+{
+    return gemm_h16<true>(A, B, C, c_f32, M, N, K, lda, ldb, ldc, transA, transB, alpha, beta, bias, rowscale, splitk, epilogue,
+                          aux, ldaux, splitk_ws, m_live, stream);
 }

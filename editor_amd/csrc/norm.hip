@@ -28,6 +28,18 @@ template <> struct Vec4<bf16_t> {
     }
 };
 
+template <> struct Vec4<f16_t> {
+    static __device__ __forceinline__ float4 ld(const f16_t* p) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        const float2_t_ a = H16<true>::unpack2(u.x), b = H16<true>::unpack2(u.y);
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
+    static __device__ __forceinline__ void st(f16_t* p, float4 v) {
+        uint2 u; u.x = pack_f16x2(v.x, v.y); u.y = pack_f16x2(v.z, v.w);
+        *reinterpret_cast<uint2*>(p) = u;
+    }
+};
+
 constexpr int kMaxV = 4;   // float4 chunks per lane: D <= 64*4*4 = 1024
 
 // ------------------------------------------------------------------------------------------------
@@ -85,7 +97,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ mean_in, const float* __restrict__ rstd_in, long M, int D,
     const uint8_t* __restrict__ rowmask, int mask_period, const float* __restrict__ dx_in, float* __restrict__ dx_out,
-    float* __restrict__ partials, const int* __restrict__ m_live)
+    float* __restrict__ partials, const int* __restrict__ m_live, float dy_scale)
 {
     __shared__ float red[4][2][1024];
     if (m_live) M = min(M, (long)((*m_live + 63) & ~63));
@@ -107,6 +119,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             const int c0 = (i * 64 + lane) * 4;
             const float4 xv = *reinterpret_cast<const float4*>(x + row * D + c0);
             d[i] = keep ? Vec4<T>::ld(dy + row * D + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            d[i].x *= dy_scale; d[i].y *= dy_scale; d[i].z *= dy_scale; d[i].w *= dy_scale;   // (loss-scaled f16 gradients)
             xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
             dg[i].x += d[i].x * xh[i].x; dg[i].y += d[i].y * xh[i].y; dg[i].z += d[i].z * xh[i].z; dg[i].w += d[i].w * xh[i].w;
             db[i].x += d[i].x; db[i].y += d[i].y; db[i].z += d[i].z; db[i].w += d[i].w;
@@ -241,12 +254,12 @@ __global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, lon
 // out[m,:] = in[m,:] * rowscale[m]  (fp32 -> activation dtype): gradient of a drop-path-scaled branch
 template <typename TO>
 __global__ void cast_rows_kernel(const float* __restrict__ in, const float* __restrict__ rowscale, long M, int D,
-                                 TO* __restrict__ out, const int* __restrict__ m_live)
+                                 TO* __restrict__ out, const int* __restrict__ m_live, float scale)
 {
     const int d4 = D >> 2;
     if (m_live) M = min(M, (long)((*m_live + 63) & ~63));
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < M * d4; e += (long)gridDim.x * blockDim.x) {
-        const float r = rowscale ? rowscale[e / d4] : 1.f;
+        const float r = (rowscale ? rowscale[e / d4] : 1.f) * scale;
         float4 v = *reinterpret_cast<const float4*>(in + e * 4);
         v.x *= r; v.y *= r; v.z *= r; v.w *= r;
         Vec4<TO>::st(out + e * 4, v);
@@ -258,9 +271,10 @@ __global__ void cast_rows_kernel(const float* __restrict__ in, const float* __re
 // per-block partial rows -> reduce_rows_kernel (fixed order).  D a multiple of 256, D <= 256 * kMaxV.
 __device__ __forceinline__ float round_like(float v, float) { return v; }
 __device__ __forceinline__ float round_like(float v, bf16_t) { return bf16_to_f32(f32_to_bf16(v)); }
+__device__ __forceinline__ float round_like(float v, f16_t) { return f16_to_f32(f32_to_f16(v)); }
 template <typename TO>
 __global__ __launch_bounds__(256) void cast_rows_colsum_kernel(const float* __restrict__ in, const float* __restrict__ rowscale,
-    long M, int D, TO* __restrict__ out, float* __restrict__ partials)
+    long M, int D, TO* __restrict__ out, float* __restrict__ partials, float scale)
 {
     __shared__ float red[4][256 * kMaxV];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(256) void cast_rows_colsum_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < kMaxV; ++i) cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long row = (long)blockIdx.x * 4 + w; row < M; row += (long)gridDim.x * 4) {
-        const float r = rowscale ? rowscale[row] : 1.f;
+        const float r = (rowscale ? rowscale[row] : 1.f) * scale;
 #pragma unroll
         for (int i = 0; i < kMaxV; ++i) if (i < nv) {
             const int c0 = (i * 64 + lane) * 4;
@@ -339,7 +353,7 @@ __global__ void embed_assemble_kernel(const T* __restrict__ patch, const float* 
 
 // backward of the assembly: dpatch = dx[:,1:,:] (cast), dpos[t] = sum_b dx[b,t], rowsum[b] = sum_t dx[b,t]
 template <typename T>
-__global__ void embed_bwd_patch_kernel(const float* __restrict__ dx, long Btot, int Tn, int D, T* __restrict__ dpatch)
+__global__ void embed_bwd_patch_kernel(const float* __restrict__ dx, long Btot, int Tn, int D, T* __restrict__ dpatch, float scale)
 {
     const int d4 = D >> 2;
     const long total = Btot * (Tn - 1) * d4;
@@ -348,7 +362,9 @@ __global__ void embed_bwd_patch_kernel(const float* __restrict__ dx, long Btot, 
         const long rp = e / d4;
         const long b = rp / (Tn - 1);
         const int p = (int)(rp % (Tn - 1));
-        Vec4<T>::st(dpatch + rp * D + c0, *reinterpret_cast<const float4*>(dx + (b * Tn + p + 1) * D + c0));
+        float4 v = *reinterpret_cast<const float4*>(dx + (b * Tn + p + 1) * D + c0);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        Vec4<T>::st(dpatch + rp * D + c0, v);
     }
 }
 // dpos[t,:] = sum_b dx[b,t,:]   grid (Tn, ceil(D/1024)), 256 thr x float4
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(256) void sfts_apply_kernel(const float* __restrict
         const int tk = (int)(rt % Tn);
         const long b = rt / Tn;
         const bool sel = tk == 0 || index[b * (Tn - 1) + tk - 1];
-        float4 v[3];
+        float4 v[4];
         for (int m = 0; m < nmod; ++m) {
             v[m] = *reinterpret_cast<const float4*>(feat + m * mstride + rt * D + c0);
             *reinterpret_cast<float4*>(out + m * mstride + rt * D + c0) = sel ? v[m] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -455,7 +471,7 @@ __global__ __launch_bounds__(256) void sfts_apply_bwd_kernel(const float* __rest
                 *reinterpret_cast<float4*>(dfeat + m * mstride + rt * D + c0) =
                     *reinterpret_cast<const float4*>(dout + m * mstride + rt * D + c0);
         } else {
-            float4 v[3], s = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v[4], s = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int m = 0; m < nmod; ++m) {
                 v[m] = *reinterpret_cast<const float4*>(feat + m * mstride + rt * D + c0);
                 s.x += v[m].x; s.y += v[m].y; s.z += v[m].z; s.w += v[m].w;
@@ -536,7 +552,9 @@ inline unsigned grid_for(long n, int block = 256, long cap = 256L * 16) {
 
 }  // namespace
 
-#define DISPATCH_T(is_bf16, CALL) do { if (is_bf16) { using TT = bf16_t; CALL; } else { using TT = float; CALL; } } while (0)
+// dtype code: 0 = fp32, 1 = bf16, 2 = f16
+#define DISPATCH_T(dt, CALL) do { if ((dt) == 1) { using TT = bf16_t; CALL; } else if ((dt) == 2) { using TT = f16_t; CALL; } \
+                                  else if ((dt) == 0) { using TT = float; CALL; } else return (int)hipErrorInvalidValue; } while (0)
 
 extern "C" int editor_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, long M, int D,
     const uint8_t* rowmask, int mask_period, void* y, int y_bf16, float* mean, float* rstd, const int* m_live,
@@ -549,7 +567,7 @@ extern "C" int editor_layernorm_fwd(const float* x, const float* gamma, const fl
     return 0;
 }
 
-extern "C" int editor_layernorm_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
+extern "C" int editor_layernorm_bwd(const void* dy, int dy_bf16, float dy_scale, const float* x, const float* gamma, const float* mean,
     const float* rstd, long M, int D, const uint8_t* rowmask, int mask_period, const float* dx_in, float* dx_out,
     float* dgamma, float* dbeta, float* workspace, int ws_rows, const int* m_live, hipStream_t stream)
 {
@@ -557,7 +575,7 @@ extern "C" int editor_layernorm_bwd(const void* dy, int dy_bf16, const float* x,
     long blocks = (M + 3) / 4;
     if (blocks > ws_rows) blocks = ws_rows;
     DISPATCH_T(dy_bf16, hipLaunchKernelGGL(layernorm_bwd_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, stream,
-               (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out, dgamma ? workspace : nullptr, m_live));
+               (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out, dgamma ? workspace : nullptr, m_live, dy_scale));
     EDITOR_LAUNCH_CHECK();
     if (dgamma) {
         // workspace rows are [block][2][D] = P rows of 2D columns; dgamma and dbeta must be ONE (2,D) buffer
@@ -571,7 +589,7 @@ extern "C" int editor_layernorm_bwd(const void* dy, int dy_bf16, const float* x,
 }
 
 extern "C" int editor_colsum(const void* dy, int dy_bf16, long M, int N, long ld, float* out, float* workspace,
-                             int ws_rows, hipStream_t stream)
+                             int ws_rows, float scale, hipStream_t stream)
 {
     if (N % 4 || ws_rows < 1) return (int)hipErrorInvalidValue;
     int rows_per = 64;                                   // 16 rows per wave-group pass x 4
@@ -580,7 +598,7 @@ extern "C" int editor_colsum(const void* dy, int dy_bf16, long M, int N, long ld
     DISPATCH_T(dy_bf16, hipLaunchKernelGGL(colsum_kernel<TT>, dim3((N / 4 + 63) / 64, gy), dim3(256), 0, stream,
                (const TT*)dy, M, N, ld, rows_per, workspace));
     EDITOR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 63) / 64), dim3(1024), 0, stream, workspace, gy, (long)N, out, 0, 1.f);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 63) / 64), dim3(1024), 0, stream, workspace, gy, (long)N, out, 0, scale);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }
@@ -617,6 +635,20 @@ extern "C" int editor_cast_f32_to_bf16(const float* in, uint16_t* out, long n, h
     EDITOR_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int editor_cast_f32_to_f16(const float* in, uint16_t* out, long n, hipStream_t stream)
+{
+    if (n % 4) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((cast_kernel<float, f16_t>), dim3(grid_for(n / 4)), dim3(256), 0, stream, in, (f16_t*)out, n / 4);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int editor_cast_f16_to_f32(const uint16_t* in, float* out, long n, hipStream_t stream)
+{
+    if (n % 4) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((cast_kernel<f16_t, float>), dim3(grid_for(n / 4)), dim3(256), 0, stream, (const f16_t*)in, out, n / 4);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int editor_cast_bf16_to_f32(const uint16_t* in, float* out, long n, hipStream_t stream)
 {
     if (n % 4) return (int)hipErrorInvalidValue;
@@ -626,26 +658,27 @@ extern "C" int editor_cast_bf16_to_f32(const uint16_t* in, float* out, long n, h
 }
 
 extern "C" int editor_cast_rows(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16,
-                                const int* m_live, hipStream_t stream)
+                                const int* m_live, float scale, hipStream_t stream)
 {
     if (D % 4) return (int)hipErrorInvalidValue;
     DISPATCH_T(out_bf16, hipLaunchKernelGGL(cast_rows_kernel<TT>, dim3(grid_for(M * (D / 4))), dim3(256), 0, stream,
-               in, rowscale, M, D, (TT*)out, m_live));
+               in, rowscale, M, D, (TT*)out, m_live, scale));
     EDITOR_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int editor_cast_rows_colsum(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16,
-                                       float* colsum, float* workspace, int ws_rows, hipStream_t stream)
+                                       float* colsum, float* workspace, int ws_rows, float scale, float colsum_scale,
+                                       hipStream_t stream)
 {
     if ((D & 255) || D > 256 * kMaxV || ws_rows < 1 || !colsum || !workspace) return (int)hipErrorInvalidValue;
     long blocks = (M + 3) / 4;
     if (blocks > ws_rows) blocks = ws_rows;
     DISPATCH_T(out_bf16, hipLaunchKernelGGL(cast_rows_colsum_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, stream,
-               in, rowscale, M, D, (TT*)out, workspace));
+               in, rowscale, M, D, (TT*)out, workspace, scale));
     EDITOR_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((D + 63) / 64), dim3(1024), 0, stream, workspace, (int)blocks, (long)D, colsum,
-                       0, 1.f);
+                       0, colsum_scale);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }
@@ -671,12 +704,13 @@ extern "C" int editor_embed_assemble(const void* patch, int patch_bf16, const fl
 }
 
 extern "C" int editor_embed_assemble_bwd(const float* dx, const long* cam, int Bcam, int ncam, float coef, long Btot,
-    int T, int D, void* dpatch, int dpatch_bf16, float* dpos, float* dsie, float* workspace, hipStream_t stream)
+    int T, int D, void* dpatch, int dpatch_bf16, float dpatch_scale, float* dpos, float* dsie, float* workspace,
+    hipStream_t stream)
 {
     if (D % 4) return (int)hipErrorInvalidValue;
     const long total = Btot * (T - 1) * (D / 4);
     DISPATCH_T(dpatch_bf16, hipLaunchKernelGGL(embed_bwd_patch_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, stream,
-               dx, Btot, T, D, (TT*)dpatch));
+               dx, Btot, T, D, (TT*)dpatch, dpatch_scale));
     EDITOR_LAUNCH_CHECK();
     hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(T, (D + 1023) / 1024), dim3(256), 0, stream, dx, Btot, T, D, dpos);
     EDITOR_LAUNCH_CHECK();
@@ -695,7 +729,7 @@ extern "C" int editor_embed_assemble_bwd(const float* dx, const long* cam, int B
 extern "C" int editor_sfts_apply(const float* feat, const uint8_t* index, int nmod, long B, int T, int D, float* out,
                                  float* loss, float* workspace, int ws_len, hipStream_t stream)
 {
-    if (D % 4 || nmod < 2 || nmod > 3) return (int)hipErrorInvalidValue;
+    if (D % 4 || nmod < 2 || nmod > 4) return (int)hipErrorInvalidValue;
     const long total = B * T * (D / 4);
     unsigned g = grid_for(total);
     if (loss && (int)g > ws_len) g = (unsigned)ws_len;
@@ -713,7 +747,7 @@ extern "C" int editor_sfts_apply(const float* feat, const uint8_t* index, int nm
 extern "C" int editor_sfts_apply_bwd(const float* feat, const uint8_t* index, const float* dout, const float* dloss,
                                      int nmod, long B, int T, int D, float* dfeat, hipStream_t stream)
 {
-    if (D % 4 || nmod < 2 || nmod > 3) return (int)hipErrorInvalidValue;
+    if (D % 4 || nmod < 2 || nmod > 4) return (int)hipErrorInvalidValue;
     const long total = B * T * (D / 4);
     hipLaunchKernelGGL(sfts_apply_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, feat, index, dout, dloss,
                        2.f / ((float)B * (T - 1) * D), nmod, B, T, D, dfeat);

@@ -2,7 +2,7 @@
 //   editor_probe_tr16: what ds_read_b64_tr_b16 returns for a known LDS image.
 //   editor_probe_mfma16: lane->element maps of mfma_f32_16x16x32_bf16 for A, B and C/D.
 #include "common.h"
-#include "../../include/editor_hip.h"
+#include "../../include/editor_debug.h"
 
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((ext_vector_type(8))) short short8_t;

@@ -54,7 +54,7 @@ __device__ __forceinline__ Quad gather_level(float v, int lane, int bx, int by) 
 }
 
 __global__ __launch_bounds__(256) void freq_counts_kernel(
-    const float* __restrict__ m0, const float* __restrict__ m1, const float* __restrict__ m2,
+    const float* __restrict__ m0, const float* __restrict__ m1, const float* __restrict__ m2, const float* __restrict__ m3,
     int nmod, int B, int C, int H, int W, int32_t* __restrict__ counts)
 {
     const int lane = threadIdx.x & 63;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void freq_counts_kernel(
     const int ty = p / tiles_x, tx = p % tiles_x;
     const int lx = lane & 7, ly = lane >> 3;             // lane grid 8x8, 2x2 pixels per lane
     const int y0 = ty * 16 + ly * 2, x0 = tx * 16 + lx * 2;
-    const float* mods[3] = {m0, m1, m2};
+    const float* mods[4] = {m0, m1, m2, m3};
     const float fnm = (float)nmod;
 
     float sum[4] = {0.f, 0.f, 0.f, 0.f};                 // channel sums of the reconstruction
@@ -260,15 +260,14 @@ __global__ __launch_bounds__(512) void rollout_kernel(const float* __restrict__ 
     float* r = reinterpret_cast<float*>(smem);          // [T]
     float* part = r + ((T + 3) & ~3);                    // [G][T]
     const long bh = blockIdx.x;
-    const int G = blockDim.x / T;                        // row groups
-    const int g = threadIdx.x / T, j = threadIdx.x % T;
-    const bool active = g < G;
+    const int G = max(1, (int)blockDim.x / T);           // row groups (T > blockDim: one group, columns strided)
     const float* A = probs + (long)(L - 1) * layer_stride + bh * (long)T * ldp;
     for (int t = threadIdx.x; t < T; t += blockDim.x) r[t] = A[t];           // CLS row of the last layer
     __syncthreads();
     for (int l = L - 2; l >= 0; --l) {
         A = probs + (long)l * layer_stride + bh * (long)T * ldp;
-        if (active) {
+        for (int e = threadIdx.x; e < G * T; e += blockDim.x) {
+            const int g = e / T, j = e % T;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             int i = g;
             for (; i + 3 * G < T; i += 4 * G) {
@@ -310,7 +309,19 @@ extern "C" int editor_freq_counts_f32(const float* rgb, const float* nir, const 
     const int nmod = tir ? 3 : 2;
     const long tiles = (long)B * (H >> 4) * (W >> 4);
     hipLaunchKernelGGL(freq_counts_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream,
-                       rgb, nir, tir, nmod, B, C, H, W, counts);
+                       rgb, nir, tir, nullptr, nmod, B, C, H, W, counts);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_freq_counts_nmod_f32(const float* m0, const float* m1, const float* m2, const float* m3, int nmod,
+                                           int B, int C, int H, int W, int32_t* counts, hipStream_t stream)
+{
+    if ((H & 15) || (W & 15) || B <= 0 || C <= 0 || nmod < 2 || nmod > 4 || !m0 || !m1 || (nmod > 2 && !m2) || (nmod > 3 && !m3))
+        return (int)hipErrorInvalidValue;
+    const long tiles = (long)B * (H >> 4) * (W >> 4);
+    hipLaunchKernelGGL(freq_counts_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream,
+                       m0, m1, m2, m3, nmod, B, C, H, W, counts);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }
@@ -345,10 +356,10 @@ extern "C" int editor_topk_mask_f32(const float* vals, int rows, int n, int k, i
 extern "C" int editor_attn_rollout_f32(const float* probs, int L, int BH, int T, int ldp, long layer_stride, float* scores,
                                        hipStream_t stream)
 {
-    if (L < 1 || T < 2 || T > 512 || ldp < T) return (int)hipErrorInvalidValue;
+    if (L < 1 || T < 2 || T > 1024 || ldp < T) return (int)hipErrorInvalidValue;
     int threads = (512 / T) * T;                       // G full row-groups of T threads
-    if (threads < 64) threads = T;
-    const int G = threads / T;
+    if (threads < 64) threads = T < 512 ? T : 512;
+    const int G = threads / T > 0 ? threads / T : 1;
     const size_t lds = (size_t)(((T + 3) & ~3) + (size_t)G * T) * sizeof(float);
     hipLaunchKernelGGL(rollout_kernel, dim3(BH), dim3(threads), lds, stream, probs, L, layer_stride, T, ldp, scores);
     EDITOR_LAUNCH_CHECK();

@@ -3,6 +3,7 @@
 Host side (Python, as in the reference) + one HIP kernel (csrc/augment.hip):
     RandomIdentitySampler      data/datasets/sampler.py:7-66      same class name / arguments / RNG consumption: the same
                                `random` + `numpy.random` seeds give the same index list (golden-pinned)
+    RandomIdentitySampler_DDP  data/datasets/sampler_ddp.py:111-196  per-rank mini-batches of one agreed global list
     ErasingParams              the rectangle selection of RandomErasing._erase (make_dataloader.py:108-130): same draws
                                from Python's `random`, returned as numbers instead of applied (golden-pinned)
     DeviceTrainTransform       T.RandomHorizontalFlip -> T.Pad -> T.RandomCrop -> T.ToTensor -> T.Normalize ->
@@ -63,6 +64,80 @@ class RandomIdentitySampler(torch.utils.data.sampler.Sampler):
                 if len(per_pid[pid]) == 0:
                     avai.remove(pid)
         return iter(final)
+
+    def __len__(self):
+        return self.length
+
+
+class RandomIdentitySampler_DDP(torch.utils.data.sampler.Sampler):
+    """data/datasets/sampler_ddp.py:111-196: every rank builds the SAME global list of identity batches from a seed
+    agreed across ranks, then keeps its own mini-batches - block j of `batch_size // world` indices goes to rank
+    j % world.  Same numpy.random consumption as the reference (identity draw, optional with-replacement fill,
+    shuffle on an identity's first appearance), so the same shared seed gives the same per-rank index lists
+    (golden-pinned for world 1 / 2 / 4).  rank / world_size default to torch.distributed's."""
+
+    def __init__(self, data_source, batch_size, num_instances, rank=None, world_size=None, seed=None):
+        import torch.distributed as dist
+        self.data_source = data_source
+        self.batch_size = batch_size
+        self.world_size = dist.get_world_size() if world_size is None else int(world_size)
+        self.rank = dist.get_rank() if rank is None else int(rank)
+        self.num_instances = num_instances
+        self.mini_batch_size = self.batch_size // self.world_size
+        self.num_pids_per_batch = self.mini_batch_size // self.num_instances
+        self.index_dic = defaultdict(list)
+        for index, (_, pid, _, _) in enumerate(self.data_source):
+            self.index_dic[pid].append(index)
+        self.pids = list(self.index_dic.keys())
+        self.seed = seed
+        total = 0
+        for pid in self.pids:
+            num = max(len(self.index_dic[pid]), self.num_instances)
+            total += num - num % self.num_instances
+        self.length = total // self.world_size
+
+    def _shared_seed(self):
+        """sampler_ddp.py:100-109: every rank draws, rank 0's draw wins."""
+        import torch.distributed as dist
+        mine = int(np.random.randint(2 ** 31))
+        if self.seed is not None:
+            return int(self.seed)
+        if self.world_size == 1 or not (dist.is_available() and dist.is_initialized()):
+            return mine
+        box = [mine]
+        dist.broadcast_object_list(box, src=0)
+        return int(box[0])
+
+    def global_list(self):
+        """The batch-ordered index list every rank agrees on (sampler_ddp.py:166-190)."""
+        k = self.num_instances
+        live = copy.deepcopy(self.pids)
+        queue = {}
+        out = []
+        while len(live) >= self.num_pids_per_batch:
+            for pid in np.random.choice(live, self.num_pids_per_batch, replace=False).tolist():
+                q = queue.get(pid)
+                if q is None:
+                    q = copy.deepcopy(self.index_dic[pid])
+                    if len(q) < k:
+                        q = np.random.choice(q, size=k, replace=True).tolist()
+                    np.random.shuffle(q)
+                    queue[pid] = q
+                out.extend(q[:k])
+                del q[:k]
+                if len(q) < k:
+                    live.remove(pid)
+        return out
+
+    def __iter__(self):
+        np.random.seed(self._shared_seed())
+        allidx = np.asarray(self.global_list(), dtype=np.int64)
+        total, mini = len(allidx), self.mini_batch_size
+        blocks = (int(math.ceil(total / self.world_size)) // mini)
+        pos = ((np.arange(blocks) * self.world_size + self.rank)[:, None] * mini + np.arange(mini)[None, :]).reshape(-1)
+        mine = allidx[pos[pos < total]].tolist()
+        self.length = len(mine)
+        return iter(mine)
 
     def __len__(self):
         return self.length

@@ -5,9 +5,10 @@ the graph that hands parameter gradients to nn.Parameter.grad (so DDP hooks / op
 Granularity is one node per transformer block (12 backbone blocks + 3 modality blocks + 1 joint block),
 so gradient buckets become ready block by block and the RCCL all-reduce overlaps the rest of backward.
 
-Activation dtype: torch.bfloat16 (performance mode, bf16 MFMA with fp32 accumulation) or torch.float32
-(parity mode, exact-f32 MFMA).  The residual stream, LayerNorm statistics, losses and every parameter
-gradient are fp32 in both modes.
+Activation dtype: torch.bfloat16 (performance mode, bf16 MFMA with fp32 accumulation), torch.float16 (the
+reference's own autocast dtype, engine/processor.py:79: same MFMA rate, 3 more mantissa bits; its backward
+runs on LOSS-SCALED half gradients as amp.GradScaler does, :94) or torch.float32 (parity mode, exact-f32
+MFMA).  The residual stream, LayerNorm statistics, losses and every parameter gradient are fp32 in all modes.
 """
 import os
 import weakref
@@ -18,6 +19,25 @@ from . import ops
 
 _BF16_CACHE = {}
 _WEIGHT_EPOCH = 0
+
+# f16 mode: gradients that travel as half tensors (dy into the dgrad / wgrad products, attention backward, the LayerNorm
+# backward's input) are multiplied by this power of two where they are cast from the fp32 residual gradient and divided
+# out again where they return to fp32 (wgrad alpha, column sums, LayerNorm backward) - the static form of the
+# reference's amp.GradScaler (engine/processor.py:60,94-96).  Exact whenever nothing under- / overflows: half keeps
+# |g| * scale in [6e-8, 65504], i.e. gradient elements from 1.5e-11 to 16 at the default.  cfg.MODEL.GRAD_SCALE.
+F16_GRAD_SCALE = 4096.0
+
+
+def set_f16_grad_scale(v):
+    global F16_GRAD_SCALE
+    v = float(v)
+    if v <= 0 or (v != 2.0 ** round(__import__("math").log2(v))):
+        raise ValueError("GRAD_SCALE must be a positive power of two")
+    F16_GRAD_SCALE = v
+
+
+def grad_scale(dtype):
+    return F16_GRAD_SCALE if dtype == torch.float16 else 1.0
 
 
 def invalidate_weight_cache():
@@ -30,23 +50,23 @@ def invalidate_weight_cache():
 def install_weight_copies(pairs):
     """(parameter, bf16 tensor holding its current value) pairs -> entries of the operand cache for the current epoch."""
     for w, h in pairs:
-        _BF16_CACHE[id(w)] = (weakref.ref(w), w._version, h, w.data_ptr(), _WEIGHT_EPOCH)
+        _BF16_CACHE[(id(w), h.dtype)] = (weakref.ref(w), w._version, h, w.data_ptr(), _WEIGHT_EPOCH)
 
 
 def act_weight(w, dtype):
-    """fp32 master parameter -> GEMM operand dtype.  bf16 copies are cached per parameter OBJECT and re-cast when
+    """fp32 master parameter -> GEMM operand dtype.  16-bit copies are cached per parameter OBJECT and re-cast when
     the parameter's version counter moves (optimizer step, load_state_dict).  The entry holds a weak reference so
     that a recycled id()/address of a freed parameter can never serve stale weights."""
     if dtype == torch.float32:
         return w.detach()
-    key = id(w)
+    key = (id(w), dtype)
     ent = _BF16_CACHE.get(key)
     ver = w._version
     if ent is None or ent[0]() is not w or ent[1] != ver or ent[3] != w.data_ptr() or ent[4] != _WEIGHT_EPOCH:
         if len(_BF16_CACHE) > 4096:                       # drop entries of dead parameters
             for k in [k for k, e in _BF16_CACHE.items() if e[0]() is None]:
                 del _BF16_CACHE[k]
-        ent = (weakref.ref(w), ver, ops.cast(w.detach().contiguous().view(-1), torch.bfloat16).view(w.shape),
+        ent = (weakref.ref(w), ver, ops.cast(w.detach().contiguous().view(-1), dtype).view(w.shape),
                w.data_ptr(), _WEIGHT_EPOCH)
         _BF16_CACHE[key] = ent
     return ent[2]
@@ -86,22 +106,25 @@ def join_side_stream(device):
     _SIDE_KEEP.clear()          # (main-stream work enqueued from here on is ordered after the side stream's reads)
 
 
-def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None):
+def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None, gs=1.0):
     """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy) (or the
     caller's, when the kernel that produced dy summed its columns on the way).  dx_colsum: also return colsum(dx) - the
-    bias gradient of the layer BELOW - from the dgrad's own epilogue when it can deliver it (else None)."""
+    bias gradient of the layer BELOW - from the dgrad's own epilogue when it can deliver it (else None).
+    gs: loss scale carried by dy (f16 mode): dx keeps it, dW / db / the returned column sums have it divided out."""
     m, n = dy.shape
     k = x2d.shape[1]
-    use_side = WGRAD_SIDE_STREAM and dy.dtype == torch.bfloat16 and m >= 2048
+    inv = 1.0 / gs
+    use_side = WGRAD_SIDE_STREAM and dy.dtype in ops.HALF_DTYPES and m >= 2048
     dy_ready = torch.cuda.current_stream(dy.device).record_event() if use_side else None   # BEFORE the dgrad launch
     dx = torch.empty(m, k, dtype=x2d.dtype, device=dy.device)
     dxcs = None
     if dx_colsum and ops.gemm_colsum_ok(m, k, n, dx.dtype, 0, 1, m_live):
         dxcs = torch.empty(k, dtype=torch.float32, device=dy.device)
     if gelu_pre is None:
-        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, m_live=m_live, colsum=dxcs)    # B stored (Kred=n, Nout=k)
+        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, m_live=m_live, colsum=dxcs, colsum_scale=inv)    # B stored (Kred=n, Nout=k)
     else:
-        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=gelu_pre, m_live=m_live, colsum=dxcs)
+        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=gelu_pre, m_live=m_live, colsum=dxcs,
+                 colsum_scale=inv)
     dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
     if need_bias and db is None:
         db = torch.empty(n, dtype=torch.float32, device=dy.device)
@@ -116,13 +139,13 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, 
         # allocator hold blocks back and cost 3 ms per eager step)
         _SIDE_KEEP.append((dy, x2d))
         with torch.cuda.stream(side):
-            ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, splitk=_splitk_for(n, k, m), m_live=m_live)
+            ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, alpha=inv, splitk=_splitk_for(n, k, m), m_live=m_live)
             if need_colsum:
-                ops.colsum(dy, out=db)
+                ops.colsum(dy, out=db, scale=inv)
     else:
-        ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, splitk=_splitk_for(n, k, m), m_live=m_live)   # both stored (Kred=m, .)
+        ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, alpha=inv, splitk=_splitk_for(n, k, m), m_live=m_live)   # both stored (Kred=m, .)
         if need_colsum:
-            ops.colsum(dy, out=db)
+            ops.colsum(dy, out=db, scale=inv)
     if dx_colsum is not None:
         return dx, dw, (db if need_bias else None), dxcs
     return dx, dw, (db if need_bias else None)
@@ -156,7 +179,7 @@ class TransformerBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, mask, probs_out,
-                heads, eps, act_dtype, rowscale_attn, rowscale_mlp, cu=None, max_t=None, m_live=None):
+                heads, eps, act_dtype, rowscale_attn, rowscale_mlp, cu=None, max_t=None, m_live=None, qk_scale=None):
         # dense: x (B,T,D), mask (B,T) token mask.  packed (compacted HMA): x (M,D), cu (B+1) sequence row ranges,
         # max_t = longest sequence, mask (M) = 1 for live rows / 0 for the padding rows at the end.
         if cu is None:
@@ -171,10 +194,10 @@ class TransformerBlockFn(torch.autograd.Function):
         h1, mean1, rstd1 = ops.layernorm_fwd(x2d, n1w, n1b, eps, act_dtype, mask, 0, m_live=m_live)
         qkv = _linear_fwd(h1, wq, qkvb, act_dtype, m_live)
         if isinstance(probs_out, list):            # bf16 backbone: no probability tensor; the rollout recomputes it
-            ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, None, cu=cu)
+            ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, None, cu=cu, scale=qk_scale)
             probs_out.append((qkv, attn_saved))
         else:
-            ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, probs_out, cu=cu)
+            ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, probs_out, cu=cu, scale=qk_scale)
         x1 = torch.empty_like(x2d)                  # x1 = x + rs * (ao Wp^T + b): residual add in the GEMM epilogue
         ops.gemm(ao, wp, x1, m, d, d, d, d, d, 0, 0, bias=projb, rowscale=rowscale_attn,
                  epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)
@@ -189,48 +212,51 @@ class TransformerBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
                               qkvw, projw, fc1w, fc2w, mask, attn_saved, rowscale_attn, rowscale_mlp, cu, m_live)
         ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None,
-                    tuple(x.shape))
+                    tuple(x.shape), qk_scale)
         return x2.view(x.shape)
 
     @staticmethod
     def backward(ctx, dx2):
         (x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w, qkvw, projw, fc1w, fc2w, mask,
          attn_saved, rs_attn, rs_mlp, cu, m_live) = ctx.saved_tensors
-        b, t, d, heads, act_dtype, hb_qkv, hb_proj, hb_fc1, hb_fc2, xshape = ctx.meta
+        b, t, d, heads, act_dtype, hb_qkv, hb_proj, hb_fc1, hb_fc2, xshape, qk_scale = ctx.meta
+        gs = grad_scale(act_dtype)                   # f16: half gradients travel loss-scaled (1.0 otherwise)
         m = x2d.shape[0]
         hd = d // heads
         amask = None if cu is not None else mask
         wq, wp, w1, w2 = (act_weight(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w))
         dx2 = dx2.contiguous().view(m, d)
         # ---- MLP branch:  x2 = x1 + rs * fc2(gelu(fc1(LN2(x1))))
-        dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2)
+        dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2, gs)
         da, dw2, db2, da_cs = _linear_bwd(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live, db=dbias,
-                                          dx_colsum=hb_fc1)                              # da = (dy W2) * gelu'(a)
-        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs)
-        dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w, mean2, rstd2, mask, 0, dx_in=dx2, m_live=m_live)
+                                          dx_colsum=hb_fc1, gs=gs)                       # da = (dy W2) * gelu'(a)
+        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs, gs=gs)
+        dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w, mean2, rstd2, mask, 0, dx_in=dx2, m_live=m_live,
+                                            dy_scale=1.0 / gs)
         # ---- attention branch:  x1 = x + rs * proj(attn(qkv(LN1(x))))
-        dy, dbias = _scaled_cast_colsum(dx1, rs_attn, act_dtype, m_live, hb_proj)
-        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live, db=dbias)
-        dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, amask, attn_saved, ao, cu=cu)
-        dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live)
-        dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1, m_live=m_live)
+        dy, dbias = _scaled_cast_colsum(dx1, rs_attn, act_dtype, m_live, hb_proj, gs)
+        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live, db=dbias, gs=gs)
+        dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, amask, attn_saved, ao, cu=cu, scale=qk_scale)
+        dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live, gs=gs)
+        dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1, m_live=m_live,
+                                           dy_scale=1.0 / gs)
         join_side_stream(dx.device)                  # the four weight gradients (side stream) are complete
         return (dx.view(xshape), dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
-def _scaled_cast_colsum(dx, rowscale, dtype, m_live, want_colsum):
-    """_scaled_cast, plus the column sums of the result when the consumer has a bias (dense bf16 rows only)."""
-    if (want_colsum and m_live is None and dtype == torch.bfloat16 and dx.dtype == torch.float32
+def _scaled_cast_colsum(dx, rowscale, dtype, m_live, want_colsum, gs=1.0):
+    """_scaled_cast, plus the (unscaled) column sums of the result when the consumer has a bias (dense 16-bit rows only)."""
+    if (want_colsum and m_live is None and dtype in ops.HALF_DTYPES and dx.dtype == torch.float32
             and dx.shape[1] % 256 == 0 and dx.shape[1] <= 1024):
-        return ops.cast_rows_colsum(dx, rowscale, dtype)
-    return _scaled_cast(dx, rowscale, dtype, m_live), None
+        return ops.cast_rows_colsum(dx, rowscale, dtype, gs)
+    return _scaled_cast(dx, rowscale, dtype, m_live, gs), None
 
 
-def _scaled_cast(dx, rowscale, dtype, m_live=None):
-    if rowscale is None and dx.dtype == dtype:
+def _scaled_cast(dx, rowscale, dtype, m_live=None, gs=1.0):
+    if rowscale is None and dx.dtype == dtype and gs == 1.0:
         return dx
-    return ops.cast_rows(dx, rowscale, dtype, m_live)
+    return ops.cast_rows(dx, rowscale, dtype, m_live, gs)
 
 
 class PatchEmbedFn(torch.autograd.Function):
@@ -258,13 +284,14 @@ class PatchEmbedFn(torch.autograd.Function):
         cols, conv_w, cam = ctx.saved_tensors
         coef, act_dtype, ncam, cls_shape, pos_shape, sie_shape = ctx.meta
         dx = dx.contiguous()
-        dpatch, dpos, dsie = ops.embed_assemble_bwd(dx, cam, ncam or 0, coef, act_dtype)
+        gs = grad_scale(act_dtype)
+        dpatch, dpos, dsie = ops.embed_assemble_bwd(dx, cam, ncam or 0, coef, act_dtype, gs)
         d = conv_w.shape[0]
         kdim = cols.shape[1]
         mrows = cols.shape[0]
         dw = torch.empty(d, kdim, dtype=torch.float32, device=dx.device)
-        ops.gemm(dpatch, cols, dw, d, kdim, mrows, d, kdim, kdim, 1, 1, splitk=_splitk_for(d, kdim, mrows))
-        db = ops.colsum(dpatch)
+        ops.gemm(dpatch, cols, dw, d, kdim, mrows, d, kdim, kdim, 1, 1, alpha=1.0 / gs, splitk=_splitk_for(d, kdim, mrows))
+        db = ops.colsum(dpatch, scale=1.0 / gs)
         dcls = dpos[0].clone().view(cls_shape)
         return (None, dw.view(conv_w.shape), db, dcls, dpos.view(pos_shape),
                 None if dsie is None else dsie.view(sie_shape), None, None, None)
@@ -371,17 +398,19 @@ class BatchNorm1dFn(torch.autograd.Function):
 
 
 class OCFRFn(torch.autograd.Function):
-    """OCFR.forward (OCFR.py:44-84) over the three modalities: returns the summed intra loss and updates the centre
-    tables (non-grad Parameters) in place."""
+    """OCFR.forward (OCFR.py:44-84) over the modalities: returns the summed intra loss and updates the centre
+    tables (non-grad Parameters) in place.  Arguments after nmod: nmod cls-feature tensors, then nmod centre tables."""
 
     @staticmethod
-    def forward(ctx, f_r, f_n, f_t, c_r, c_n, c_t, label, momentum):
-        loss = torch.empty(1, dtype=torch.float32, device=f_r.device)
+    def forward(ctx, label, momentum, nmod, *fc):
+        feats, centers = fc[:nmod], fc[nmod:]
+        loss = torch.empty(1, dtype=torch.float32, device=feats[0].device)
         saved = []
-        for i, (f, c) in enumerate(((f_r, c_r), (f_n, c_n), (f_t, c_t))):
+        for i, (f, c) in enumerate(zip(feats, centers)):
             fn, inv = ops.ocfr_fwd(f, label, c.data, momentum, loss, accumulate=i > 0)
             saved += [fn, inv, c.data.clone()]      # centres are overwritten by later steps: keep this step's copy
         ctx.save_for_backward(label, *saved)
+        ctx.nmod = nmod
         return loss.view(())
 
     @staticmethod
@@ -389,8 +418,8 @@ class OCFRFn(torch.autograd.Function):
         label = ctx.saved_tensors[0]
         sv = ctx.saved_tensors[1:]
         dl = dloss.contiguous().view(1).float()
-        grads = [ops.ocfr_bwd(sv[3 * i], sv[3 * i + 1], sv[3 * i + 2], label, dl) for i in range(3)]
-        return grads[0], grads[1], grads[2], None, None, None, None, None
+        grads = [ops.ocfr_bwd(sv[3 * i], sv[3 * i + 1], sv[3 * i + 2], label, dl) for i in range(ctx.nmod)]
+        return (None, None, None) + tuple(grads) + (None,) * ctx.nmod
 
 
 class CrossEntropyLabelSmoothFn(torch.autograd.Function):

@@ -20,21 +20,44 @@ def triplet_soft_margin(feat, labels):
     return Fn.TripletSoftMarginFn.apply(feat, labels)
 
 
-def make_loss(cfg=None, num_classes=None):
-    """layers/make_loss.py:13-56 for the configuration the reference trains with (sampler softmax_triplet,
-    METRIC_LOSS_TYPE triplet, NO_MARGIN, label smoothing on).  Returns loss_func(score, feat, target, target_cam)."""
+class CenterLoss(torch.nn.Module):
+    """Parameter holder with the reference's name and shape (layers/center_loss.py:19-29: `centers` (C, feat_dim),
+    N(0,1), on the CPU as make_loss builds it with use_gpu=False).  train_net.py:72-74 hands it to make_optimizer and
+    do_train; with the shipped METRIC_LOSS_TYPE ('triplet') its forward is never called (processor.py:97-100 touches
+    it only when 'center' is in the loss type), so no kernel exists for it."""
+
+    def __init__(self, num_classes=751, feat_dim=2048):
+        super().__init__()
+        self.num_classes, self.feat_dim = num_classes, feat_dim
+        self.centers = torch.nn.Parameter(torch.randn(num_classes, feat_dim))
+
+    def forward(self, x, labels):
+        raise NotImplementedError("center loss is not on the EDITOR hot path (METRIC_LOSS_TYPE is 'triplet' in every "
+                                  "shipped config)")
+
+
+def _loss_func(cfg=None):
     idw = float(getattr(getattr(cfg, "MODEL", None), "ID_LOSS_WEIGHT", 1.0)) if cfg is not None else 1.0
     trw = float(getattr(getattr(cfg, "MODEL", None), "TRIPLET_LOSS_WEIGHT", 1.0)) if cfg is not None else 1.0
 
     def loss_func(score, feat, target, target_cam=None):
+        if feat.shape[0] != target.shape[0]:                          # make_loss.py:38-39
+            target = target.repeat(feat.shape[0] // target.shape[0])
         return idw * cross_entropy_label_smooth(score, target) + trw * triplet_soft_margin(feat, target)
 
     return loss_func
 
 
+def make_loss(cfg=None, num_classes=None):
+    """layers/make_loss.py:13-80 for the configuration the reference trains with (sampler softmax_triplet,
+    METRIC_LOSS_TYPE triplet, NO_MARGIN, label smoothing on).  Returns (loss_func(score, feat, target, target_cam),
+    center_criterion) as the reference does (train_net.py:72 unpacks both)."""
+    return _loss_func(cfg), CenterLoss(num_classes=num_classes or 751, feat_dim=2048)
+
+
 def loss_pairs(output, target, loss_fn=None):
     """engine/processor.py:82-92: odd-length output = (score_i, feat_i) pairs + trailing aux loss."""
-    loss_fn = loss_fn or make_loss()
+    loss_fn = loss_fn or _loss_func()
     npair = len(output) - (len(output) % 2)
     loss = output[-1] if len(output) % 2 == 1 else None
     for i in range(0, npair, 2):

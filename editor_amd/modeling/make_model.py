@@ -24,14 +24,19 @@ from .. import functional as fn
 from .. import ops
 
 _ARCH = {
-    # name: (embed_dim, depth, heads, mlp_ratio, qkv_bias)   vit_pytorch.py:693-727
-    "vit_base_patch16_224": (768, 12, 12, 4.0, True),
-    "deit_base_patch16_224": (768, 12, 12, 4.0, True),
-    "deit_small_patch16_224": (384, 12, 6, 4.0, True),
-    "vit_small_patch16_224": (768, 8, 8, 3.0, False),
+    # name: (embed_dim, depth, heads, mlp_ratio, qkv_bias, qk_scale)   vit_pytorch.py:693-727
+    "vit_base_patch16_224": (768, 12, 12, 4.0, True, None),
+    "deit_base_patch16_224": (768, 12, 12, 4.0, True, None),
+    "deit_small_patch16_224": (384, 12, 6, 4.0, True, None),
+    "vit_small_patch16_224": (768, 8, 8, 3.0, False, 768 ** -0.5),        # vit_pytorch.py:712: qk_scale=768 ** -0.5
     # extension (BASELINE.json config 5): not in the reference's factory (make_model.py:363-368)
-    "vit_large_patch16_224": (1024, 24, 16, 4.0, True),
+    "vit_large_patch16_224": (1024, 24, 16, 4.0, True, None),
 }
+
+# (input dict key, name of the REDUCE layer / OCFR centre table, BlockMask tag): the reference's three modalities
+# (make_model.py:153-155,106-108; vit_pytorch.py:268-290; OCFR.py:16-18) and the 4th of the synthetic 4-modal
+# configuration (BASELINE.json config 5) - an extension, the reference's forward hard-codes three keys
+_MODALITIES = (("RGB", "RGB", "R"), ("NI", "NIR", "N"), ("TI", "TIR", "T"), ("M4", "M4", "M4"))
 
 
 def _trunc_normal_(t, std=0.02):
@@ -40,7 +45,13 @@ def _trunc_normal_(t, std=0.02):
 
 def _act_dtype(cfg):
     name = getattr(cfg.MODEL, "COMPUTE_DTYPE", "bf16")
-    return torch.float32 if name in ("f32", "fp32", "float32") else torch.bfloat16
+    if name in ("f32", "fp32", "float32"):
+        return torch.float32
+    if name in ("f16", "fp16", "float16", "half"):
+        return torch.float16
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    raise ValueError("cfg.MODEL.COMPUTE_DTYPE must be 'bf16', 'f16' or 'f32', got %r" % (name,))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -96,9 +107,11 @@ def _init_linear_ln(mod):
 class Trans(nn.Module):
     """Parameter layout of the reference's ViT `Trans` (vit_pytorch.py:461-534)."""
 
-    def __init__(self, img_size, embed_dim, depth, heads, mlp_ratio, qkv_bias, camera, sie_xishu, drop_path_rate):
+    def __init__(self, img_size, embed_dim, depth, heads, mlp_ratio, qkv_bias, camera, sie_xishu, drop_path_rate,
+                 qk_scale=None):
         super().__init__()
         self.embed_dim, self.depth, self.heads = embed_dim, depth, heads
+        self.qk_scale = qk_scale
         self.num_y, self.num_x = img_size[0] // 16, img_size[1] // 16
         self.num_patches = self.num_y * self.num_x
         self.img_size = tuple(img_size)
@@ -159,11 +172,11 @@ class build_transformer(nn.Module):
     def __init__(self, num_classes, cfg, camera_num):
         super().__init__()
         ttype = cfg.MODEL.TRANSFORMER_TYPE
-        dim, depth, heads, mlp_ratio, qkv_bias = _ARCH[ttype]
+        dim, depth, heads, mlp_ratio, qkv_bias, qk_scale = _ARCH[ttype]
         self.token_dim = dim
         cams = camera_num if cfg.MODEL.SIE_CAMERA else 0
         self.base = Trans(cfg.INPUT.SIZE_TRAIN, dim, depth, heads, mlp_ratio, qkv_bias, cams, cfg.MODEL.SIE_COE,
-                          cfg.MODEL.DROP_PATH)
+                          cfg.MODEL.DROP_PATH, qk_scale)
         if cfg.MODEL.PRETRAIN_CHOICE == "imagenet":
             self.base.load_param(cfg.MODEL.PRETRAIN_PATH_T)
 
@@ -190,25 +203,25 @@ class FrequencyIndex(nn.Module):
         if stride != 16:
             raise NotImplementedError("the HIP frequency kernel tiles 16x16 windows (STRIDE_SIZE 16)")
 
-    def forward(self, x, y, z=None, **_):
-        mask, _ = ops.frequency_mask(x, y, z, self.keep)
+    def forward(self, x, y, z=None, w=None, **_):
+        mask, _ = ops.frequency_mask(x, y, z, self.keep, w)
         return mask.bool()
 
 
 class OCFRCenters(nn.Module):
-    def __init__(self, dim, num_class):
+    def __init__(self, dim, num_class, names=("RGB", "NIR", "TIR")):
         super().__init__()
-        for n in ("RGB", "NIR", "TIR"):
+        for n in names:
             setattr(self, n + "_centers", nn.Parameter(torch.zeros(num_class, dim), requires_grad=False))
 
 
 class BlockMask(nn.Module):
     """Parameter layout of the HMA head (vit_pytorch.py:261-307)."""
 
-    def __init__(self, dim, num_class, mlp_ratio=4.0, momentum=0.8):
+    def __init__(self, dim, num_class, mlp_ratio=4.0, momentum=0.8, modalities=_MODALITIES[:3]):
         super().__init__()
         hidden = int(dim * mlp_ratio)
-        for tag in ("R", "N", "T"):
+        for tag in [m[2] for m in modalities]:
             setattr(self, "norm" + tag, nn.LayerNorm(dim))
             setattr(self, "attn" + tag, _Attn(dim, False))
             setattr(self, "norm" + tag + "_", nn.LayerNorm(dim))
@@ -218,7 +231,7 @@ class BlockMask(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = _Mlp(dim, hidden, False)
         self.out_norm = nn.LayerNorm(dim)
-        self.memory_cls = OCFRCenters(dim, num_class)
+        self.memory_cls = OCFRCenters(dim, num_class, [m[1] for m in modalities])
         self.momentum = momentum
         _init_linear_ln(self)
 
@@ -242,24 +255,40 @@ class EDITOR(nn.Module):
         self.head_k = int(self.num_patches * self.ratio)                        # SFTS.py:155
         self.FREQ_INDEX = FrequencyIndex(cfg.MODEL.FREQUENCY_KEEP, cfg.MODEL.STRIDE_SIZE[0])
         self.hma_heads = getattr(cfg.MODEL, "HMA_HEADS", 12 if dim % 12 == 0 else 16)    # make_model.py:97
-        self.FUSE_block = BlockMask(dim, num_classes, 4.0, 0.8)
-        for tag in ("RGB", "NIR", "TIR"):
+        nmod = int(getattr(cfg.MODEL, "NUM_MODALITIES", 3))
+        if nmod not in (3, 4):
+            raise NotImplementedError("EDITOR fuses 3 modalities (make_model.py:153-155); NUM_MODALITIES = 4 is the "
+                                      "synthetic extension of BASELINE config 5")
+        self.modalities = _MODALITIES[:nmod]
+        self.nmod = nmod
+        self.FUSE_block = BlockMask(dim, num_classes, 4.0, 0.8, self.modalities)
+        for tag in [m[1] for m in self.modalities]:
             lin = nn.Linear(2 * dim, dim)
             nn.init.kaiming_normal_(lin.weight, a=0, mode="fan_out")            # make_model.py:10-14
             nn.init.constant_(lin.bias, 0.0)
             setattr(self, tag + "_REDUCE", lin)
-        self.FUSE_HEAD = nn.Linear(3 * dim, num_classes, bias=False)
-        self.FUSE_BN = nn.BatchNorm1d(3 * dim)
+        self.FUSE_HEAD = nn.Linear(nmod * dim, num_classes, bias=False)
+        self.FUSE_BN = nn.BatchNorm1d(nmod * dim)
         nn.init.normal_(self.FUSE_HEAD.weight, std=0.001)                       # make_model.py:26-31
         self.BACKBONE_HEAD = nn.Linear(dim, num_classes, bias=False)
         self.BACKBONE_BN = nn.BatchNorm1d(dim)
         nn.init.normal_(self.BACKBONE_HEAD.weight, std=0.001)
         self.AL = cfg.MODEL.AL
         if self.AL:
-            self.AL_HEAD = nn.Linear(3 * dim, num_classes, bias=False)
-            self.AL_BN = nn.BatchNorm1d(3 * dim)
+            self.AL_HEAD = nn.Linear(nmod * dim, num_classes, bias=False)
+            self.AL_BN = nn.BatchNorm1d(nmod * dim)
             nn.init.normal_(self.AL_HEAD.weight, std=0.001)
         self.act_dtype = _act_dtype(cfg)
+        base = self.BACKBONE.base
+        if self.act_dtype != torch.float32 and (dim // base.heads != 64 or dim // self.hma_heads != 64):
+            # the fused 16-bit attention kernels are written for 64-wide heads (ViT-B/L, DeiT-B); the exact-f32 parity
+            # kernels take any head width
+            raise NotImplementedError(
+                "%s with COMPUTE_DTYPE=%s: head widths %d (backbone) / %d (HMA) - the bf16 / f16 attention kernels need 64; "
+                "use COMPUTE_DTYPE='f32' for this architecture" % (cfg.MODEL.TRANSFORMER_TYPE, cfg.MODEL.COMPUTE_DTYPE,
+                                                                   dim // base.heads, dim // self.hma_heads))
+        if hasattr(cfg.MODEL, "GRAD_SCALE"):
+            fn.set_f16_grad_scale(cfg.MODEL.GRAD_SCALE)
         self.hma_compact = bool(getattr(cfg.MODEL, "HMA_COMPACT", True))
         self.rollout_probs = bool(getattr(cfg.MODEL, "ROLLOUT_PROBS", False))
         self.teacher_index = None            # optional (B,N) bool: force the SFTS selection (bf16 protocol)
@@ -310,7 +339,8 @@ class EDITOR(nn.Module):
             if scales is not None and base.drop_rates[i] > 0.0:
                 rs_a, rs_m = scales[i, 0], scales[i, 1]
             x = fn.TransformerBlockFn.apply(x, *_block_args(blk.norm1, blk.attn, blk.norm2, blk.mlp), None,
-                                            probs if recompute else probs[i], base.heads, 1e-6, self.act_dtype, rs_a, rs_m)
+                                            probs if recompute else probs[i], base.heads, 1e-6, self.act_dtype, rs_a, rs_m,
+                                            None, None, None, base.qk_scale)
         x = fn.LayerNormFn.apply(x, base.norm.weight, base.norm.bias, 1e-6, None)
         return x, probs
 
@@ -326,13 +356,15 @@ class EDITOR(nn.Module):
             base = self.BACKBONE.base
             h, t = base.heads, base.num_patches + 1
             btot = probs[0][0].shape[0] // t
-            scores = ops.attn_rollout_qk(probs, btot, t, h, probs[0][0].shape[1] // (3 * h))
+            scores = ops.attn_rollout_qk(probs, btot, t, h, probs[0][0].shape[1] // (3 * h), base.qk_scale)
         else:
             l, btot, h, t = probs.shape[:4]
             scores = ops.attn_rollout(probs)                                    # (3B, h, N)
         m = ops.topk_mask(scores.view(btot * h, t - 1), self.head_k, group=h)    # (3B, N)
         nmod = btot // b
         index = ops.mask_or(m[:b], m[b:2 * b], m[2 * b:3 * b] if nmod > 2 else None, mask_fre)
+        if nmod > 3:
+            index = ops.mask_or(index, m[3 * b:4 * b])
         self.last_aux = {"scores": scores, "attn_masks": m.view(nmod, b, t - 1), "mask_fre": mask_fre, "index": index}
         return index
 
@@ -343,7 +375,7 @@ class EDITOR(nn.Module):
         mask = torch.cat([torch.ones(b, 1, dtype=torch.uint8, device=index.device), index], dim=1).contiguous()
         mods = []
         feats_mod = feats_s.unbind(0)                  # (unbind's backward is one stack; per-index selects zero-fill and add)
-        for i, tag in enumerate(("R", "N", "T")):
+        for i, tag in enumerate(m_[2] for m_ in self.modalities):
             args = _block_args(getattr(fb, "norm" + tag), getattr(fb, "attn" + tag), getattr(fb, "norm" + tag + "_"),
                                getattr(fb, "mlp" + tag))
             mods.append(fn.TransformerBlockFn.apply(feats_mod[i], *args, mask, None, self.hma_heads, 1e-5,
@@ -367,7 +399,7 @@ class EDITOR(nn.Module):
         xa = fn.GatherRowsFn.apply(feats_s.reshape(nmod * b * t, d), plan.map_a, plan.live_a, 1, plan.ma)   # layout A
         mods = []
         xa_mod = torch.split(xa, plan.ma, dim=0)       # (split's backward is one cat; slices would zero-fill and add)
-        for i, tag in enumerate(("R", "N", "T")):
+        for i, tag in enumerate(m_[2] for m_ in self.modalities):
             args = _block_args(getattr(fb, "norm" + tag), getattr(fb, "attn" + tag), getattr(fb, "norm" + tag + "_"),
                                getattr(fb, "mlp" + tag))
             mods.append(fn.TransformerBlockFn.apply(xa_mod[i], *args, plan.mask_a, None,
@@ -377,7 +409,7 @@ class EDITOR(nn.Module):
         loss_ocfr = None
         if self.training:
             cls = fn.GatherRowsFn.apply(xa, plan.map_cls).view(nmod, b, d)
-            loss_ocfr = self._ocfr([cls[0], cls[1], cls[2]], label)
+            loss_ocfr = self._ocfr(list(cls.unbind(0)), label)
         xb = fn.GatherRowsFn.apply(xa, plan.map_b, plan.live_a, nmod, plan.mb)             # layout B (MB, D)
         xb = fn.TransformerBlockFn.apply(xb, *_block_args(fb.norm1, fb.attn1, fb.norm2, fb.mlp), plan.mask_b, None,
                                          self.hma_heads, 1e-5, self.act_dtype, None, None, plan.cu3, nmod * t, plan.live_b)
@@ -389,19 +421,21 @@ class EDITOR(nn.Module):
     def _ocfr(self, cls_feats, label):
         """OCFR.forward (OCFR.py:44-84): normalise, per-label centre update (momentum 0.8), MSE to own-class centre."""
         mc = self.FUSE_block.memory_cls
-        return fn.OCFRFn.apply(cls_feats[0], cls_feats[1], cls_feats[2], mc.RGB_centers, mc.NIR_centers, mc.TIR_centers,
-                               label.contiguous(), float(self.FUSE_block.momentum))
+        centers = [getattr(mc, m_[1] + "_centers") for m_ in self.modalities]
+        return fn.OCFRFn.apply(label.contiguous(), float(self.FUSE_block.momentum), len(cls_feats), *cls_feats, *centers)
 
     # -- forward (make_model.py:150-258) ----------------------------------------------------------
     def forward(self, x, cam_label=None, label=None, view_label=None, img_path=None, mode=1, writer=None, epoch=None):
-        rgb, nir, tir = x["RGB"], x["NI"], x["TI"]
+        mods = [x[m_[0]].contiguous() for m_ in self.modalities]             # make_model.py:153-155
+        rgb = mods[0]
+        nmod = self.nmod
         if not rgb.is_cuda:
             raise RuntimeError("EDITOR (MI355X build): inputs must be on the GPU; there is no CPU fallback path")
         b = rgb.shape[0]
         dim = self.BACKBONE.token_dim
         with torch.no_grad():
-            mask_fre, _ = ops.frequency_mask(rgb.contiguous(), nir.contiguous(), tir.contiguous(), self.FREQ_INDEX.keep)
-        imgs = torch.cat([rgb, nir, tir], dim=0).contiguous()
+            mask_fre, _ = ops.frequency_mask(mods[0], mods[1], mods[2], self.FREQ_INDEX.keep, mods[3] if nmod > 3 else None)
+        imgs = torch.cat(mods, dim=0)
         feats, probs = self._backbone(imgs, cam_label)
         t = feats.shape[1]
         with torch.no_grad():
@@ -410,7 +444,7 @@ class EDITOR(nn.Module):
                 index = self.teacher_index.to(index.device).to(torch.uint8).contiguous()
                 self.last_aux["index"] = index
         del probs
-        feats = feats.view(3, b, t, dim)
+        feats = feats.view(nmod, b, t, dim)
         training = self.training
         feats_s, loss_bcc, cls_all = fn.SFTSApplyFn.apply(feats, index, training)
         cls_tri = list(cls_all.unbind(0))
@@ -421,15 +455,15 @@ class EDITOR(nn.Module):
             else:
                 mod_scores = [fn.LinearFn.apply(self._bn(self.BACKBONE_BN, c), self.BACKBONE_HEAD.weight, None)
                               for c in cls_tri]
-        if self.hma_compact and self.act_dtype == torch.bfloat16 and b * t >= 256:
+        if self.hma_compact and self.act_dtype != torch.float32 and b * t >= 256:
             pooled, num, loss_ocfr = self._hma_compact(feats_s, index, label)
         else:                      # dense-masked form, as the reference computes it (always used in f32 parity mode)
             fused, loss_ocfr = self._hma(feats_s, index, label)
-            pooled, num = fn.PoolFn.apply(fused, 3, t)
+            pooled, num = fn.PoolFn.apply(fused, nmod, t)
         if training and writer is not None:
             writer.add_scalar("num_count", num.mean(), epoch)                      # make_model.py:199-200
-        red = [fn.LinearFn.apply(pooled[i], getattr(self, tag + "_REDUCE").weight, getattr(self, tag + "_REDUCE").bias)
-               for i, tag in enumerate(("RGB", "NIR", "TIR"))]
+        red = [fn.LinearFn.apply(pooled[i], getattr(self, m_[1] + "_REDUCE").weight, getattr(self, m_[1] + "_REDUCE").bias)
+               for i, m_ in enumerate(self.modalities)]
         cls4t = torch.cat(red, dim=-1)
         self.last_aux.update(num=num, loss_bcc=loss_bcc, loss_ocfr=loss_ocfr)
         if not training:
@@ -438,8 +472,7 @@ class EDITOR(nn.Module):
         aux_loss = loss_bcc + loss_ocfr
         if self.AL:
             return score, cls4t, ori_score, ori, aux_loss
-        return (score, cls4t, mod_scores[0], cls_tri[0], mod_scores[1], cls_tri[1], mod_scores[2], cls_tri[2],
-                aux_loss)
+        return (score, cls4t) + tuple(v for pair in zip(mod_scores, cls_tri) for v in pair) + (aux_loss,)
 
     def _bn(self, bn, x):
         if self.training:

@@ -12,12 +12,16 @@ _raw_stream = _lib._raw_stream
 # ---------------------------------------------------------------------------------------------
 # token selection
 # ---------------------------------------------------------------------------------------------
-def freq_counts(rgb, nir, tir):
-    """Frequency.py:65-84,42-56 -> (B, N) int32 positive-pixel counts per 16x16 patch."""
+def freq_counts(rgb, nir, tir, m4=None):
+    """Frequency.py:65-84,42-56 -> (B, N) int32 positive-pixel counts per 16x16 patch (m4: 4-modal extension)."""
     b, c, h, w = rgb.shape
     counts = torch.empty(b, (h // 16) * (w // 16), dtype=torch.int32, device=rgb.device)
-    call("editor_freq_counts_f32", rgb.contiguous(), nir.contiguous(),
-         None if tir is None else tir.contiguous(), b, c, h, w, counts)
+    if m4 is not None:
+        call("editor_freq_counts_nmod_f32", rgb.contiguous(), nir.contiguous(), tir.contiguous(), m4.contiguous(), 4,
+             b, c, h, w, counts)
+    else:
+        call("editor_freq_counts_f32", rgb.contiguous(), nir.contiguous(),
+             None if tir is None else tir.contiguous(), b, c, h, w, counts)
     return counts
 
 
@@ -34,8 +38,8 @@ def topk_mask(vals, k, group=1):
     return mask
 
 
-def frequency_mask(rgb, nir, tir, keep):
-    counts = freq_counts(rgb, nir, tir)
+def frequency_mask(rgb, nir, tir, keep, m4=None):
+    counts = freq_counts(rgb, nir, tir, m4)
     return topk_mask(counts, keep), counts
 
 
@@ -48,7 +52,7 @@ def attn_rollout(probs):
     return scores
 
 
-def attn_rollout_qk(layers, b, t, heads, hd):
+def attn_rollout_qk(layers, b, t, heads, hd, scale=None):
     """Rollout scores (B, H, T-1) from the per-layer (qkv, lse) pairs of the bf16 backbone, first layer first:
     r = e_cls^T A_{L-1}; r <- r A_l for l = L-2 .. 0, each A_l recomputed on the fly (no probability tensor)."""
     dev = layers[0][0].device
@@ -58,7 +62,8 @@ def attn_rollout_qk(layers, b, t, heads, hd):
     for i, (qkv, lse) in enumerate(reversed(layers)):
         last = i == len(layers) - 1
         out = scores if last else bufs[i & 1]
-        call("editor_attn_rollout_step_bf16", qkv, lse, r_in, b, t, heads, hd, hd ** -0.5, out, 1 if last else 0)
+        call(_h16(qkv, "attn_rollout_step"), qkv, lse, r_in, b, t, heads, hd, float(scale or hd ** -0.5), out,
+             1 if last else 0)
         r_in = out
     return scores
 
@@ -73,21 +78,36 @@ def mask_or(a, b=None, c=None, d=None):
 # helpers
 # ---------------------------------------------------------------------------------------------
 _WS = {}
+_WS_RETIRED = []
 
 
 def workspace(device, nfloats):
     """fp32 scratch for partial reductions (kernels never allocate): one buffer per device AND stream, so that the
-    weight-gradient products running on the side stream never share partial-sum slabs with the main stream."""
+    weight-gradient products running on the side stream never share partial-sum slabs with the main stream.
+    A buffer that was handed out is NEVER freed: a captured hipGraph keeps replaying launches that hold its address, so
+    when a later request outgrows it the old block is retired (kept alive), not returned to the allocator."""
     key = (device.type, device.index, _raw_stream(device.index if device.index is not None else torch.cuda.current_device()))
     ws = _WS.get(key)
     if ws is None or ws.numel() < nfloats:
+        if ws is not None:
+            _WS_RETIRED.append(ws)
         ws = torch.empty(max(int(nfloats), 1 << 22), dtype=torch.float32, device=device)
         _WS[key] = ws
     return ws
 
 
+_DT_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+HALF_DTYPES = (torch.bfloat16, torch.float16)
+
+
 def _is_bf16(t):
-    return 1 if t.dtype == torch.bfloat16 else 0
+    """dtype code of the C ABI (include/editor_hip.h): 0 = fp32, 1 = bf16, 2 = f16."""
+    return _DT_CODE[t.dtype]
+
+
+def _h16(t, name):
+    """entry point of the 16-bit kernel family for tensor t's dtype (editor_<name>_bf16 / _f16)."""
+    return "editor_" + name + ("_f16" if t.dtype == torch.float16 else "_bf16")
 
 
 def _ptr(t, off=0):
@@ -114,24 +134,24 @@ def layernorm_fwd(x2d, gamma, beta, eps, out_dtype, rowmask=None, mask_period=0,
 
 
 def layernorm_bwd(dy, x2d, gamma, mean, rstd, rowmask=None, mask_period=0, dx_in=None, want_param_grads=True,
-                  m_live=None):
+                  m_live=None, dy_scale=1.0):
     m, d = x2d.shape
     dx = torch.empty(m, d, dtype=torch.float32, device=x2d.device)
     dgb = torch.empty(2, d, dtype=torch.float32, device=x2d.device) if want_param_grads else None
     dg = dgb[0] if want_param_grads else None
     db = dgb[1] if want_param_grads else None
     ws = workspace(x2d.device, WS_ROWS * 2 * d)
-    call("editor_layernorm_bwd", dy, _is_bf16(dy), x2d, gamma, mean, rstd, m, d, rowmask, int(mask_period), dx_in, dx,
+    call("editor_layernorm_bwd", dy, _is_bf16(dy), float(dy_scale), x2d, gamma, mean, rstd, m, d, rowmask, int(mask_period), dx_in, dx,
          dg, db, ws, WS_ROWS, m_live)
     return dx, dg, db
 
 
-def colsum(dy, out=None):
+def colsum(dy, out=None, scale=1.0):
     m, n = dy.shape
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=dy.device)
     ws = workspace(dy.device, WS_ROWS * n)
-    call("editor_colsum", dy, _is_bf16(dy), m, n, n, out, ws, WS_ROWS)
+    call("editor_colsum", dy, _is_bf16(dy), m, n, n, out, ws, WS_ROWS, float(scale))
     return out
 
 
@@ -155,26 +175,30 @@ def cast(x, dtype):
         call("editor_cast_f32_to_bf16", x, out, x.numel())
     elif x.dtype == torch.bfloat16 and dtype == torch.float32:
         call("editor_cast_bf16_to_f32", x, out, x.numel())
+    elif x.dtype == torch.float32 and dtype == torch.float16:
+        call("editor_cast_f32_to_f16", x, out, x.numel())
+    elif x.dtype == torch.float16 and dtype == torch.float32:
+        call("editor_cast_f16_to_f32", x, out, x.numel())
     else:
         raise TypeError((x.dtype, dtype))
     return out
 
 
-def cast_rows(x2d, rowscale, dtype, m_live=None):
-    """x * rowscale[:, None] cast to `dtype` (one pass)."""
+def cast_rows(x2d, rowscale, dtype, m_live=None, scale=1.0):
+    """x * rowscale[:, None] * scale cast to `dtype` (one pass)."""
     m, d = x2d.shape
     out = torch.empty(m, d, dtype=dtype, device=x2d.device)
-    call("editor_cast_rows", x2d, rowscale, m, d, out, _is_bf16(out), m_live)
+    call("editor_cast_rows", x2d, rowscale, m, d, out, _is_bf16(out), m_live, float(scale))
     return out
 
 
-def cast_rows_colsum(x2d, rowscale, dtype):
-    """cast_rows + the column sums of its output (bias gradient) in the same pass."""
+def cast_rows_colsum(x2d, rowscale, dtype, scale=1.0):
+    """cast_rows + the column sums of its output (bias gradient, with the scale removed again) in the same pass."""
     m, d = x2d.shape
     out = torch.empty(m, d, dtype=dtype, device=x2d.device)
     cs = torch.empty(d, dtype=torch.float32, device=x2d.device)
     ws = workspace(x2d.device, WS_ROWS * d)
-    call("editor_cast_rows_colsum", x2d, rowscale, m, d, out, _is_bf16(out), cs, ws, WS_ROWS)
+    call("editor_cast_rows_colsum", x2d, rowscale, m, d, out, _is_bf16(out), cs, ws, WS_ROWS, float(scale), 1.0 / float(scale))
     return out, cs
 
 
@@ -192,14 +216,14 @@ def embed_assemble(patch, cls, pos, sie, cam, coef, btot, t, d):
     return x
 
 
-def embed_assemble_bwd(dx, cam, ncam, coef, dtype):
+def embed_assemble_bwd(dx, cam, ncam, coef, dtype, scale=1.0):
     btot, t, d = dx.shape
     dpatch = torch.empty(btot * (t - 1), d, dtype=dtype, device=dx.device)
     dpos = torch.empty(t, d, dtype=torch.float32, device=dx.device)
     dsie = torch.empty(ncam, d, dtype=torch.float32, device=dx.device) if ncam else None
     ws = workspace(dx.device, btot * d) if ncam else None
     call("editor_embed_assemble_bwd", dx, cam, 0 if cam is None else cam.numel(), int(ncam), float(coef), btot, t, d,
-         dpatch, _is_bf16(dpatch), dpos, dsie, ws)
+         dpatch, _is_bf16(dpatch), float(scale), dpos, dsie, ws)
     return dpatch, dpos, dsie
 
 
@@ -241,16 +265,17 @@ EPI_NONE, EPI_RESIDUAL, EPI_GELU, EPI_GELU_BWD = 0, 1, 2, 3
 
 
 EPI_COLSUM = 0x100
+EPI_FORCE_PP = 0x200          # run the 256x256 ping-pong kernel whatever the shape heuristic says (tests)
 
 
 def gemm_colsum_ok(m, n, k, c_dtype, trans_a, splitk, m_live):
-    """Can editor_gemm_bf16 also deliver the column sums of its (bf16) output?  (one-pass 256x256 epilogue only)"""
-    return (c_dtype == torch.bfloat16 and not trans_a and splitk == 1 and m_live is None and m >= 2048 and n >= 512
+    """Can the 16-bit GEMM also deliver the column sums of its (16-bit) output?  (one-pass 256x256 epilogue only)"""
+    return (c_dtype in HALF_DTYPES and not trans_a and splitk == 1 and m_live is None and m >= 2048 and n >= 512
             and n % 8 == 0 and k % 64 == 0)
 
 
 def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=0.0, bias=None, rowscale=None,
-         splitk=1, a_off=0, b_off=0, c_off=0, epilogue=0, aux=None, m_live=None, colsum=None):
+         splitk=1, a_off=0, b_off=0, c_off=0, epilogue=0, aux=None, m_live=None, colsum=None, colsum_scale=1.0):
     """c = alpha * op(a) op(b) (+bias) (+beta*c) (*rowscale); dtype picks the kernel family
     (fp32 -> exact-f32 MFMA, bf16 -> bf16 MFMA with fp32 accumulate; c may be fp32 for bf16 inputs)."""
     if a.dtype == torch.float32:
@@ -272,8 +297,9 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
         call("editor_gemm_f32", _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), m, n, k, lda, ldb, ldc,
              int(trans_a), int(trans_b), 1, 0, 0, 0, 1, 0, 0, 0, float(alpha), float(beta), bias, rowscale, int(splitk),
              int(epilogue), aux, n)
-    elif a.dtype == torch.bfloat16:
-        assert b.dtype == torch.bfloat16
+    elif a.dtype in HALF_DTYPES:
+        assert b.dtype == a.dtype
+        entry = _h16(a, "gemm")
         if m_live is not None and (m < 256 or n < 128 or k % 64):
             raise RuntimeError("live-row GEMM needs the pipelined path (M >= 256, N >= 128, K % 64 == 0)")
         if trans_a and trans_b and splitk > 1 and k % 64 and k > 64 and m_live is None and beta == 0.0:
@@ -291,19 +317,19 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
             assert gemm_colsum_ok(m, n, k, c.dtype, trans_a, splitk, m_live) and ldc == n
             tiles_m = (m + 255) // 256
             part = workspace(a.device, tiles_m * n)
-            call("editor_gemm_bf16", _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), 0, m, n, k, lda, ldb, ldc,
+            call(entry, _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), 0, m, n, k, lda, ldb, ldc,
                  int(trans_a), int(trans_b), float(alpha), float(beta), bias, rowscale, 1, int(epilogue) | EPI_COLSUM, aux,
                  n, part, None)
-            call("editor_reduce_rows", part, tiles_m, n, colsum, 0, 1.0)
+            call("editor_reduce_rows", part, tiles_m, n, colsum, 0, float(colsum_scale))
             return
-        call("editor_gemm_bf16", _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), 1 if c.dtype == torch.float32 else 0,
+        call(entry, _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), 1 if c.dtype == torch.float32 else 0,
              m, n, k, lda, ldb, ldc, int(trans_a), int(trans_b), float(alpha), float(beta), bias, rowscale, int(splitk),
              int(epilogue), aux, n, workspace(a.device, int(splitk) * m * n) if splitk > 1 else None, m_live)
     else:
         raise TypeError(a.dtype)
 
 
-def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True, cu=None):
+def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True, cu=None, scale=None):
     """Attention / AttentionMask core on packed qkv (rows, 3*heads*hd) -> (rows, heads*hd).
     Dense: rows = b*t.  Variable length (compacted HMA): cu (b+1 int32) = packed row range of every sequence,
     t = longest sequence; rows outside every sequence (padding) come out as zeros.
@@ -311,7 +337,7 @@ def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True, cu
     the per-row log-sum-exp in bf16 mode."""
     d = heads * hd
     rows = qkv.shape[0]
-    scale = hd ** -0.5
+    scale = float(scale or hd ** -0.5)          # qk_scale of the architecture (vit_pytorch.py:176), default head_dim ** -0.5
     if qkv.dtype == torch.float32:
         if cu is not None:
             raise RuntimeError("variable-length attention exists in the bf16 kernels only (f32 = dense parity mode)")
@@ -322,13 +348,13 @@ def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True, cu
         return out, probs
     out = (torch.zeros if cu is not None else torch.empty)(rows, d, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(heads * rows, dtype=torch.float32, device=qkv.device) if want_lse else None
-    call("editor_attention_fwd_bf16", qkv, b, t, heads, hd, scale, mask, out, probs,
+    call(_h16(qkv, "attention_fwd"), qkv, b, t, heads, hd, scale, mask, out, probs,
          0 if probs is None else probs.shape[-1], lse, cu, rows)
     return out, lse
 
 
-def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None, cu=None):
-    scale = hd ** -0.5
+def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None, cu=None, scale=None):
+    scale = float(scale or hd ** -0.5)
     rows = qkv.shape[0]
     if qkv.dtype == torch.float32:
         dqkv = torch.empty_like(qkv)
@@ -337,7 +363,7 @@ def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None, c
     else:
         dqkv = torch.zeros_like(qkv) if cu is not None else torch.empty_like(qkv)
         ws = torch.empty(heads * rows, dtype=torch.float32, device=qkv.device)
-        call("editor_attention_bwd_bf16", qkv, dout, out, saved, b, t, heads, hd, scale, mask, dqkv, ws, cu, rows)
+        call(_h16(qkv, "attention_bwd"), qkv, dout, out, saved, b, t, heads, hd, scale, mask, dqkv, ws, cu, rows)
     return dqkv
 
 

@@ -1,6 +1,17 @@
 """Fused SGD for the EDITOR training step (row N4 of SURVEY.md 8(f)): the per-parameter groups of
 solver/make_optimizer.py:4-29 (SGD, momentum 0.9, weight decay 1e-4, lr x2 for biases) applied to all ~200 parameter
-tensors in ONE HIP launch (editor_sgd_multi) instead of torch's three foreach passes."""
+tensors in ONE HIP launch (editor_sgd_multi) instead of torch's three foreach passes.
+
+The object quacks like the torch.optim.SGD the reference builds: `param_groups` is one dict per trainable parameter
+(make_optimizer.py:19 appends a group per parameter) carrying 'params', 'lr', 'weight_decay', 'momentum', so the
+reference's scheduler (solver/scheduler.py:76-80 writes param_group['lr']) and amp.GradScaler.step (iterates
+param_groups) drive it unchanged; `state_dict()` / `load_state_dict()` use torch.optim.SGD's layout
+({'state': {i: {'momentum_buffer'}}, 'param_groups'}).
+
+hipGraph-replay safety: the kernel reads lr / weight decay from per-tensor DEVICE tables.  Hyper-parameter changes
+are pushed into those tables in place by `sync_param_groups()` (called by step() outside capture, and by
+editor_amd.solver's scheduler), so a captured step replays with the new values; a change made while a stream is
+capturing is refused instead of being baked into the graph."""
 import torch
 
 from . import _lib
@@ -8,49 +19,119 @@ from . import _lib
 
 class FusedSGD:
     def __init__(self, named_params, base_lr=1e-3, weight_decay=1e-4, bias_lr_factor=2.0, weight_decay_bias=1e-4,
-                 momentum=0.9, shadow_bf16=True):
+                 momentum=0.9, shadow_bf16=True, shadow_dtype=None):
         self.params = [(n, p) for n, p in named_params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FusedSGD: no trainable parameters")
         dev = self.params[0][1].device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedSGD updates parameters with a HIP kernel: move the model to the GPU first")
         self.device = dev
-        self.momentum = momentum
-        self.first = True
+        self.momentum = float(momentum)
+        self.defaults = dict(lr=base_lr, momentum=momentum, weight_decay=weight_decay, dampening=0, nesterov=False)
         chunk = _lib.lib().cdll.editor_sgd_chunk_elems()
-        lrs, wds, numel, chunk_t, chunk_o = [], [], [], [], []
+        numel, chunk_t, chunk_o = [], [], []
+        self.param_groups = []
         for i, (name, p) in enumerate(self.params):
             is_bias = "bias" in name                                   # make_optimizer.py:12-14
-            lrs.append(base_lr * bias_lr_factor if is_bias else base_lr)
-            wds.append(weight_decay_bias if is_bias else weight_decay)
+            self.param_groups.append({"params": [p], "name": name,
+                                      "lr": base_lr * bias_lr_factor if is_bias else base_lr,
+                                      "weight_decay": weight_decay_bias if is_bias else weight_decay,
+                                      "momentum": self.momentum, "dampening": 0, "nesterov": False})
             numel.append(p.numel())
             for off in range(0, p.numel(), chunk):
                 chunk_t.append(i)
                 chunk_o.append(off)
+        n = len(self.params)
         self.bufs = [torch.zeros_like(p, memory_format=torch.contiguous_format) for _, p in self.params]
-        self.lr = torch.tensor(lrs, dtype=torch.float32, device=dev)
-        self.wd = torch.tensor(wds, dtype=torch.float32, device=dev)
+        self.lr = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.wd = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(2, n, dtype=torch.float32).pin_memory()
+        self._hyper_cached = None
+        self.sync_param_groups()
         self.numel = torch.tensor(numel, dtype=torch.int64, device=dev)
         self.chunk_t = torch.tensor(chunk_t, dtype=torch.int32, device=dev)
         self.chunk_o = torch.tensor(chunk_o, dtype=torch.int64, device=dev)
         self.nchunks = len(chunk_t)
-        # bf16 shadows of the GEMM weights (>= 2-D parameters): written by the update kernel itself and handed to the
+        # 16-bit shadows of the GEMM weights (>= 2-D parameters): written by the update kernel itself and handed to the
         # operand cache of editor_amd.functional, instead of one cast launch per weight at the next forward
-        self.shadows = [torch.empty(p.shape, dtype=torch.bfloat16, device=dev) if (shadow_bf16 and p.dim() >= 2) else None
-                        for _, p in self.params]
+        if shadow_dtype is None:
+            shadow_dtype = torch.bfloat16 if shadow_bf16 else None
+        self.shadow_dtype = shadow_dtype
+        self.shadows = [torch.empty(p.shape, dtype=shadow_dtype, device=dev) if (shadow_dtype is not None and p.dim() >= 2)
+                        else None for _, p in self.params]
         self.h_ptrs = torch.tensor([0 if h is None else h.data_ptr() for h in self.shadows], dtype=torch.int64, device=dev)
         self.p_ptrs = torch.tensor([p.data_ptr() for _, p in self.params], dtype=torch.int64, device=dev)
         self.m_ptrs = torch.tensor([b.data_ptr() for b in self.bufs], dtype=torch.int64, device=dev)
         # gradient tensors are new every step: their addresses go to the device through double-buffered pinned staging
         # (an event per buffer keeps the host from overwriting a table whose async copy has not executed yet)
-        self._g_host = [torch.zeros(len(self.params), dtype=torch.int64).pin_memory() for _ in range(2)]
-        self._g_dev = [torch.zeros(len(self.params), dtype=torch.int64, device=dev) for _ in range(2)]
-        self._g_host_cap = torch.zeros(len(self.params), dtype=torch.int64).pin_memory()   # table of a captured step
-        self._g_dev_cap = torch.zeros(len(self.params), dtype=torch.int64, device=dev)
+        self._g_host = [torch.zeros(n, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self._g_dev = [torch.zeros(n, dtype=torch.int64, device=dev) for _ in range(2)]
+        self._g_host_cap = torch.zeros(n, dtype=torch.int64).pin_memory()   # table of a captured step
+        self._g_dev_cap = torch.zeros(n, dtype=torch.int64, device=dev)
         self._ev = [None, None]
         self._slot = 0
         self._keep = [None, None]
 
+    # -- torch.optim.Optimizer surface --------------------------------------------------------------------
     def zero_grad(self, set_to_none=True):
         for _, p in self.params:
-            p.grad = None
+            if set_to_none or p.grad is None:
+                p.grad = None
+            else:
+                p.grad.zero_()
+
+    def sync_param_groups(self):
+        """Push param_groups' lr / weight_decay into the device tables the kernel reads (in place: replay safe)."""
+        vals = ([float(g["lr"]) for g in self.param_groups], [float(g["weight_decay"]) for g in self.param_groups])
+        if vals == self._hyper_cached:
+            return False
+        for g in self.param_groups:
+            if float(g.get("momentum", self.momentum)) != self.momentum or g.get("nesterov") or g.get("dampening"):
+                raise NotImplementedError("FusedSGD: one momentum for all groups, no dampening / nesterov "
+                                          "(solver/make_optimizer.py:24 uses neither)")
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FusedSGD: learning rate / weight decay changed during hipGraph capture; "
+                               "change it between replays (the tables are read from device memory)")
+        torch.cuda.current_stream(self.device).synchronize()     # the pinned staging row may still be in flight
+        self._hyper_host[0] = torch.tensor(vals[0], dtype=torch.float32)
+        self._hyper_host[1] = torch.tensor(vals[1], dtype=torch.float32)
+        self.lr.copy_(self._hyper_host[0], non_blocking=True)
+        self.wd.copy_(self._hyper_host[1], non_blocking=True)
+        self._hyper_cached = vals
+        return True
+
+    def set_lr(self, lr):
+        """lr: one float for every group, or one value per group (same order as param_groups)."""
+        if not isinstance(lr, (list, tuple)):
+            lr = [lr] * len(self.param_groups)
+        for g, v in zip(self.param_groups, lr):
+            g["lr"] = float(v)
+        self.sync_param_groups()
+
+    def state_dict(self):
+        groups = []
+        for i, g in enumerate(self.param_groups):
+            d = {k: v for k, v in g.items() if k != "params"}
+            d["params"] = [i]
+            groups.append(d)
+        return {"state": {i: {"momentum_buffer": b.detach().clone()} for i, b in enumerate(self.bufs)},
+                "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        if len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError("FusedSGD.load_state_dict: parameter group count differs")
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            for k, v in s.items():
+                if k != "params":
+                    g[k] = v
+        for i, b in enumerate(self.bufs):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is not None and st.get("momentum_buffer") is not None:
+                b.copy_(st["momentum_buffer"])
+            else:
+                b.zero_()
+        self.sync_param_groups()
 
     @torch.no_grad()
     def step(self):
@@ -61,6 +142,7 @@ class FusedSGD:
             # no events, no host waits
             host, dev_tab, k = self._g_host_cap, self._g_dev_cap, None    # (allocated up front: pinning is not capturable)
         else:
+            self.sync_param_groups()
             k = self._slot
             self._slot ^= 1
             if self._ev[k] is not None:
@@ -81,15 +163,19 @@ class FusedSGD:
         else:
             self._keep[k] = grads                                        # keep the tensors alive until the kernel ran
         dev_tab.copy_(host, non_blocking=True)
-        _lib.call("editor_sgd_multi", self.p_ptrs, dev_tab, self.m_ptrs, self.chunk_t, self.chunk_o, self.numel,
-                  self.lr, self.wd, float(self.momentum), 1 if self.first else 0, self.nchunks, self.h_ptrs)
+        # momentum buffers start at zero, so mu*0 + g' == g' reproduces torch's first-step `buf = clone(g')` exactly
+        # without a "first step" flag (a flag passed by value would be baked into a captured graph)
+        with torch.cuda.device(self.device):
+            _lib.call("editor_sgd_multi", self.p_ptrs, dev_tab, self.m_ptrs, self.chunk_t, self.chunk_o, self.numel,
+                      self.lr, self.wd, float(self.momentum), self.nchunks, self.h_ptrs,
+                      2 if self.shadow_dtype == torch.float16 else 1)
         if not capturing:
             self._ev[k] = torch.cuda.Event()
             self._ev[k].record()
-        self.first = False
-        # the kernel wrote the parameters behind autograd's back: tell the bf16 operand cache (version counters did not
+        # the kernel wrote the parameters behind autograd's back: tell the operand cache (version counters did not
         # move) and hand it the shadows of the weights that just got a gradient
         from . import functional
         functional.invalidate_weight_cache()
-        functional.install_weight_copies((p, h) for (_, p), h in zip(self.params, self.shadows)
-                                         if h is not None and p.grad is not None)
+        if self.shadow_dtype is not None:
+            functional.install_weight_copies((p, h) for (_, p), h in zip(self.params, self.shadows)
+                                             if h is not None and p.grad is not None)

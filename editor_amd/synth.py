@@ -65,13 +65,13 @@ def integers(seed, name, shape, high):
     return torch.from_numpy((w % np.uint64(high)).astype(np.int64).reshape(shape))
 
 
-def make_batch(seed, batch, height, width, cams, instances=16, smooth=False):
+def make_batch(seed, batch, height, width, cams, instances=16, smooth=False, keys=("RGB", "NI", "TI")):
     """Tri-modal synthetic batch in the reference's collate layout
     (/root/reference/engine/processor.py:73-81): dict of (B,3,H,W) fp32 +
     label / cam_label / view_label int64.  label = P identities x K contiguous
     instances (the layout OCFR assumes, modeling/fusion_part/OCFR.py:33-39)."""
     img = {}
-    for key in ("RGB", "NI", "TI"):
+    for key in keys:
         img[key] = uint8_image(seed, "img/" + key, (batch, 3, height, width))
         if smooth:
             # low-pass variant: makes the per-patch positive counts spread out

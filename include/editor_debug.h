@@ -1,0 +1,25 @@
+/* Debug / bring-up entry points.  NOT part of libeditor_hip.so: they live in separate shared objects that only tests
+ * and tools load, so that the product library keeps its contract (include/editor_hip.h: no allocation, no
+ * synchronisation, no environment lookups inside an entry point).
+ *
+ *   editor_amd/libeditor_probe.so   csrc/probe.hip - hardware-semantics probes used by tests/test_gpu_select.py
+ *   editor_amd/libeditor_gemm_trace.so   csrc/gemm_bf16.hip compiled with -DEDITOR_DEBUG_TRACE: the same
+ *       editor_gemm_bf16 / editor_gemm_f16 symbols, plus (EDITOR_GEMM_TRACE=1 in the environment) a per-workgroup
+ *       s_memtime timeline printed per launch - this build allocates a device buffer and synchronises; the
+ *       EDITOR_GEMM_PP / EDITOR_GEMM_PP_STAGED experiment switches exist only here.  Built on demand by
+ *       `python -m editor_amd.build --trace`; used by tools/gemm_bench.py. */
+#ifndef EDITOR_DEBUG_H
+#define EDITOR_DEBUG_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct ihipStream_t* editor_stream_t;
+/* what ds_read_b64_tr_b16 returns for a known LDS image (lds[i] = i as u16): lane l reads at byte address addr[l] */
+int editor_probe_tr16(const int* addr, uint16_t* out, editor_stream_t stream);
+/* lane -> element maps of v_mfma_f32_16x16x32_bf16: D (16x16) = A (16x32) B (32x16), operands given as fp32 */
+int editor_probe_mfma16(const float* A, const float* B, float* D, editor_stream_t stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -9,9 +9,15 @@
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator); kernels never
  *     allocate or free; workspaces are passed in;
  *   - every launch is asynchronous on `stream` (hipStream_t; pass torch.cuda.current_stream().cuda_stream);
- *   - return value is a hipError_t as int (0 = success); no exceptions, no global mutable state;
- *   - dtype suffix: _f32 = float activations, _bf16 = bfloat16 activations (raw uint16 bits);
+ *   - return value is a hipError_t as int (0 = success); no exceptions, no global mutable state, no environment
+ *     lookups, no allocation or synchronisation inside an entry point (measurement hooks live in separate debug
+ *     libraries: include/editor_debug.h);
+ *   - dtype suffix: _f32 = float activations, _bf16 = bfloat16 activations, _f16 = IEEE half activations (raw
+ *     uint16 bits); arguments named `*_bf16` / `dtype` are dtype CODES: 0 = fp32, 1 = bf16, 2 = f16;
  *     statistics, residual stream, losses and parameter gradients are always fp32;
+ *   - f16 activations carry LOSS-SCALED gradients (as the reference's amp.GradScaler does, engine/processor.py:94):
+ *     the `scale` arguments of the cast / column-sum / LayerNorm-backward entry points apply and remove a
+ *     power-of-two factor, so results equal the unscaled computation whenever nothing under- or overflows;
  *   - masks are uint8 (0/1), row-major; token rows are (sample, token) row-major.
  */
 #ifndef EDITOR_HIP_H
@@ -31,6 +37,8 @@ typedef struct ihipStream_t* editor_stream_t;   /* == hipStream_t */
 #define EDITOR_EPI_COLSUM 0x100 /* OR-able (editor_gemm_bf16, bf16 C, M >= 2048, N >= 512, A k-major, splitk 1): also write
                                  * the column sums of every 256-row tile of the ROUNDED C to splitk_ws[(M+255)/256][N] - the bias
                                  * gradient of the layer this gradient feeds, folded by editor_reduce_rows */
+#define EDITOR_EPI_FORCE_PP 0x200 /* OR-able: run the 256x256 ping-pong kernel whatever the shape heuristic says (N >= 256,
+                                   * whole 64-deep K-tiles); tests use it to reach that kernel's edge cases */
 
 /* ---- token selection (non-differentiable) ---------------------------------------------------- */
 
@@ -40,6 +48,11 @@ typedef struct ihipStream_t* editor_stream_t;   /* == hipStream_t */
  * counts: (B, H/16*W/16) int32, patches row-major as PatchEmbed flattens them (vit_pytorch.py:457). */
 int editor_freq_counts_f32(const float* rgb, const float* nir, const float* tir, int B, int C, int H, int W,
                            int32_t* counts, editor_stream_t stream);
+
+/* the same for 2..4 modalities given explicitly (nmod = 4: the synthetic 4-modal configuration; the mean of
+ * Frequency.py:71-74 over one more term) */
+int editor_freq_counts_nmod_f32(const float* m0, const float* m1, const float* m2, const float* m3, int nmod, int B, int C,
+                                int H, int W, int32_t* counts, editor_stream_t stream);
 
 /* torch.topk(k) -> sort -> scatter_ to a bool row (Frequency.py:58-62, SFTS.py:155-158) with torch's CPU tie
  * order (libstdc++ partial_sort if k*64<=n else nth_element).  vals: (rows,n); `group` consecutive rows OR
@@ -67,27 +80,31 @@ int editor_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
                          const int* m_live, editor_stream_t stream);
 /* backward: dx_out = (dx_in ? dx_in : 0) + dLN/dx ; dgamma/dbeta: ONE (2,D) fp32 buffer (dbeta == dgamma + D; NULL to
  * skip).  workspace: ws_rows*2*D floats. */
-int editor_layernorm_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
+int editor_layernorm_bwd(const void* dy, int dy_bf16, float dy_scale /* dy is multiplied by it on load */,
+                         const float* x, const float* gamma, const float* mean,
                          const float* rstd, long M, int D, const uint8_t* rowmask, int mask_period,
                          const float* dx_in, float* dx_out, float* dgamma, float* dbeta, float* workspace,
                          int ws_rows, const int* m_live, editor_stream_t stream);
-/* out[n] = sum_m dy[m,n]  (bias gradients of every nn.Linear).  workspace: ws_rows*N floats. */
+/* out[n] = scale * sum_m dy[m,n]  (bias gradients of every nn.Linear).  workspace: ws_rows*N floats. */
 int editor_colsum(const void* dy, int dy_bf16, long M, int N, long ld, float* out, float* workspace, int ws_rows,
-                  editor_stream_t stream);
+                  float scale, editor_stream_t stream);
 int editor_reduce_rows(const float* partials, int P, long ncol, float* out, int accumulate, float scale,
                        editor_stream_t stream);
 /* nn.GELU() exact erf (vit_pytorch.py:130,141) and its derivative */
 int editor_gelu_fwd(const void* a, void* g, long n, int bf16, editor_stream_t stream);
 int editor_gelu_bwd(const void* a, const void* dg, void* da, long n, int bf16, editor_stream_t stream);
 int editor_cast_f32_to_bf16(const float* in, uint16_t* out, long n, editor_stream_t stream);
-/* out[m,:] = in[m,:] * rowscale[m] (rowscale may be NULL): fp32 gradient -> GEMM operand dtype, with the
- * per-sample drop-path factor keep/keep_prob of vit_pytorch.py:52-69 folded in. */
+int editor_cast_f32_to_f16(const float* in, uint16_t* out, long n, editor_stream_t stream);
+int editor_cast_f16_to_f32(const uint16_t* in, float* out, long n, editor_stream_t stream);
+/* out[m,:] = in[m,:] * rowscale[m] * scale (rowscale may be NULL): fp32 gradient -> GEMM operand dtype, with the
+ * per-sample drop-path factor keep/keep_prob of vit_pytorch.py:52-69 (and the f16 loss scale) folded in. */
 int editor_cast_rows(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16,
-                     const int* m_live, editor_stream_t stream);
+                     const int* m_live, float scale, editor_stream_t stream);
 /* editor_cast_rows plus colsum[d] = sum_m out[m,d] (the rounded values): the bias gradient of the nn.Linear that `out`
  * feeds, without another pass over it.  D a multiple of 256; workspace: ws_rows*D floats. */
 int editor_cast_rows_colsum(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16, float* colsum,
-                            float* workspace, int ws_rows, editor_stream_t stream);
+                            float* workspace, int ws_rows, float scale, float colsum_scale /* applied to colsum only */,
+                            editor_stream_t stream);
 int editor_cast_bf16_to_f32(const uint16_t* in, float* out, long n, editor_stream_t stream);
 
 /* PatchEmbed_overlap with stride == patch == 16 (vit_pytorch.py:449-458): im2col rows (b*N+p), cols (c,i,j). */
@@ -98,8 +115,8 @@ int editor_embed_assemble(const void* patch, int patch_bf16, const float* cls, c
                           const long* cam, int Bcam, float coef, long Btot, int T, int D, float* x,
                           editor_stream_t stream);
 int editor_embed_assemble_bwd(const float* dx, const long* cam, int Bcam, int ncam, float coef, long Btot, int T, int D,
-                              void* dpatch, int dpatch_bf16, float* dpos, float* dsie, float* workspace /* Btot*D */,
-                              editor_stream_t stream);
+                              void* dpatch, int dpatch_bf16, float dpatch_scale, float* dpos, float* dsie,
+                              float* workspace /* Btot*D */, editor_stream_t stream);
 
 /* SFTS.forward mask application + BCC loss (SFTS.py:208-225).  feat/out: (nmod,B,T,D) fp32; index (B,T-1) uint8;
  * loss (1) fp32 or NULL (eval); workspace: ws_len floats. */
@@ -134,6 +151,12 @@ int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, i
                      float* splitk_ws /* splitk*M*N floats or NULL (then split-K uses fp32 atomics) */,
                      const int* m_live /* see below */, editor_stream_t stream);
 
+/* the same contraction on IEEE-half operands (v_mfma_f32_16x16x32_f16): C half or fp32 */
+int editor_gemm_f16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda, long ldb,
+                    long ldc, int transA, int transB, float alpha, float beta, const float* bias,
+                    const float* rowscale, int splitk, int epilogue, void* aux, long ldaux, float* splitk_ws,
+                    const int* m_live, editor_stream_t stream);
+
 /* m_live (device int32 scalar, may be NULL) - compacted HMA without a host round trip: buffers and launches are sized
  * for the worst-case row count, only the first *m_live token rows are live.  Row kernels process rows below
  * roundup64(*m_live) (rows in [*m_live, roundup64) carry mask 0 / zeros), GEMMs skip tiles of dead rows (forward, dgrad)
@@ -153,8 +176,12 @@ int editor_attention_bwd_f32(const float* qkv, const float* dout, const float* p
  * r[1:] (the CLS->patch scores); otherwise (B*heads, T).  Dense, unmasked sequences (the backbone). */
 int editor_attn_rollout_step_bf16(const uint16_t* qkv, const float* lse, const float* r_in, int B, int T, int heads, int hd,
                                   float scale, float* r_out, int final_step, editor_stream_t stream);
+int editor_attn_rollout_step_f16(const uint16_t* qkv, const float* lse, const float* r_in, int B, int T, int heads, int hd,
+                                 float scale, float* r_out, int final_step, editor_stream_t stream);
 
-/* Fused bf16 form (hd must be 64; T <= 608).  probs optional (NULL skips the write).  lse (heads*Mtot fp32, log2 units
+/* Fused 16-bit form (hd must be 64).  T <= 608: one workgroup per (sample, head) with the whole key range in LDS.
+ * T > 608 (joint HMA block of the 4-modal 512-token configuration): 64 own rows per workgroup, the other side streamed
+ * through LDS in 256-row chunks; mask and probs must be NULL there.  probs optional (NULL skips the write).  lse (heads*Mtot fp32, log2 units
  * of the scaled scores, +inf for masked queries) is written by the forward (NULL to skip) and consumed by the backward,
  * which recomputes the probabilities from it; `out` is the forward output (delta = rowsum(dO*O));
  * workspace: heads*Mtot floats.  Variable-length (compacted HMA) form: cu (B+1 int32) gives each sequence's packed row
@@ -165,6 +192,12 @@ int editor_attention_fwd_bf16(const uint16_t* qkv, int B, int T, int heads, int 
 int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, int B,
                               int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv,
                               float* workspace, const int* cu, long Mtot, editor_stream_t stream);
+int editor_attention_fwd_f16(const uint16_t* qkv, int B, int T, int heads, int hd, float scale, const uint8_t* mask,
+                             uint16_t* out, float* probs, int ldp, float* lse, const int* cu, long Mtot,
+                             editor_stream_t stream);
+int editor_attention_bwd_f16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, int B,
+                             int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv,
+                             float* workspace, const int* cu, long Mtot, editor_stream_t stream);
 
 /* ---- compacted (variable-length) HMA: packing plan and row movement (csrc/compact.hip) ------------------ */
 /* index (B,N) uint8 -> cu (B+1): exclusive prefix sum of L_b = 1 + #selected; tok (>= cu[B] ints): token id (0 = cls,
@@ -252,21 +285,19 @@ int editor_augment_u8(const uint8_t* in, const int* params, int B, int H, int W,
 /* torch.optim.SGD(momentum, weight_decay, dampening 0) over many tensors in one launch.  Pointer tables and per-tensor
  * lr / wd live in device memory; chunk c covers elements [chunk_off[c], +editor_sgd_chunk_elems()) of tensor chunk_tensor[c].
  * g_ptrs[t] == NULL skips tensor t.  first != 0: momentum buffers are initialised with the (decayed) gradient.
- * h_ptrs (optional table, entries may be NULL): bf16 shadow of the updated tensor - the GEMM operand copy - written in
- * the same pass instead of by one cast launch per weight. */
+ * h_ptrs (optional table, entries may be NULL): 16-bit shadow of the updated tensor - the GEMM operand copy - written in
+ * the same pass instead of by one cast launch per weight; shadow_dtype: 1 = bf16, 2 = f16.
+ * Momentum buffers must start at zero: mu*0 + g' reproduces torch's first-step `buf = g'` exactly (no "first" flag that
+ * a captured hipGraph would bake in). */
 int editor_sgd_multi(float* const* p_ptrs, const float* const* g_ptrs, float* const* m_ptrs, const int* chunk_tensor,
                      const long* chunk_off, const long* numel, const float* lr, const float* wd, float momentum,
-                     int first, long nchunks, uint16_t* const* h_ptrs, editor_stream_t stream);
+                     long nchunks, uint16_t* const* h_ptrs, int shadow_dtype, editor_stream_t stream);
 /* per-row drop-path scales keep/keep_prob for L blocks x 2 branches x B samples, expanded over T tokens:
  * scales (L,2,B*T) fp32; rates (L) fp32 on device; counter-based RNG keyed by `seed`. */
 int editor_droppath_scales(const float* rates, int L, long B, int T, long seed, float* scales, editor_stream_t stream);
 /* the same with the seed in DEVICE memory: state[0] keys this draw and is advanced by one afterwards, so a captured
  * hipGraph of the training step draws fresh masks on every replay */
 int editor_droppath_scales_dev(const float* rates, int L, long B, int T, long* state, float* scales, editor_stream_t stream);
-
-/* ---- bring-up probes (tests only) ------------------------------------------------------------- */
-int editor_probe_tr16(const int* addr, uint16_t* out, editor_stream_t stream);
-int editor_probe_mfma16(const float* A, const float* B, float* D, editor_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -118,10 +118,11 @@ def haar_idwt2(ll, highs):
     return ll
 
 
-def frequency_counts(rgb, nir, tir, window=16, levels=4):
+def frequency_counts(rgb, nir, tir, window=16, levels=4, extra=()):
     """Per-patch count of positive pixels of IDWT(mean_m DWT(x_m)) averaged over channels
-    (Frequency.py:65-80 and :42-56).  Returns int32 (B, H/window * W/window), row-major patches."""
-    mods = [m for m in (rgb, nir, tir) if m is not None]
+    (Frequency.py:65-80 and :42-56).  Returns int32 (B, H/window * W/window), row-major patches.
+    extra: further modalities (the 4-modal extension of BASELINE config 5 - the same mean over one more term)."""
+    mods = [m for m in (rgb, nir, tir) + tuple(extra) if m is not None]
     coeffs = [haar_dwt2(m.float(), levels) for m in mods]
     nm = float(len(mods))
     low = sum(c[0] for c in coeffs) / nm
@@ -132,8 +133,8 @@ def frequency_counts(rgb, nir, tir, window=16, levels=4):
     return pos.sum(dim=(2, 4)).to(torch.int32).reshape(b, -1), inv
 
 
-def frequency_mask(rgb, nir, tir, keep=10, window=16):
-    counts, _ = frequency_counts(rgb, nir, tir, window)
+def frequency_mask(rgb, nir, tir, keep=10, window=16, extra=()):
+    counts, _ = frequency_counts(rgb, nir, tir, window, extra=extra)
     return topk_mask(counts, int(keep)), counts
 
 
@@ -151,7 +152,7 @@ def _drop_path(x, keep_mask, keep_prob):
     return x / keep_prob * keep_mask.view(-1, 1, 1)
 
 
-def vit_block(x, sd, p, heads, eps=1e-6, keep=None, keep_prob=1.0):
+def vit_block(x, sd, p, heads, eps=1e-6, keep=None, keep_prob=1.0, qk_scale=None):
     """Block.forward(get_att=True) (vit_pytorch.py:215-220) with Attention (:184-198), Mlp (:139-145)."""
     b, t, d = x.shape
     hd = d // heads
@@ -159,7 +160,7 @@ def vit_block(x, sd, p, heads, eps=1e-6, keep=None, keep_prob=1.0):
     qkv = F.linear(h, sd[p + ".attn.qkv.weight"], sd.get(p + ".attn.qkv.bias"))
     qkv = qkv.reshape(b, t, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    attn = (q @ k.transpose(-2, -1)) * (hd ** -0.5)
+    attn = (q @ k.transpose(-2, -1)) * (qk_scale or hd ** -0.5)       # vit_pytorch.py:176: qk_scale or head_dim ** -0.5
     attn = attn.softmax(dim=-1)
     o = (attn @ v).transpose(1, 2).reshape(b, t, d)
     o = F.linear(o, sd[p + ".attn.proj.weight"], sd.get(p + ".attn.proj.bias"))
@@ -173,7 +174,7 @@ def vit_block(x, sd, p, heads, eps=1e-6, keep=None, keep_prob=1.0):
 
 
 def vit_forward(sd, img, cam, heads=12, sie_coef=3.0, prefix="BACKBONE.base", drop_keep=None,
-                drop_rates=None):
+                drop_rates=None, qk_scale=None):
     """Trans.forward (vit_pytorch.py:623-644).  drop_keep: optional (depth, B) 0/1 keep masks."""
     w = sd[prefix + ".patch_embed.proj.weight"]
     x = F.conv2d(img, w, sd[prefix + ".patch_embed.proj.bias"], stride=w.shape[-1])
@@ -191,7 +192,7 @@ def vit_forward(sd, img, cam, heads=12, sie_coef=3.0, prefix="BACKBONE.base", dr
         keep, kp = None, 1.0
         if drop_keep is not None and drop_rates is not None and drop_rates[i] > 0:
             keep, kp = drop_keep[i].to(x.dtype), 1.0 - drop_rates[i]
-        x, a = vit_block(x, sd, f"{prefix}.blocks.{i}", heads, 1e-6, keep, kp)
+        x, a = vit_block(x, sd, f"{prefix}.blocks.{i}", heads, 1e-6, keep, kp, qk_scale)
         attns.append(a)
     return _ln(x, sd, prefix + ".norm", 1e-6), attns
 
@@ -258,10 +259,10 @@ def _masked_mlp(x, mask, sd, p):
     return F.linear(F.gelu(F.linear(x, sd[p + ".fc1.weight"])), sd[p + ".fc2.weight"])
 
 
-def hma_modality_blocks(feats, mask, sd, prefix="FUSE_block", heads=12):
+def hma_modality_blocks(feats, mask, sd, prefix="FUSE_block", heads=12, tags=("R", "N", "T")):
     """The three per-modality masked blocks (vit_pytorch.py:310-317). mask: (B,T,1) float."""
     out = []
-    for f, tag in zip(feats, ("R", "N", "T")):
+    for f, tag in zip(feats, tags):
         f = f + _masked_attention(_ln(f, sd, f"{prefix}.norm{tag}", 1e-5), mask, sd,
                                   f"{prefix}.attn{tag}", heads)
         f = f + _masked_mlp(_ln(f, sd, f"{prefix}.norm{tag}_", 1e-5), mask, sd, f"{prefix}.mlp{tag}")
@@ -309,19 +310,27 @@ def _bn1d(x, sd, p, training, momentum=0.1, eps=1e-5):
                         sd[p + ".bias"], training, momentum, eps)
 
 
+# the reference's three modalities: (input key, name of the REDUCE layer / centre table, BlockMask tag)
+MODALITIES3 = (("RGB", "RGB", "R"), ("NI", "NIR", "N"), ("TI", "TIR", "T"))
+# 4-modal extension (BASELINE.json config 5; no counterpart in the reference, whose forward hard-codes three keys,
+# make_model.py:153-155): the same computation with one more term in every per-modality loop / sum / OR / concat
+MODALITIES4 = MODALITIES3 + (("M4", "M4", "M4"),)
+
+
 def editor_forward(sd, x, cam, label=None, training=False, al=1, head_keep=2, frequency_keep=10,
                    heads=12, hma_heads=12, sie_coef=3.0, drop_keep=None, drop_rates=None,
-                   teacher_index=None, return_aux=False):
+                   teacher_index=None, return_aux=False, modalities=MODALITIES3, qk_scale=None):
     """EDITOR.forward (make_model.py:150-258).  `sd` maps state-dict names to tensors (leaf
     tensors requiring grad for a backward run; BN running stats / OCFR centres are mutated).
     teacher_index: optional (B,N) bool to force the SFTS selection (bf16 protocol)."""
-    rgb, nir, tir = x["RGB"], x["NI"], x["TI"]
+    imgs = [x[m[0]] for m in modalities]
+    nmod = len(imgs)
     aux = {}
-    mask_fre, counts = frequency_mask(rgb, nir, tir, frequency_keep)
+    mask_fre, counts = frequency_mask(imgs[0], imgs[1], imgs[2] if nmod > 2 else None, frequency_keep, extra=imgs[3:])
     feats, masks, scores = [], [], []
-    for img, dk in zip((rgb, nir, tir), (0, 1, 2)):
+    for img, dk in zip(imgs, range(nmod)):
         dkm = None if drop_keep is None else drop_keep[dk]
-        f, attns = vit_forward(sd, img, cam, heads, sie_coef, drop_keep=dkm, drop_rates=drop_rates)
+        f, attns = vit_forward(sd, img, cam, heads, sie_coef, drop_keep=dkm, drop_rates=drop_rates, qk_scale=qk_scale)
         n = f.shape[1] - 1
         k = int(n * ((1 / n) * int(head_keep)))                 # make_model.py:92, SFTS.py:155
         with torch.no_grad():
@@ -329,7 +338,9 @@ def editor_forward(sd, x, cam, label=None, training=False, al=1, head_keep=2, fr
         feats.append(f)
         scores.append(sc)
         masks.append(part_attention_mask(sc, k))
-    index = masks[0] | masks[1] | masks[2] | mask_fre
+    index = mask_fre
+    for mk in masks:
+        index = index | mk
     if teacher_index is not None:
         index = teacher_index
     aux.update(mask_fre=mask_fre, counts=counts, attn_masks=masks, scores=scores, index=index)
@@ -344,17 +355,17 @@ def editor_forward(sd, x, cam, label=None, training=False, al=1, head_keep=2, fr
                           for c in cls_tri]
     feats_s, loss_bcc = sfts_apply(feats, index, training)
     mask = torch.cat([torch.ones(index.shape[0], 1, 1), index.unsqueeze(-1).float()], dim=1)
-    mods = hma_modality_blocks(feats_s, mask, sd, heads=hma_heads)
+    mods = hma_modality_blocks(feats_s, mask, sd, heads=hma_heads, tags=[m[2] for m in modalities])
     loss_ocfr = None
     if training:
-        centers = [sd["FUSE_block.memory_cls.%s_centers" % m] for m in ("RGB", "NIR", "TIR")]
+        centers = [sd["FUSE_block.memory_cls.%s_centers" % m[1]] for m in modalities]
         loss_ocfr = ocfr([m[:, 0] for m in mods], centers, label)
     fused = hma_joint_block(mods, mask, sd, heads=hma_heads)
     t = feats[0].shape[1]
-    parts = [fused[:, i * t:(i + 1) * t] for i in range(3)]
+    parts = [fused[:, i * t:(i + 1) * t] for i in range(nmod)]
     num = (parts[0][:, 1:].sum(dim=2) != 0).sum(dim=1).unsqueeze(-1)   # RGB's count for all three
     red = []
-    for part, tag in zip(parts, ("RGB", "NIR", "TIR")):
+    for part, tag in zip(parts, [m[1] for m in modalities]):
         pooled = part[:, 1:].sum(dim=1) / num
         red.append(F.linear(torch.cat([part[:, 0], pooled], dim=-1), sd[tag + "_REDUCE.weight"],
                             sd[tag + "_REDUCE.bias"]))
@@ -366,8 +377,7 @@ def editor_forward(sd, x, cam, label=None, training=False, al=1, head_keep=2, fr
     if al:
         out = (score, cls4t, ori_score, ori, loss_bcc + loss_ocfr)
     else:
-        out = (score, cls4t, mod_scores[0], cls_tri[0], mod_scores[1], cls_tri[1], mod_scores[2],
-               cls_tri[2], loss_bcc + loss_ocfr)
+        out = (score, cls4t) + tuple(v for pair in zip(mod_scores, cls_tri) for v in pair) + (loss_bcc + loss_ocfr,)
     return (out, aux) if return_aux else out
 
 

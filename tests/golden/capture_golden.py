@@ -165,6 +165,8 @@ if __name__ == "__main__":
     if "f4" in which:
         f4_f5_train("RGBNT201", 31, 16, 8, "vitb_al1")
         f4_f5_train("RGBNT100", 33, 16, 8, "vitb_al0")
+    if "f4c4" in which:                               # BASELINE config 4 geometry: 384x128 (T = 193), AL = 0, train
+        f4_f5_train("MSVR310", 35, 16, 8, "vitb_384x128")
     if "f6" in which:
         f6_blocks()
 
@@ -294,3 +296,140 @@ def f9_input(seed=91):
 
 if __name__ == "__main__" and "f9" in sys.argv[1:]:
     f9_input()
+
+
+def f10_solver():
+    """F10 (row N4): the reference's make_optimizer group table (solver/make_optimizer.py:4-29) on the reference EDITOR
+    module and the learning rates its create_scheduler (solver/scheduler_factory.py:7-31 -> CosineLRScheduler,
+    solver/cosine_lr.py:67-94) writes into those groups for epochs 0..80."""
+    import json
+    ref_shims.install()
+    import importlib
+    mo = importlib.import_module("solver.make_optimizer")
+    sf = importlib.import_module("solver.scheduler_factory")
+    cfg, c, cams = config.preset("RGBNT201")
+    cfg.SOLVER.CENTER_LR = 0.5
+    m = ref_shims.build_reference_model(cfg, c, cams)
+    center = torch.nn.Linear(2, 2)
+    opt, _ = mo.make_optimizer(cfg, m, center)
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert len(names) == len(opt.param_groups)
+    table = [[n, g["lr"], g["weight_decay"]] for n, g in zip(names, opt.param_groups)]
+    sched = sf.create_scheduler(cfg, opt)
+    i_w = names.index("BACKBONE.base.blocks.0.attn.qkv.weight")
+    i_b = names.index("BACKBONE.base.blocks.0.attn.qkv.bias")
+    after_init = [opt.param_groups[i_w]["lr"], opt.param_groups[i_b]["lr"]]
+    lrs = []
+    for epoch in range(0, 81):
+        sched.step(epoch)
+        lrs.append([opt.param_groups[i_w]["lr"], opt.param_groups[i_b]["lr"]])
+    json.dump({"table": table, "momentum": opt.param_groups[0]["momentum"], "after_init": after_init, "lrs": lrs,
+               "solver": {k: getattr(cfg.SOLVER, k) for k in ("BASE_LR", "MAX_EPOCHS", "WARMUP_ITERS", "BIAS_LR_FACTOR",
+                                                               "WEIGHT_DECAY", "WEIGHT_DECAY_BIAS", "MOMENTUM")}},
+              open(os.path.join(OUT, "f10_solver.json"), "w"))
+    print("wrote f10_solver.json")
+
+
+if __name__ == "__main__" and "f10" in sys.argv[1:]:
+    f10_solver()
+
+
+def f11_load_param(seed=111):
+    """F11 (row A9): Trans.load_param + resize_pos_embed (vit_pytorch.py:646-690) of the reference on a seeded
+    'ImageNet-style' checkpoint: 14x14 position grid -> 16x8, flattened patch-embed weight, head / dist keys skipped, a
+    wrongly shaped tensor reported and skipped.  Small widths (D=64, depth 1) - the code path does not depend on them."""
+    import tempfile
+    ref_shims.install()
+    import importlib
+    for k in [k for k in sys.modules if k == "modeling" or k.startswith("modeling.")]:
+        del sys.modules[k]
+    vp = importlib.import_module("modeling.backbones.vit_pytorch")
+    d = 64
+    ref = vp.Trans(img_size=(256, 128), patch_size=16, stride_size=16, embed_dim=d, depth=1, num_heads=2, mlp_ratio=4,
+                   qkv_bias=True, camera=4, drop_path_rate=0.0, sie_xishu=3.0)
+    ck = {
+        "pos_embed": synth.normal(seed, "ck/pos", (1, 197, d), 0.02),
+        "cls_token": synth.normal(seed, "ck/cls", (1, 1, d), 0.02),
+        "patch_embed.proj.weight": synth.normal(seed, "ck/pe", (d, 768), 0.05),          # flattened (old checkpoints)
+        "patch_embed.proj.bias": synth.normal(seed, "ck/peb", (d,), 0.05),
+        "blocks.0.attn.qkv.weight": synth.normal(seed, "ck/qkv", (3 * d, d), 0.02),
+        "blocks.0.mlp.fc1.weight": synth.normal(seed, "ck/bad", (7, 5), 1.0),            # wrong shape: reported, skipped
+        "norm.weight": synth.normal(seed, "ck/norm", (d,), 1.0),
+        "head.weight": synth.normal(seed, "ck/head", (1000, d), 1.0),                    # skipped
+        "dist_token": synth.normal(seed, "ck/dist", (1, 1, d), 1.0),                     # skipped
+    }
+    before_fc1 = ref.state_dict()["blocks.0.mlp.fc1.weight"].clone()
+    import contextlib, io
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "jx_vit_small_p16_224.pth")
+        torch.save({"model": ck}, path)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref.load_param(path)
+    sd = ref.state_dict()
+    assert torch.equal(sd["blocks.0.mlp.fc1.weight"], before_fc1)
+    # resize_pos_embed alone, also to the 24x8 grid of the 384x128 configs
+    with contextlib.redirect_stdout(io.StringIO()):
+        r2 = vp.resize_pos_embed(ck["pos_embed"], torch.zeros(1, 193, d), 24, 8)
+    save("f11_load_param", seed=seed, pos_embed=sd["pos_embed"], cls_token=sd["cls_token"],
+         pe_weight=sd["patch_embed.proj.weight"][:6], pe_bias=sd["patch_embed.proj.bias"], qkv=sd["blocks.0.attn.qkv.weight"][:16],
+         norm_w=sd["norm.weight"], resized_24x8=r2)
+
+
+if __name__ == "__main__" and "f11" in sys.argv[1:]:
+    f11_load_param()
+
+
+def f12_sampler_ddp(seed=121):
+    """F12 (row N3): the reference's RandomIdentitySampler_DDP (data/datasets/sampler_ddp.py:111-196) with its
+    torch.distributed queries answered by a stand-in (world 2, both ranks; world 1) and the cross-rank shared seed fixed."""
+    import importlib.util, types
+    spec = importlib.util.spec_from_file_location("ref_sampler_ddp", "/root/reference/data/datasets/sampler_ddp.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n_ids = 37
+    data = []
+    for pid in range(n_ids):
+        for k in range(2 + (pid * 5) % 23):
+            data.append((f"img_{pid}_{k}.jpg", pid, k % 4, 0))
+    rec = {}
+    for world in (1, 2, 4):
+        for rank in range(world):
+            mod.dist = types.SimpleNamespace(get_world_size=lambda w=world: w, get_rank=lambda r=rank: r)
+            mod.shared_random_seed = lambda: seed
+            s = mod.RandomIdentitySampler_DDP(data, 64, 8)
+            rec[f"w{world}r{rank}"] = np.asarray(list(iter(s)), dtype=np.int64)
+            rec[f"w{world}r{rank}_len"] = np.int64(len(s))
+    save("f12_sampler_ddp", seed=seed, **rec)
+
+
+if __name__ == "__main__" and "f12" in sys.argv[1:]:
+    f12_sampler_ddp()
+
+
+def f6_blocks_large(seed=43):
+    """F6 at D=1024 / 16 heads (pins the ViT-L kernels of BASELINE config 5): the reference's Block and
+    BlockMask classes (vit_pytorch.py:201-224, 261-352) instantiated at that width, T = 513 tokens (512 patches)."""
+    ref_shims.install()
+    import importlib
+    for k in [k for k in sys.modules if k == "modeling" or k.startswith("modeling.")]:
+        del sys.modules[k]
+    vp = importlib.import_module("modeling.backbones.vit_pytorch")
+    d, heads, t = 1024, 16, 513
+    blk = vp.Block(dim=d, num_heads=heads, mlp_ratio=4.0, qkv_bias=True, norm_layer=lambda n: torch.nn.LayerNorm(n, eps=1e-6))
+    synth.fill_state_dict_(blk.state_dict(), seed)
+    hma = vp.BlockMask(dim=d, num_heads=heads, mlp_ratio=4.0, num_class=8, qkv_bias=False, momentum=0.8)
+    synth.fill_state_dict_(hma.state_dict(), seed + 1)
+    blk.eval(); hma.eval()
+    x = synth.normal(seed, "blkL/x", (2, t, d), 1.0)
+    with torch.no_grad():
+        y, a = blk(x, get_att=True)
+        feats = [synth.normal(seed, "hmaL/%d" % i, (2, t, d), 1.0) for i in range(3)]
+        idx = synth.integers(seed, "hmaL/mask", (2, t - 1), 2).bool()
+        fs = [torch.cat([f[:, :1], f[:, 1:] * idx.unsqueeze(-1)], 1) for f in feats]
+        z = hma(fs[0], fs[1], fs[2], mask=idx.unsqueeze(-1), label=None)
+    save("f6_blocks_large", block_out=y[:, ::64, :64], block_out_norm=y.norm(), block_attn=a[:, :2, :4, :],
+         hma_out=z[:, ::96, :64], hma_out_norm=z.norm(), seed=seed)
+
+
+if __name__ == "__main__" and "f6L" in sys.argv[1:]:
+    f6_blocks_large()

@@ -17,7 +17,9 @@ def test_loss_head_matches_reference_golden():
     score = synth.normal(seed, "loss/score", (32, 171), 2.0).cuda().requires_grad_(True)
     feat = synth.normal(seed, "loss/feat", (32, 2304), 1.0).cuda().requires_grad_(True)
     target = torch.arange(4).repeat_interleave(8).cuda()
-    loss = losses.make_loss()(score=score, feat=feat, target=target, target_cam=None)
+    loss_fn, center = losses.make_loss(None, num_classes=171)
+    assert center.centers.shape == (171, 2048)
+    loss = loss_fn(score=score, feat=feat, target=target, target_cam=None)
     loss.backward()
     assert rel_err(loss.detach().cpu(), g["loss"]) < 1e-6
     assert rel_err(score.grad.cpu(), g["dscore"]) < 1e-5

@@ -1,5 +1,7 @@
 """GPU parity of the token-selection kernels against the oracle + the reference's golden fixtures.
 All calls go through the C ABI (editor_amd.ops -> libeditor_hip.so)."""
+import ctypes
+
 import pytest
 import torch
 
@@ -73,7 +75,9 @@ def test_probe_tr16(ops):
     # lane i of each 16-lane group points at row (i>>2), 8-byte chunk (i&3) of a [4][16] u16 block (row = 64 B)
     addr = ((lane >> 4) * 512 + (i >> 2) * 64 + (i & 3) * 8).int().cuda()
     out = torch.zeros(256, dtype=torch.int16, device="cuda")
-    _lib.call("editor_probe_tr16", addr, out)
+    rc = _lib.probe_lib().editor_probe_tr16(ctypes.c_void_p(addr.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
     got = out.cpu().view(64, 4).long()
     print("tr16 lane0..17:", got[:18].tolist())
     # hypothesis A: lane i receives column i of the block: elements [r][i], r = 0..3  (u16 index = g*256 + r*32 + i)
@@ -87,7 +91,11 @@ def test_probe_mfma16(ops):
     a = torch.randn(16, 32, generator=g).bfloat16().float()
     b = torch.randn(32, 16, generator=g).bfloat16().float()
     d = torch.zeros(16, 16, device="cuda")
-    _lib.call("editor_probe_mfma16", a.cuda(), b.cuda(), d)
+    ag, bg = a.cuda(), b.cuda()
+    rc = _lib.probe_lib().editor_probe_mfma16(ctypes.c_void_p(ag.data_ptr()), ctypes.c_void_p(bg.data_ptr()),
+                                              ctypes.c_void_p(d.data_ptr()),
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
     assert torch.allclose(d.cpu(), a @ b, atol=1e-4, rtol=1e-4)
 
 
