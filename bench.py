@@ -56,7 +56,7 @@ class _GemmProbe:
         probe = self
 
         def recorded(a, b, c, m, n, k, *args, **kw):
-            if probe.recording and a.dtype == torch.bfloat16:
+            if probe.recording and a.dtype in (torch.bfloat16, torch.float16):
                 ta = args[3] if len(args) > 3 else kw.get("trans_a", 0)
                 tb = args[4] if len(args) > 4 else kw.get("trans_b", 0)
                 kind = "fwd" if not ta and not tb else ("dgrad" if not ta else "wgrad")
@@ -204,11 +204,13 @@ def main():
     # solver/make_optimizer.py:4-29: SGD, momentum 0.9, wd 1e-4, bias lr x2 (BASE_LR 0.001) - fused HIP update
     from editor_amd.optim import FusedSGD
     opt = FusedSGD(model.named_parameters(), base_lr=1e-3, weight_decay=1e-4, bias_lr_factor=2.0,
-                   weight_decay_bias=1e-4, momentum=0.9)
+                   weight_decay_bias=1e-4, momentum=0.9,
+                   shadow_dtype=None if model.act_dtype == torch.float32 else model.act_dtype)
 
     h, w = cfg.INPUT.SIZE_TRAIN
     b = args.batch
-    img, label, cam, view = synth.make_batch(1111 + rank, b, h, w, cams, instances=16)
+    img, label, cam, view = synth.make_batch(1111 + rank, b, h, w, cams, instances=16,
+                                             keys=config.MODALITY_KEYS[:int(getattr(cfg.MODEL, "NUM_MODALITIES", 3))])
     img = {k: v.to(dev) for k, v in img.items()}
     label, cam, view = label.to(dev), cam.to(dev), view.to(dev)
     writer = _Writer()

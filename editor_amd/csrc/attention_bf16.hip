@@ -511,8 +511,8 @@ __global__ __launch_bounds__(256) void attn_rollout_step_kernel(const bf16_t* __
 // Long sequences (T > 608: the joint HMA block of the 4-modal 512-token configuration, up to 4 x 513 = 2052 tokens).
 // The key range no longer fits the CU's LDS, so a workgroup owns 64 "own" rows (one 16-row tile per wave) and streams the
 // "other" side through LDS in chunks of 256 rows (K,V or Q,dO: 64 KiB -> two workgroups per CU); grid = (B*heads,
-// ceil(Tmax/64)).  Same tile algebra as the whole-sequence kernels above; key validity is computed per tile (no masks:
-// long sequences are the dense backbone or packed live tokens).  FWD sweeps the chunks twice (row statistics, then
+// ceil(Tmax/64)).  Same tile algebra as the whole-sequence kernels above; key validity (sequence end, optional token mask
+// of the dense-masked form) is computed per tile.  FWD sweeps the chunks twice (row statistics, then
 // P V with the final log-sum-exp - no running rescale of the output accumulators); DQ and DKV sweep once.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int LCH = 256;
@@ -533,8 +533,10 @@ __global__ __launch_bounds__(256) void attn_q_long_kernel(AttnArgs a)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const bf16_t* qbase = a.qkv + row0 * ld + hh * HD;
+    const uint8_t* mk = a.mask ? a.mask + (long)b * T : nullptr;     // dense-masked form only (packed rows are all live)
     const int q0 = qb0 + w * 16, q = q0 + li;
-    const bool qok = q < T;
+    const bool qin = q < T;
+    const bool qok = qin && (!mk || mk[q]);
     short8_t qf[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) qf[s] = frag_own(qbase, ld, q0, T, s, lane);
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(256) void attn_q_long_kernel(AttnArgs a)
                 const int key0 = c0 + 16 * t + 4 * lg;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    sv[r] = key0 + r < T ? acc[r] * sc : -INFINITY;
+                    sv[r] = (key0 + r < T && (!mk || mk[key0 + r])) ? acc[r] * sc : -INFINITY;
                     tm = fmaxf(tm, sv[r]);
                 }
                 if (tm > m) { l *= __builtin_amdgcn_exp2f(m - tm); m = tm; }
@@ -567,9 +569,9 @@ __global__ __launch_bounds__(256) void attn_q_long_kernel(AttnArgs a)
         const float M = group_max(m);
         const float L = group_sum(m > -INFINITY ? l * __builtin_amdgcn_exp2f(m - M) : 0.f);
         lse = (qok && L > 0.f) ? M + __builtin_amdgcn_logf(L) : INFINITY;
-        if (a.lse && lg == 0 && qok) a.lse[row_idx0 + q] = lse;
+        if (a.lse && lg == 0 && qin) a.lse[row_idx0 + q] = lse;
     } else {
-        lse = qok ? a.lse[row_idx0 + q] : INFINITY;
+        lse = qin ? a.lse[row_idx0 + q] : INFINITY;
     }
     float dl = 0.f;
     short8_t dof[2];
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(256) void attn_q_long_kernel(AttnArgs a)
             for (int e = 0; e < 8; ++e) dl += H16<F16>::to_f32((uint16_t)dof[s][e]) * H16<F16>::to_f32((uint16_t)of[e]);
         }
         dl = group_sum(dl);
-        if (lg == 0 && qok) a.delta[row_idx0 + q] = dl;
+        if (lg == 0 && qin) a.delta[row_idx0 + q] = dl;
     }
     float4_t o[4];
 #pragma unroll
@@ -610,7 +612,8 @@ __global__ __launch_bounds__(256) void attn_q_long_kernel(AttnArgs a)
                 float pv[4];
                 const int key0 = c0 + 16 * t + 4 * lg;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(key0 + r < T ? acc[r] * sc - lse : -INFINITY);
+                for (int r = 0; r < 4; ++r)
+                    pv[r] = __builtin_amdgcn_exp2f((key0 + r < T && (!mk || mk[key0 + r])) ? acc[r] * sc - lse : -INFINITY);
                 if (!BWD) pk[half] = pack4<F16>(pv[0], pv[1], pv[2], pv[3]);
                 else pk[half] = pack4<F16>(pv[0] * (dp[0] - dl) * a.scale, pv[1] * (dp[1] - dl) * a.scale,
                                            pv[2] * (dp[2] - dl) * a.scale, pv[3] * (dp[3] - dl) * a.scale);
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(256) void attn_q_long_kernel(AttnArgs a)
             for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16<F16>(frag_t(timg, s2, dt, lane), pf, o[dt]);
         }
     }
-    if (qok) {
+    if (qin) {
         bf16_t* orow = BWD ? a.dqkv + (row0 + q) * ld + hh * HD + 4 * lg : a.out + (row0 + q) * D + hh * HD + 4 * lg;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
@@ -647,8 +650,10 @@ __global__ __launch_bounds__(256) void attn_kv_long_kernel(AttnArgs a)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const bf16_t* qbase = a.qkv + row0 * ld + hh * HD;
+    const uint8_t* mk = a.mask ? a.mask + (long)b * T : nullptr;
     const int k0 = kb0 + w * 16, key = k0 + li;
-    const bool kok = key < T;
+    const bool kin = key < T;
+    const bool kok = kin && (!mk || mk[key]);
     const float sc = a.scale * kLog2e;
     short8_t kf[2], vf[2];
 #pragma unroll
@@ -666,8 +671,9 @@ __global__ __launch_bounds__(256) void attn_kv_long_kernel(AttnArgs a)
         load_image(doimg, a.dout + (row0 + c0) * D + hh * HD, D, len, ntc * 16);
         for (int t = threadIdx.x; t < ntc * 16; t += blockDim.x) {
             const long idx = (long)hh * a.Mtot + row0 + c0 + t;
-            lse_s[t] = t < len ? a.lse[idx] : INFINITY;
-            dl_s[t] = t < len ? a.delta[idx] : 0.f;
+            const bool ok = t < len && (!mk || mk[c0 + t]);
+            lse_s[t] = ok ? a.lse[idx] : INFINITY;
+            dl_s[t] = ok ? a.delta[idx] : 0.f;
         }
         __syncthreads();
 #pragma unroll 1
@@ -712,7 +718,7 @@ __global__ __launch_bounds__(256) void attn_kv_long_kernel(AttnArgs a)
             }
         }
     }
-    if (kok) {
+    if (kin) {
         bf16_t* krow = a.dqkv + (row0 + key) * ld + D + hh * HD + 4 * lg;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -771,7 +777,7 @@ int launch_all(const AttnArgs& a, int B, int mode, hipStream_t stream)
 template <bool F16>
 int launch_long(const AttnArgs& a, int B, int mode, hipStream_t stream)
 {
-    if (a.mask || a.probs) return (int)hipErrorInvalidValue;       // long form: dense unmasked or packed live tokens
+    if (a.probs) return (int)hipErrorInvalidValue;                 // (no probability output: the backbone's sequences are short)
     const dim3 grid(B * a.heads, (a.T + 63) / 64);
     const size_t img = (size_t)2 * LCH * ROWB;
     int rc;

@@ -181,7 +181,7 @@ int editor_attn_rollout_step_f16(const uint16_t* qkv, const float* lse, const fl
 
 /* Fused 16-bit form (hd must be 64).  T <= 608: one workgroup per (sample, head) with the whole key range in LDS.
  * T > 608 (joint HMA block of the 4-modal 512-token configuration): 64 own rows per workgroup, the other side streamed
- * through LDS in 256-row chunks; mask and probs must be NULL there.  probs optional (NULL skips the write).  lse (heads*Mtot fp32, log2 units
+ * through LDS in 256-row chunks; probs must be NULL there.  probs optional (NULL skips the write).  lse (heads*Mtot fp32, log2 units
  * of the scaled scores, +inf for masked queries) is written by the forward (NULL to skip) and consumed by the backward,
  * which recomputes the probabilities from it; `out` is the forward output (delta = rowsum(dO*O));
  * workspace: heads*Mtot floats.  Variable-length (compacted HMA) form: cu (B+1 int32) gives each sequence's packed row

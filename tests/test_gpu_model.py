@@ -52,7 +52,7 @@ def test_eval_parity_f32(tag, preset):
     assert rel_err(cls4t.cpu(), g["cls4t"]) < 1e-3
 
 
-@pytest.mark.parametrize("tag,preset", [("vitb_al1", "RGBNT201"), ("vitb_al0", "RGBNT100")])
+@pytest.mark.parametrize("tag,preset", [("vitb_al1", "RGBNT201"), ("vitb_al0", "RGBNT100"), ("vitb_384x128", "MSVR310")])
 def test_train_parity_f32(tag, preset, oracle):
     g = load_golden("f4_train_" + tag)
     seed, batch, inst = int(g["seed"]), int(g["batch"]), int(g["instances"])
@@ -105,15 +105,24 @@ def test_forward_rejects_cpu():
 
 
 # ---------------------------------------------------------------------------------------------------
-# bf16 performance mode: protocol of SURVEY.md 7 - selection agreement is REPORTED (bf16 scores cannot be
+# 16-bit performance modes: protocol of SURVEY.md 7 - selection agreement is REPORTED (16-bit scores cannot be
 # bit-identical to fp32 ones), features / grads are checked with the reference's selection teacher-forced.
-# Measured bf16-vs-fp32 feature error is ~5e-3 relative (bf16 operand rounding, same as torch's own bf16
-# autocast: 7e-3); the north-star's 1e-3 is met by the f32 parity mode above.
+#   bf16: 8-bit mantissa operands -> ~5e-3 relative on the features (torch's own CPU bf16 autocast: 7e-3)
+#   f16 : the reference's own autocast dtype (engine/processor.py:79), 11-bit mantissa, same MFMA rate: this is the mode
+#         that meets the north-star's 1e-3 on the features at full speed (f32 parity mode: exact-f32 MFMA, 1/16 rate)
+# Bounds = measured on MI355X (tools/parity_table.py, profiles/r02_parity_table.txt) x 1.5.
 # ---------------------------------------------------------------------------------------------------
-def test_eval_bf16_teacher_forced():
+TOL = {
+    "bf16": dict(agree=0.95, eval_cls4t=1.0e-2, train_out=1.8e-2, grad=3.0e-2),
+    "f16": dict(agree=0.99, eval_cls4t=1.0e-3, train_out=1.5e-3, grad=4.0e-3),
+}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_eval_16bit_teacher_forced(dtype):
     g = load_golden("f3_eval_vitb_256x128")
     seed, batch = int(g["seed"]), int(g["batch"])
-    m, cfg, c, cams = _model("RGBNT201", seed, "bf16", drop_path=0.0)
+    m, cfg, c, cams = _model("RGBNT201", seed, dtype, drop_path=0.0)
     m.eval()
     img, label, cam, view = _cuda_batch(*synth.make_batch(seed + 1, batch, 256, 128, cams))
     with torch.no_grad():
@@ -122,20 +131,21 @@ def test_eval_bf16_teacher_forced():
     assert torch.equal(aux["mask_fre"].cpu().bool(), t(g["mask_fre"]))          # integer path: exact in any mode
     agree = [(aux["attn_masks"][i].cpu().bool() == t(g["mask_" + n])).float().mean().item()
              for i, n in enumerate(("rgb", "nir", "tir"))]
-    print("bf16 per-modality attention-mask agreement:", agree)
-    assert min(agree) > 0.95
+    print(dtype, "per-modality attention-mask agreement:", agree)
+    assert min(agree) > TOL[dtype]["agree"]
     m.teacher_index = t(g["index"])
     with torch.no_grad():
         cls4t = m(img, cam_label=cam, view_label=view)
     err = rel_err(cls4t.cpu(), g["cls4t"])
-    print("bf16 cls4t rel err (teacher-forced):", err)
-    assert err < 2e-2
+    print(dtype, "cls4t rel err (teacher-forced):", err)
+    assert err < TOL[dtype]["eval_cls4t"]
 
 
-def test_train_bf16_teacher_forced():
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_train_16bit_teacher_forced(dtype):
     g = load_golden("f4_train_vitb_al0")
     seed, batch, inst = int(g["seed"]), int(g["batch"]), int(g["instances"])
-    m, cfg, c, cams = _model("RGBNT100", seed, "bf16", drop_path=0.0)
+    m, cfg, c, cams = _model("RGBNT100", seed, dtype, drop_path=0.0)
     m.train()
     h, w = cfg.INPUT.SIZE_TRAIN
     img, label, cam, view = _cuda_batch(*synth.make_batch(seed + 1, batch, h, w, cams, instances=inst))
@@ -148,8 +158,8 @@ def test_train_bf16_teacher_forced():
     del mf
     out = m(img, label=label, cam_label=cam, view_label=view, writer=_Writer(), epoch=1)
     errs = [rel_err(o.detach().float().cpu(), g["out%d" % i]) for i, o in enumerate(out)]
-    print("bf16 train outputs rel err:", errs)
-    assert max(errs) < 3e-2
+    print(dtype, "train outputs rel err:", errs)
+    assert max(errs) < TOL[dtype]["train_out"]
     total = out[-1]
     for i, o in enumerate(out[:-1]):
         total = total + (o * synth.uniform(5, "proj/%d" % i, tuple(o.shape)).cuda()).mean()
@@ -162,8 +172,38 @@ def test_train_bf16_teacher_forced():
         elif key.startswith("gs:"):
             gr = named[key[3:]].grad
             worst = max(worst, rel_err(gr.reshape(gr.shape[0], -1)[:16, :16].cpu(), val))
-    print("bf16 worst gradient rel err:", worst)
-    assert worst < 8e-2
+    print(dtype, "worst gradient rel err:", worst)
+    assert worst < TOL[dtype]["grad"]
+
+
+def test_f16_grad_scale_is_transparent():
+    """The static loss scale of the f16 backward (functional.F16_GRAD_SCALE, a power of two) only shifts exponents: two
+    different scales give the same parameter gradients up to half rounding of sub-/near-normal values."""
+    from editor_amd import functional as fnc
+    seed, batch = 31, 8
+    img, label, cam, view = _cuda_batch(*synth.make_batch(seed + 1, batch, 256, 128, 4, instances=4))
+    grads = {}
+    old = fnc.F16_GRAD_SCALE
+    try:
+        for gs in (1024.0, 16384.0):
+            fnc.set_f16_grad_scale(gs)
+            m, cfg, c, cams = _model("RGBNT201", seed, "f16", drop_path=0.0)
+            m.train()
+            out = m(img, label=label, cam_label=cam, view_label=view, writer=_Writer(), epoch=1)
+            total = out[-1]
+            for i, o in enumerate(out[:-1]):
+                total = total + (o * synth.uniform(5, "proj/%d" % i, tuple(o.shape)).cuda()).mean()
+            total.backward()
+            named = dict(m.named_parameters())
+            grads[gs] = {k: named[k].grad.float().cpu() for k in ("BACKBONE.base.blocks.0.attn.qkv.weight",
+                                                                  "BACKBONE.base.blocks.6.mlp.fc1.bias",
+                                                                  "BACKBONE.base.patch_embed.proj.weight",
+                                                                  "FUSE_block.attn1.qkv.weight", "BACKBONE.base.cls_token")}
+    finally:
+        fnc.set_f16_grad_scale(old)
+    for k in grads[1024.0]:
+        assert torch.isfinite(grads[16384.0][k]).all()
+        assert rel_err(grads[1024.0][k], grads[16384.0][k]) < 2e-3, k
 
 
 def test_hma_compact_equals_dense_bf16():
@@ -196,12 +236,13 @@ def test_hma_compact_equals_dense_bf16():
         assert rel_err(res[True][1][k], res[False][1][k]) < 4e-2, k
 
 
-def test_eval_bf16_384x128_config4():
-    """BASELINE.json config 4 geometry (384x128 -> 192 patches, T = 193, joint HMA block of up to 579 tokens) in bf16,
-    compacted HMA, reference selection teacher-forced."""
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_eval_16bit_384x128_config4(dtype):
+    """BASELINE.json config 4 geometry (384x128 -> 192 patches, T = 193, joint HMA block of up to 579 tokens) in the 16-bit
+    modes, compacted HMA, reference selection teacher-forced."""
     g = load_golden("f3_eval_vitb_384x128")
     seed, batch = int(g["seed"]), int(g["batch"])
-    m, cfg, c, cams = _model("MSVR310", seed, "bf16", drop_path=0.0)
+    m, cfg, c, cams = _model("MSVR310", seed, dtype, drop_path=0.0)
     m.eval()
     img, label, cam, view = _cuda_batch(*synth.make_batch(seed + 1, batch, 384, 128, cams))
     m.teacher_index = t(g["index"])
@@ -209,8 +250,8 @@ def test_eval_bf16_384x128_config4():
         cls4t = m(img, cam_label=cam, view_label=view)
     assert torch.equal(m.last_aux["mask_fre"].cpu().bool(), t(g["mask_fre"]))
     err = rel_err(cls4t.cpu(), g["cls4t"])
-    print("bf16 384x128 cls4t rel err:", err)
-    assert err < 2e-2
+    print(dtype, "384x128 cls4t rel err:", err)
+    assert err < TOL[dtype]["eval_cls4t"]
 
 
 def test_hipgraph_replay_matches_eager_training():
