@@ -1,20 +1,29 @@
 #!/usr/bin/env python
 """bench.py - tri-modal images/sec, forward+backward+optimizer step, of the EDITOR hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|f16|f32] [--preset RGBNT201|RGBNT100|MSVR310|SYNTH4L]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): RGBNT201 cfg, 3 modalities, ViT-B/16, 256x128, B=128 PER GPU
-(weak scaling, SURVEY.md 7 "DDP batch semantics"), bf16 MFMA with fp32 accumulation/residual/grads,
-synthetic seeded uint8-derived images, random-init weights of the real architecture.  A "step" is what
-engine/processor.py:70-107 does per batch minus the host->device copy (inputs are resident in HBM):
-zero_grad -> forward -> loss (pairs + aux) -> backward (+ gradient all-reduce) -> SGD step.
+Workload (BASELINE.json configs[1]): RGBNT201 cfg, 3 modalities, ViT-B/16, 256x128, B=128 PER GPU (weak scaling, SURVEY.md 7
+"DDP batch semantics"), bf16 MFMA with fp32 accumulation/residual/grads, synthetic seeded uint8-derived images, random-init
+weights of the real architecture.  A "step" is what engine/processor.py:70-107 does per batch:
+zero_grad -> forward -> loss (pairs + aux) -> backward (+ gradient all-reduce, overlapped) -> SGD step.
 
-One JSON line on rank 0.  `roofline`: the dominant kernel family (bf16 MFMA GEMM): algorithmic FLOPs of
-every launch in the timed region / their HIP-event durations, against the 2.5 PFLOP/s dense bf16 peak.
-`cpu_baseline`: the oracle (CPU restatement pinned to the reference) timed on this host's cores on a
-bounded sample of the same workload (N=1 only).
+`value` (the headline): inputs resident in HBM, K steps between two synchronisations (the contract of this file).
+`with_h2d_sync`: the same step fed the way the reference's loop feeds it (processor.py:73-78,107): pinned double-buffered
+host batches copied to the device every step and a device synchronisation per iteration (N = 1 only).
+
+One JSON line on rank 0.
+  roofline      the dominant kernel family (16-bit MFMA GEMM): algorithmic FLOPs of every launch of one step / their
+                HIP-event durations (replayed back to back after the timed region), against the 2.5 PFLOP/s dense peak;
+                `traffic` = HBM bytes per step of those launches from the committed PMC profile of the same command
+                (profiles/r02_pmc_traffic.json, tools/pmc_traffic.sh), null when absent;
+                `hbm_kernels` = the memory-bound select / gather / normalisation kernels timed live with HIP events
+                against the 8 TB/s HBM peak (algorithmic bytes).
+  cpu_baseline  the oracle (CPU restatement pinned to the reference) timed on this host's cores: the same step at B=128
+                (1 warm-up + 3 timed iterations: forward, the reference's loss, backward, SGD) and config 1 (`c1`: B=32,
+                RGB only, backbone forward).  N = 1 only.
 """
 import argparse
 import json
@@ -28,7 +37,9 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_TFLOPS = 2500.0               # MI355X dense bf16 / f16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3            # dense fp32 MFMA (v_mfma_f32_16x16x4_f32), parity mode
+PEAK_HBM_GBS = 8000.0              # HBM3E
 
 
 class _Writer:                     # engine/processor.py:42 passes a SummaryWriter into forward
@@ -37,14 +48,13 @@ class _Writer:                     # engine/processor.py:42 passes a SummaryWrit
 
 
 class _GemmProbe:
-    """HIP-event timing of the dominant kernel family (bf16 MFMA GEMM).
+    """HIP-event timing of the dominant kernel family (16-bit MFMA GEMM).
 
-    Every bf16 GEMM launch of the LAST timed step is recorded (arguments kept alive); after the timed region the
-    recorded launches are replayed back to back on the same stream between two HIP events.  Timing each launch in
-    place would fold host launch gaps of the eager step into the kernel time (measured: +17 %), which is not a
-    property of the kernel; the replay has the same operands, shapes and epilogues and no other work in between.
-    The rocprofv3 --kernel-trace --stats summary of the same command (profiles/) gives the in-situ durations and
-    agrees with the replay."""
+    Every 16-bit GEMM launch of ONE step is recorded (arguments kept alive); after the timed region the recorded
+    launches are replayed back to back on the same stream between two HIP events.  Timing each launch in place would
+    fold host launch gaps of the eager step into the kernel time (measured: +17 %), which is not a property of the
+    kernel; the replay has the same operands, shapes and epilogues and no other work in between.  The rocprofv3
+    --kernel-trace --stats summary of the same command (profiles/) gives the in-situ durations and agrees."""
 
     def __init__(self):
         self.calls = []
@@ -98,6 +108,62 @@ class _GemmProbe:
         return by_kind
 
 
+def _event_us(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / reps
+
+
+def hbm_kernels(model, img, b, act_dtype):
+    """The memory-bound kernels of the path (north_star: "achieved HBM GB/s for the memory-bound select/gather"), each
+    timed live on this GPU with HIP events on its real operand shapes; algorithmic bytes per launch from SURVEY.md 8(d)."""
+    from editor_amd import ops
+    dev = img[next(iter(img))].device
+    base = model.BACKBONE.base
+    nmod, d, heads = model.nmod, base.embed_dim, base.heads
+    t = base.num_patches + 1
+    m = nmod * b * t
+    mods = [v for v in img.values()]
+    out = []
+
+    def add(name, alg_bytes, fn):
+        us = _event_us(fn)
+        gbs = alg_bytes / us / 1e3
+        out.append({"kernel": name, "alg_bytes": int(alg_bytes), "us": round(us, 1), "GB/s": round(gbs, 0),
+                    "frac": round(gbs / PEAK_HBM_GBS, 3)})
+
+    px = mods[0].numel() * 4
+    add("freq_counts_kernel (Haar DWT -> mean -> IDWT -> positive count)", nmod * px,
+        lambda: ops.freq_counts(mods[0], mods[1], mods[2], mods[3] if nmod > 3 else None))
+    feat = torch.randn(nmod, b, t, d, device=dev)
+    index = (torch.rand(b, t - 1, device=dev) > 0.5).to(torch.uint8)
+    add("sfts_apply_kernel (mask apply + BCC partial sums)", 2 * feat.numel() * 4, lambda: ops.sfts_apply(feat, index, True))
+    x = torch.randn(m, d, device=dev)
+    g = torch.ones(d, device=dev)
+    bb = torch.zeros(d, device=dev)
+    if act_dtype != torch.float32:
+        qkv = (torch.randn(m, 3 * d, device=dev) * 0.5).to(act_dtype)
+        _, lse = ops.attention_fwd(qkv, nmod * b, t, heads, d // heads)
+        add("attn_rollout_step_kernel (one layer: q,k + lse in, r out)", m * 2 * d * 2 + 2 * heads * m * 4,
+            lambda: ops.attn_rollout_qk([(qkv, lse)], nmod * b, t, heads, d // heads))
+        add("attn_q_pass_kernel fwd (qkv in, o out)", m * 4 * d * 2,
+            lambda: ops.attention_fwd(qkv, nmod * b, t, heads, d // heads))
+        del qkv, lse
+    esz = 4 if act_dtype == torch.float32 else 2
+    y, mean, rstd = ops.layernorm_fwd(x, g, bb, 1e-6, act_dtype)
+    add("layernorm_fwd_kernel", m * d * (4 + esz), lambda: ops.layernorm_fwd(x, g, bb, 1e-6, act_dtype))
+    dx_in = torch.randn(m, d, device=dev)
+    add("layernorm_bwd_kernel (+ residual-gradient add)", m * d * (esz + 4 + 4 + 4),
+        lambda: ops.layernorm_bwd(y, x, g, mean, rstd, dx_in=dx_in))
+    return out
+
+
 def _usable_cores():
     """Cores this process may really use: affinity mask, capped by the cgroup CPU quota (a container that
     reports 256 logical CPUs but is throttled to a few thrashes when handed 256 threads)."""
@@ -111,31 +177,59 @@ def _usable_cores():
     return max(1, min(n, 32))          # the oracle's per-op parallelism saturates well below 32 threads
 
 
-def cpu_baseline(model, cfg, cams, sample_b=32):
-    """Oracle (oracle/editor_ref.py) fwd+bwd on the host cores on a bounded sample of the workload."""
+def cpu_baseline(model, cfg, cams, batch, iters):
+    """SURVEY.md 8(d) "CPU baseline beside it": the oracle (oracle/editor_ref.py, proven equal to the reference by the
+    committed fixtures) on this host's cores, fp32, same synthetic batch, same step definition as the timed GPU step:
+    forward + the reference's loss (label-smoothed CE + batch-hard triplet over the pairs + aux) + backward + SGD step;
+    1 warm-up + `iters` timed iterations at B = `batch`.  Plus config 1: B=32, RGB only, backbone forward."""
     from oracle import editor_ref as oracle
     from editor_amd import synth
     cores = _usable_cores()
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    leaves = []
     for k, v in sd.items():
         if v.is_floating_point() and "centers" not in k and "running" not in k and not k.startswith("FREQ"):
             v.requires_grad_(True)
+            leaves.append(v)
+    opt = torch.optim.SGD(leaves, lr=1e-3, momentum=0.9, weight_decay=1e-4)
     h, w = cfg.INPUT.SIZE_TRAIN
+    nmod = int(getattr(cfg.MODEL, "NUM_MODALITIES", 3))
+    mods = oracle.MODALITIES4 if nmod == 4 else oracle.MODALITIES3
+    heads = model.BACKBONE.base.heads
+    img, label, cam, view = synth.make_batch(1111, batch, h, w, cams, instances=min(16, max(batch // 2, 1)),
+                                             keys=[m[0] for m in mods])
 
-    def run(b):
-        img, label, cam, view = synth.make_batch(1111, b, h, w, cams, instances=min(16, b // 2))
+    def run():
         t0 = time.perf_counter()
-        out = oracle.editor_forward(sd, img, cam, label=label, training=True, al=cfg.MODEL.AL)
-        oracle.projection_loss(out).backward()
+        opt.zero_grad(set_to_none=True)
+        out = oracle.editor_forward(sd, img, cam, label=label, training=True, al=cfg.MODEL.AL, heads=heads,
+                                    hma_heads=model.hma_heads, modalities=mods)
+        oracle.loss_pairs(out, label).backward()
+        opt.step()
         return time.perf_counter() - t0
 
-    run(2)                                          # allocator / page-fault warm-up, untimed
-    dt = run(sample_b)
-    return {"value": round(sample_b / dt, 4), "unit": "tri-modal images/sec", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"oracle fwd+bwd, fp32, B={sample_b} tri-modal 256x128 ViT-B/16, 1 timed iteration "
-                      f"({dt:.1f} s) after a B=2 warm-up"}
+    run()                                           # warm-up (allocator, page faults), untimed
+    times = [run() for _ in range(iters)]
+    mean = sum(times) / len(times)
+    res = {"value": round(batch / mean, 4), "unit": "tri-modal images/sec", "cores": torch.get_num_threads(),
+           "kind": "port",
+           "sample": f"oracle fwd + loss_pairs + bwd + SGD step, fp32, B={batch} {nmod}-modal {h}x{w}, 1 warm-up + "
+                     f"{iters} timed iterations ({', '.join('%.1f' % x for x in times)} s)"}
+    # config 1 (BASELINE.json configs[0]): B=32, RGB only, backbone forward (plumbing check of the reference's CPU path)
+    b1 = 32
+    x1, _, cam1, _ = synth.make_batch(1111, b1, h, w, cams)
+    x1 = x1["RGB"]
+    with torch.no_grad():
+        oracle.vit_forward(sd, x1[:4], cam1[:4], heads)
+        t1 = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            oracle.vit_forward(sd, x1, cam1, heads)
+            t1.append(time.perf_counter() - t0)
+    res["c1"] = {"value": round(b1 / (sum(t1) / len(t1)), 2), "unit": "images/sec",
+                 "sample": f"config 1: B={b1} RGB-only backbone forward, 3 timed iterations after a warm-up"}
+    return res
 
 
 def main():
@@ -143,33 +237,39 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE: 128)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (BASELINE: 128; SYNTH4L default 32)")
     ap.add_argument("--preset", default="RGBNT201")
-    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--graph", action="store_true", help="time a hipGraph replay of the captured step in THIS process")
     ap.add_argument("--no-graph", action="store_true", help="time the eager step (no hipGraph attempt)")
-    ap.add_argument("--no-replay", action="store_true", help="skip the GEMM replay (clean rocprof per-step totals)")
+    ap.add_argument("--no-replay", action="store_true", help="skip the GEMM replay / kernel micro-timings (clean rocprof totals)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the second timed variant (H2D copy + per-step sync)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 32 if args.preset == "SYNTH4L" else 128
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    force_ddp = os.environ.get("EDITOR_FORCE_DDP") == "1"        # exercises the RCCL path (incl. capture) on 1 GPU
     # Single GPU, default: the step is timed as a hipGraph replay (one graph launch per step instead of ~1100 kernel
     # launches issued from Python: a slow or busy host stretched the 51 ms step to 80 ms on some boxes).  The capture
     # runs in a CHILD process, because a capture the runtime rejects can crash the process instead of raising; if the
     # child does not deliver its JSON line, this process measures the eager step itself.  The child does the same K
     # timed steps between the same synchronisations - every kernel of the eager step is in the graph.
-    if world == 1 and not args.graph and not args.no_graph and os.environ.get("EDITOR_FORCE_DDP") != "1":
+    if world == 1 and not args.graph and not args.no_graph and not force_ddp:
         import subprocess
         try:
             cp = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--graph"],
-                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=2400)
             lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
             if cp.returncode == 0 and lines:
                 json.loads(lines[-1])
                 sys.stderr.write(cp.stderr[-2000:])
                 print(lines[-1], flush=True)
                 return
+            sys.stderr.write(cp.stderr[-3000:])
             sys.stderr.write(f"[bench] hipGraph child failed (rc={cp.returncode}); timing the eager step\n")
         except Exception as e:                                            # timeout, unparsable output ...
             sys.stderr.write(f"[bench] hipGraph child failed ({type(e).__name__}); timing the eager step\n")
@@ -178,7 +278,7 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1 or os.environ.get("EDITOR_FORCE_DDP") == "1"      # the flag exercises the RCCL path on 1 GPU
+    use_dist = world > 1 or force_ddp
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -186,7 +286,6 @@ def main():
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
 
     from editor_amd import config, losses, synth
-    from editor_amd.ddp import GradReducer
     from editor_amd.modeling import make_model
 
     cfg, num_class, cams = config.preset(args.preset, compute_dtype=args.dtype, drop_path=0.1)
@@ -197,21 +296,24 @@ def main():
         model = make_model(cfg, num_class, cams)
     synth.fill_state_dict_(model.state_dict(), 1111)
     model = model.to(dev).train()
-    reducer = GradReducer(model, force=use_dist) if use_dist else None
-    if reducer is not None:
-        reducer.broadcast_parameters()
+    # Multi-GPU: pure data parallelism, one AVG all-reduce of the 118.9 M gradients per step.  The
+    # gradients are written by the backward straight into a few flat 64 MiB buckets and each bucket's RCCL all-reduce is
+    # issued from inside the backward as soon as its last block is done (editor_amd.ddp.GradBuckets): overlapped with the
+    # remaining backward in the eager step AND in the captured hipGraph (the collectives are part of the graph).
+    buckets = model.enable_grad_buckets(force=force_ddp) if use_dist else None
+    if buckets is not None:
+        buckets.broadcast_parameters(model)
 
     # solver/make_optimizer.py:4-29: SGD, momentum 0.9, wd 1e-4, bias lr x2 (BASE_LR 0.001) - fused HIP update
-    from editor_amd.optim import FusedSGD
-    opt = FusedSGD(model.named_parameters(), base_lr=1e-3, weight_decay=1e-4, bias_lr_factor=2.0,
-                   weight_decay_bias=1e-4, momentum=0.9,
-                   shadow_dtype=None if model.act_dtype == torch.float32 else model.act_dtype)
+    from editor_amd import solver
+    opt, _ = solver.make_optimizer(cfg, model, None)
 
     h, w = cfg.INPUT.SIZE_TRAIN
     b = args.batch
-    img, label, cam, view = synth.make_batch(1111 + rank, b, h, w, cams, instances=16,
-                                             keys=config.MODALITY_KEYS[:int(getattr(cfg.MODEL, "NUM_MODALITIES", 3))])
-    img = {k: v.to(dev) for k, v in img.items()}
+    nmod = model.nmod
+    keys = config.MODALITY_KEYS[:nmod]
+    img_h, label, cam, view = synth.make_batch(1111 + rank, b, h, w, cams, instances=min(16, b), keys=keys)
+    img = {k: v.to(dev) for k, v in img_h.items()}
     label, cam, view = label.to(dev), cam.to(dev), view.to(dev)
     writer = _Writer()
 
@@ -220,30 +322,12 @@ def main():
         out = model(img, label=label, cam_label=cam, view_label=view, img_path=None, writer=writer, epoch=1)
         loss = losses.loss_pairs(out, label)
         loss.backward()
-        if reducer is not None:
-            reducer.finalize()
+        if buckets is not None:
+            buckets.finish()
         opt.step()
         return loss
 
-    def fwd_bwd():                                   # the part of a multi-GPU step that is captured
-        opt.zero_grad(set_to_none=True)
-        out = model(img, label=label, cam_label=cam, view_label=view, img_path=None, writer=writer, epoch=1)
-        loss = losses.loss_pairs(out, label)
-        loss.backward()
-        return loss
-
-    # Multi-GPU: forward + backward are captured into a hipGraph as well (one rank = one process = the same ~1100
-    # launches per step, and eight Python processes share the host); the gradient exchange then runs after the replay
-    # as a few flat RCCL all-reduces and the fused SGD launch follows.  This gives up the overlap of the exchange with
-    # the backward (editor_amd.ddp.GradReducer, the eager path: EDITOR_DDP_EAGER=1 or --no-graph) for a step time that
-    # does not depend on how fast the host can issue launches.
-    dist_graph = use_dist and not args.no_graph and os.environ.get("EDITOR_DDP_EAGER") != "1"
-    flat_reduce = None
-    if dist_graph:
-        from editor_amd.ddp import FlatAllReduce
-        flat_reduce = FlatAllReduce(model)           # (the warm-up steps below still use the hook-driven reducer)
-
-    want_graph = (not use_dist and args.graph) or dist_graph
+    want_graph = args.graph or (use_dist and not args.no_graph)
     side = torch.cuda.Stream() if want_graph else None
     if want_graph:
         # every eager step before the capture runs on a SIDE stream: AccumulateGrad nodes remember the stream they were
@@ -259,9 +343,9 @@ def main():
             step()
     probe = _GemmProbe()
     probe.install()
-    # --graph: the whole step (forward, loss, backward, fused SGD: ~1100 launches) is captured once into a hipGraph and
-    # the timed region replays it; the drop-path generator and the SGD pointer table are replay-safe (device-resident
-    # counter, captured upload).
+    # the whole step (forward, loss, backward incl. the bucket all-reduces, fused SGD: ~1100 launches) is captured once
+    # into a hipGraph and the timed region replays it; the drop-path generator and the SGD pointer table are replay-safe
+    # (device-resident counter, captured upload).
     graph = None
     if want_graph:
         try:
@@ -273,35 +357,26 @@ def main():
                 probe.recording = False
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            if dist_graph:
-                reducer.active = False               # from here on: no hooks, the exchange follows the replay
             opt.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                static_loss = fwd_bwd() if dist_graph else step()
+                static_loss = step()
             graph.replay()                                        # one untimed replay
-            if dist_graph:
-                flat_reduce()
-                opt.step()
             torch.cuda.synchronize()
             if rank == 0:
-                print("[bench] timed region = hipGraph replay of the captured " +
-                      ("forward+backward, then RCCL all-reduce + fused SGD" if dist_graph else "step"), file=sys.stderr)
+                print("[bench] timed region = hipGraph replay of the captured step" +
+                      (" (RCCL bucket all-reduces inside the graph)" if use_dist else ""), file=sys.stderr)
         except Exception as e:                                    # capture unsupported here: fall back to eager timing
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr)
             graph = None
             probe.calls = []
-            if dist_graph:
-                dist_graph = False
-                reducer.active = True
             torch.cuda.synchronize()
-    if dist_graph or (use_dist and want_graph):
-        # all ranks must time the SAME path: the flat exchange and the hook-driven one issue different collectives
+    if use_dist and want_graph:
+        # all ranks must time the SAME path
         okf = torch.tensor([1.0 if graph is not None else 0.0], device=dev)
         dist.all_reduce(okf, op=dist.ReduceOp.MIN)
         if okf.item() < 0.5 and graph is not None:
-            graph, dist_graph = None, False
-            reducer.active = True
+            graph = None
             probe.calls = []
     if use_dist:
         dist.barrier()
@@ -310,9 +385,6 @@ def main():
     for i in range(args.steps):
         if graph is not None:
             graph.replay()
-            if dist_graph:
-                flat_reduce()
-                opt.step()
             loss = static_loss
         else:
             probe.recording = rank == 0 and i == args.steps - 1
@@ -329,6 +401,37 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
+    # ---- second timed variant: the reference loop's feeding (processor.py:73-78: H2D copy of the image tensors and labels
+    # every iteration; :107: a device synchronisation per iteration) - pinned double-buffered host batches, copy on a side
+    # stream into the (static) device inputs, the step, a sync.  Throughput = B / mean seconds per iteration (:114-118).
+    h2d = None
+    if world == 1 and not args.no_h2d and not force_ddp:
+        pins = [{k: v.clone().pin_memory() for k, v in img_h.items()} for _ in range(2)]
+        lab_pin = [t_.cpu().clone().pin_memory() for t_ in (label, cam, view)]
+        copy_s = torch.cuda.Stream()
+        times = []
+        for i in range(args.steps + 1):
+            t1 = time.perf_counter()
+            copy_s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(copy_s):
+                for k in img:
+                    img[k].copy_(pins[i & 1][k], non_blocking=True)
+                for dst, src in zip((label, cam, view), lab_pin):
+                    dst.copy_(src, non_blocking=True)
+            torch.cuda.current_stream().wait_stream(copy_s)
+            if graph is not None:
+                graph.replay()
+            else:
+                step()
+            torch.cuda.synchronize()
+            if i:                                                    # first iteration untimed
+                times.append(time.perf_counter() - t1)
+        mean_t = sum(times) / len(times)
+        h2d = {"value": round(b / mean_t, 2), "ms_per_step": round(1e3 * mean_t, 3),
+               "h2d_mb_per_step": round(sum(v.numel() * 4 for v in img_h.values()) / 1e6, 1),
+               "what": "pinned double-buffered H2D of the image tensors + labels every step, device sync per iteration "
+                       "(engine/processor.py:73-78,107); images/sec = B / mean s per iteration (:114-118)"}
+
     if rank == 0:
         kinds = {} if args.no_replay else probe.replay()
         flops = sum(v[0] for v in kinds.values())
@@ -336,30 +439,50 @@ def main():
         launches = sum(v[2] for v in kinds.values())
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         ms_step = 1e3 * elapsed / args.steps
+        arch = cfg.MODEL.TRANSFORMER_TYPE.replace("_patch16_224", "").replace("vit_", "ViT-").replace("base", "B").replace("large", "L")
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(tpath) and args.preset == "RGBNT201" and b == 128 and args.dtype == "bf16":
+            try:
+                traffic = json.load(open(tpath))
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_TFLOPS, 4),
+                "traffic": None if traffic is None else traffic.get("gemm_hbm_bytes_per_step"),
+                "traffic_note": None if traffic is None else traffic.get("note"),
+                "kernel": "16-bit GEMM family: gemm_bf16_pp_kernel (256x256x64 ping-pong, fwd + dgrad) and gemm_bf16_pipe_kernel "
+                          "(256x128x64, 3 LDS-DMA stages, wgrad), v_mfma_f32_16x16x32_" + ("f16" if args.dtype == "f16" else "bf16"),
+                "launches_per_step": launches, "gemm_ms_per_step": round(ms, 3),
+                "alg_tflop_per_step": round(flops / 1e12, 2),
+                "alg_bytes_per_step": None if traffic is None else traffic.get("gemm_alg_bytes_per_step"),
+                "by_kind": {k: {"tflops": round(f / (m_ * 1e-3) / 1e12, 1), "ms_per_step": round(m_, 3), "launches": n}
+                            for k, (f, m_, n) in kinds.items()}}
+        if args.dtype == "f32":
+            roof.update(bound="mfma (exact-f32 parity mode: v_mfma_f32_16x16x4_f32; not the performance path)",
+                        achieved=None, frac=None, peak=PEAK_F32_TFLOPS)
+        if not args.no_replay:
+            roof["hbm_kernels"] = hbm_kernels(model, img, b, model.act_dtype)
         out = {
             "metric": "tri-modal images/sec fwd+bwd @ B=128 ViT-B",
             "value": round(world * b * args.steps / elapsed, 2),
-            "unit": "tri-modal images/sec",
+            "unit": "tri-modal images/sec" if nmod == 3 else f"{nmod}-modal images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.preset} 3-modal ViT-B/16 {h}x{w}, batch {b}/GPU, fwd+bwd+SGD step, "
+            "config": {"workload": f"{args.preset} {nmod}-modal {arch}/16 {h}x{w}, batch {b}/GPU, fwd+bwd+SGD step, "
                                    f"drop_path 0.1, SFTS+HMA HIP kernels",
                        "global_batch": world * b, "parallelism": f"dp{world}", "loss": round(lossv, 4),
-                       "launch": ("hipGraph replay" + (" (fwd+bwd) + flat RCCL all-reduce + fused SGD" if dist_graph else ""))
-                       if graph is not None else "eager"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "kernel": "bf16 GEMM family: gemm_bf16_pp_kernel (256x256x64 ping-pong, fwd + dgrad) and gemm_bf16_pipe_kernel "
-                                   "(256x128x64, 3 LDS-DMA stages, wgrad), v_mfma_f32_16x16x32_bf16",
-                         "launches_per_step": launches, "gemm_ms_per_step": round(ms, 3),
-                         "alg_tflop_per_step": round(flops / 1e12, 2),
-                         "by_kind": {k: {"tflops": round(f / (m_ * 1e-3) / 1e12, 1), "ms_per_step": round(m_, 3), "launches": n}
-                                     for k, (f, m_, n) in kinds.items()}},
+                       "launch": ("hipGraph replay" + (" incl. RCCL bucket all-reduces (overlapped with backward)" if use_dist else ""))
+                       if graph is not None else ("eager" + (", RCCL bucket all-reduces overlapped with backward" if use_dist else "")),
+                       "grad_buckets": None if buckets is None else buckets.describe()},
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, cfg, cams)
+        if h2d is not None:
+            out["with_h2d_sync"] = h2d
+        if world == 1 and not args.no_cpu_baseline and not force_ddp:
+            out["cpu_baseline"] = cpu_baseline(model, cfg, cams, b, args.cpu_iters)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -23,9 +23,12 @@ _WEIGHT_EPOCH = 0
 # f16 mode: gradients that travel as half tensors (dy into the dgrad / wgrad products, attention backward, the LayerNorm
 # backward's input) are multiplied by this power of two where they are cast from the fp32 residual gradient and divided
 # out again where they return to fp32 (wgrad alpha, column sums, LayerNorm backward) - the static form of the
-# reference's amp.GradScaler (engine/processor.py:60,94-96).  Exact whenever nothing under- / overflows: half keeps
-# |g| * scale in [6e-8, 65504], i.e. gradient elements from 1.5e-11 to 16 at the default.  cfg.MODEL.GRAD_SCALE.
-F16_GRAD_SCALE = 4096.0
+# reference's amp.GradScaler (engine/processor.py:60,94-96; its initial scale is 65536).  Exact whenever nothing
+# under- / overflows: half keeps full precision for |g| * scale in [6.1e-5, 65504], i.e. activation-gradient elements
+# from 1.9e-9 to 2.0 at the default 2^15 (measured at B = 128: with 2^12 the first layer's gradients, ~1e-8 per
+# element, fell into the subnormal range and the patch-embedding weight gradient was 2.3 % off; the mean-reduced
+# losses keep elements far below 1).  cfg.MODEL.GRAD_SCALE overrides it.
+F16_GRAD_SCALE = 32768.0
 
 
 def set_f16_grad_scale(v):
@@ -106,11 +109,14 @@ def join_side_stream(device):
     _SIDE_KEEP.clear()          # (main-stream work enqueued from here on is ordered after the side stream's reads)
 
 
-def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None, gs=1.0):
+def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None, gs=1.0, dw_out=None,
+                db_out=None, dxcs_out=None):
     """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy) (or the
     caller's, when the kernel that produced dy summed its columns on the way).  dx_colsum: also return colsum(dx) - the
     bias gradient of the layer BELOW - from the dgrad's own epilogue when it can deliver it (else None).
-    gs: loss scale carried by dy (f16 mode): dx keeps it, dW / db / the returned column sums have it divided out."""
+    gs: loss scale carried by dy (f16 mode): dx keeps it, dW / db / the returned column sums have it divided out.
+    dw_out / db_out / dxcs_out: write the weight gradient / bias gradient / column sums of dx THERE (views of a gradient
+    bucket, editor_amd.ddp.GradBuckets) instead of into fresh tensors."""
     m, n = dy.shape
     k = x2d.shape[1]
     inv = 1.0 / gs
@@ -119,15 +125,15 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, 
     dx = torch.empty(m, k, dtype=x2d.dtype, device=dy.device)
     dxcs = None
     if dx_colsum and ops.gemm_colsum_ok(m, k, n, dx.dtype, 0, 1, m_live):
-        dxcs = torch.empty(k, dtype=torch.float32, device=dy.device)
+        dxcs = dxcs_out if dxcs_out is not None else torch.empty(k, dtype=torch.float32, device=dy.device)
     if gelu_pre is None:
         ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, m_live=m_live, colsum=dxcs, colsum_scale=inv)    # B stored (Kred=n, Nout=k)
     else:
         ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=gelu_pre, m_live=m_live, colsum=dxcs,
                  colsum_scale=inv)
-    dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
+    dw = dw_out if dw_out is not None else torch.empty(n, k, dtype=torch.float32, device=dy.device)
     if need_bias and db is None:
-        db = torch.empty(n, dtype=torch.float32, device=dy.device)
+        db = db_out if db_out is not None else torch.empty(n, dtype=torch.float32, device=dy.device)
         need_colsum = True
     else:
         need_colsum = False
@@ -179,7 +185,10 @@ class TransformerBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, mask, probs_out,
-                heads, eps, act_dtype, rowscale_attn, rowscale_mlp, cu=None, max_t=None, m_live=None, qk_scale=None):
+                heads, eps, act_dtype, rowscale_attn, rowscale_mlp, cu=None, max_t=None, m_live=None, qk_scale=None,
+                sink=None):
+        # sink (editor_amd.ddp.BlockSink or None): the 12 parameter gradients of this block are written straight into
+        # views of a flat all-reduce bucket and the bucket's collective is launched from the end of the backward
         # dense: x (B,T,D), mask (B,T) token mask.  packed (compacted HMA): x (M,D), cu (B+1) sequence row ranges,
         # max_t = longest sequence, mask (M) = 1 for live rows / 0 for the padding rows at the end.
         if cu is None:
@@ -212,14 +221,16 @@ class TransformerBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
                               qkvw, projw, fc1w, fc2w, mask, attn_saved, rowscale_attn, rowscale_mlp, cu, m_live)
         ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None,
-                    tuple(x.shape), qk_scale)
+                    tuple(x.shape), qk_scale, sink)
         return x2.view(x.shape)
 
     @staticmethod
     def backward(ctx, dx2):
         (x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w, qkvw, projw, fc1w, fc2w, mask,
          attn_saved, rs_attn, rs_mlp, cu, m_live) = ctx.saved_tensors
-        b, t, d, heads, act_dtype, hb_qkv, hb_proj, hb_fc1, hb_fc2, xshape, qk_scale = ctx.meta
+        b, t, d, heads, act_dtype, hb_qkv, hb_proj, hb_fc1, hb_fc2, xshape, qk_scale, sink = ctx.meta
+        # gradient outputs in forward-argument order: n1w n1b qkvw qkvb projw projb n2w n2b fc1w fc1b fc2w fc2b
+        sv = sink.views if sink is not None else [None] * 12
         gs = grad_scale(act_dtype)                   # f16: half gradients travel loss-scaled (1.0 otherwise)
         m = x2d.shape[0]
         hd = d // heads
@@ -227,29 +238,35 @@ class TransformerBlockFn(torch.autograd.Function):
         wq, wp, w1, w2 = (act_weight(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w))
         dx2 = dx2.contiguous().view(m, d)
         # ---- MLP branch:  x2 = x1 + rs * fc2(gelu(fc1(LN2(x1))))
-        dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2, gs)
+        dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2, gs, cs_out=sv[11])
         da, dw2, db2, da_cs = _linear_bwd(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live, db=dbias,
-                                          dx_colsum=hb_fc1, gs=gs)                       # da = (dy W2) * gelu'(a)
-        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs, gs=gs)
+                                          dx_colsum=hb_fc1, gs=gs, dw_out=sv[10], db_out=sv[11],
+                                          dxcs_out=sv[9])                                # da = (dy W2) * gelu'(a)
+        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs, gs=gs, dw_out=sv[8], db_out=sv[9])
         dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w, mean2, rstd2, mask, 0, dx_in=dx2, m_live=m_live,
-                                            dy_scale=1.0 / gs)
+                                            dy_scale=1.0 / gs, dgb_out=sink.ln_pair(6) if sink is not None else None)
         # ---- attention branch:  x1 = x + rs * proj(attn(qkv(LN1(x))))
-        dy, dbias = _scaled_cast_colsum(dx1, rs_attn, act_dtype, m_live, hb_proj, gs)
-        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live, db=dbias, gs=gs)
+        dy, dbias = _scaled_cast_colsum(dx1, rs_attn, act_dtype, m_live, hb_proj, gs, cs_out=sv[5])
+        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live, db=dbias, gs=gs, dw_out=sv[4], db_out=sv[5])
         dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, amask, attn_saved, ao, cu=cu, scale=qk_scale)
-        dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live, gs=gs)
+        dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live, gs=gs, dw_out=sv[2], db_out=sv[3])
         dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1, m_live=m_live,
-                                           dy_scale=1.0 / gs)
+                                           dy_scale=1.0 / gs, dgb_out=sink.ln_pair(0) if sink is not None else None)
         join_side_stream(dx.device)                  # the four weight gradients (side stream) are complete
-        return (dx.view(xshape), dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2,
-                None, None, None, None, None, None, None, None, None, None, None)
+        grads = (dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2)
+        if sink is not None:
+            # the gradients already sit in the bucket (= the parameters' .grad): hand autograd nothing for them and let
+            # the bucket's all-reduce start now, under the rest of the backward
+            grads = tuple(None if v is not None else g_ for g_, v in zip(grads, sv))
+            sink.done()
+        return (dx.view(xshape),) + grads + (None,) * 13
 
 
-def _scaled_cast_colsum(dx, rowscale, dtype, m_live, want_colsum, gs=1.0):
+def _scaled_cast_colsum(dx, rowscale, dtype, m_live, want_colsum, gs=1.0, cs_out=None):
     """_scaled_cast, plus the (unscaled) column sums of the result when the consumer has a bias (dense 16-bit rows only)."""
     if (want_colsum and m_live is None and dtype in ops.HALF_DTYPES and dx.dtype == torch.float32
             and dx.shape[1] % 256 == 0 and dx.shape[1] <= 1024):
-        return ops.cast_rows_colsum(dx, rowscale, dtype, gs)
+        return ops.cast_rows_colsum(dx, rowscale, dtype, gs, cs_out)
     return _scaled_cast(dx, rowscale, dtype, m_live, gs), None
 
 

@@ -292,6 +292,7 @@ class EDITOR(nn.Module):
         self.hma_compact = bool(getattr(cfg.MODEL, "HMA_COMPACT", True))
         self.rollout_probs = bool(getattr(cfg.MODEL, "ROLLOUT_PROBS", False))
         self.teacher_index = None            # optional (B,N) bool: force the SFTS selection (bf16 protocol)
+        self.grad_buckets = None             # editor_amd.ddp.GradBuckets once enable_grad_buckets() was called
         self._drop_rates_dev = None
         self._drop_state = None
         self.last_aux = {}
@@ -303,6 +304,36 @@ class EDITOR(nn.Module):
         for k in param_dict:
             sd[k.replace("module.", "")].copy_(param_dict[k])
         print("Loading pretrained model from {}".format(trained_path))
+
+    # -- data-parallel gradient buckets (editor_amd.ddp.GradBuckets) ------------------------------------------------
+    def grad_segments(self):
+        """Transformer blocks in the order their gradients become READY in the backward: joint HMA block, the per-modality
+        HMA blocks (last modality first), backbone blocks depth-1 .. 0; plus the remaining parameters (tail)."""
+        fb = self.FUSE_block
+        segs = [("hma.joint", list(_block_args(fb.norm1, fb.attn1, fb.norm2, fb.mlp)))]
+        for m_ in reversed(self.modalities):
+            tag = m_[2]
+            segs.append(("hma." + tag, list(_block_args(getattr(fb, "norm" + tag), getattr(fb, "attn" + tag),
+                                                        getattr(fb, "norm" + tag + "_"), getattr(fb, "mlp" + tag)))))
+        blocks = self.BACKBONE.base.blocks
+        for i in reversed(range(len(blocks))):
+            blk = blocks[i]
+            segs.append(("backbone.%d" % i, list(_block_args(blk.norm1, blk.attn, blk.norm2, blk.mlp))))
+        inseg = {id(p) for _, ps in segs for p in ps if p is not None}
+        tail = [p for p in self.parameters() if id(p) not in inseg]
+        return segs, tail
+
+    def enable_grad_buckets(self, bucket_bytes=64 << 20, process_group=None, force=False):
+        from ..ddp import GradBuckets
+        segs, tail = self.grad_segments()
+        self.grad_buckets = GradBuckets(segs, tail, bucket_bytes, process_group, force)
+        self._seg_index = {name: i for i, (name, _) in enumerate(segs)}
+        return self.grad_buckets
+
+    def _sink(self, name):
+        if self.grad_buckets is None or not torch.is_grad_enabled():
+            return None
+        return self.grad_buckets.sink(self._seg_index[name])
 
     # -- stages ------------------------------------------------------------------------------------
     def _backbone(self, imgs, cam):
@@ -340,7 +371,7 @@ class EDITOR(nn.Module):
                 rs_a, rs_m = scales[i, 0], scales[i, 1]
             x = fn.TransformerBlockFn.apply(x, *_block_args(blk.norm1, blk.attn, blk.norm2, blk.mlp), None,
                                             probs if recompute else probs[i], base.heads, 1e-6, self.act_dtype, rs_a, rs_m,
-                                            None, None, None, base.qk_scale)
+                                            None, None, None, base.qk_scale, self._sink("backbone.%d" % i))
         x = fn.LayerNormFn.apply(x, base.norm.weight, base.norm.bias, 1e-6, None)
         return x, probs
 
@@ -379,14 +410,16 @@ class EDITOR(nn.Module):
             args = _block_args(getattr(fb, "norm" + tag), getattr(fb, "attn" + tag), getattr(fb, "norm" + tag + "_"),
                                getattr(fb, "mlp" + tag))
             mods.append(fn.TransformerBlockFn.apply(feats_mod[i], *args, mask, None, self.hma_heads, 1e-5,
-                                                    self.act_dtype, None, None))
+                                                    self.act_dtype, None, None, None, None, None, None,
+                                                    self._sink("hma." + tag)))
         loss_ocfr = None
         if self.training:
             loss_ocfr = self._ocfr([m_[:, 0] for m_ in mods], label)
         x = torch.cat(mods, dim=1)
         mask3 = mask.repeat(1, nmod).contiguous()
         x = fn.TransformerBlockFn.apply(x, *_block_args(fb.norm1, fb.attn1, fb.norm2, fb.mlp), mask3, None,
-                                        self.hma_heads, 1e-5, self.act_dtype, None, None)
+                                        self.hma_heads, 1e-5, self.act_dtype, None, None, None, None, None, None,
+                                        self._sink("hma.joint"))
         x = fn.LayerNormFn.apply(x, fb.out_norm.weight, fb.out_norm.bias, 1e-5, mask3.view(-1))
         return x, loss_ocfr
 
@@ -404,7 +437,7 @@ class EDITOR(nn.Module):
                                getattr(fb, "mlp" + tag))
             mods.append(fn.TransformerBlockFn.apply(xa_mod[i], *args, plan.mask_a, None,
                                                     self.hma_heads, 1e-5, self.act_dtype, None, None, plan.cu, t,
-                                                    plan.live_a))
+                                                    plan.live_a, None, self._sink("hma." + tag)))
         xa = torch.cat(mods, dim=0)
         loss_ocfr = None
         if self.training:
@@ -412,7 +445,8 @@ class EDITOR(nn.Module):
             loss_ocfr = self._ocfr(list(cls.unbind(0)), label)
         xb = fn.GatherRowsFn.apply(xa, plan.map_b, plan.live_a, nmod, plan.mb)             # layout B (MB, D)
         xb = fn.TransformerBlockFn.apply(xb, *_block_args(fb.norm1, fb.attn1, fb.norm2, fb.mlp), plan.mask_b, None,
-                                         self.hma_heads, 1e-5, self.act_dtype, None, None, plan.cu3, nmod * t, plan.live_b)
+                                         self.hma_heads, 1e-5, self.act_dtype, None, None, plan.cu3, nmod * t, plan.live_b,
+                                         None, self._sink("hma.joint"))
         xb = fn.LayerNormFn.apply(xb, fb.out_norm.weight, fb.out_norm.bias, 1e-5, plan.mask_b, plan.live_b)
         pooled, num = fn.PoolPackedFn.apply(xb, plan.cu, b, nmod)
         self.last_aux["plan"] = plan

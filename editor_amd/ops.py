@@ -134,10 +134,14 @@ def layernorm_fwd(x2d, gamma, beta, eps, out_dtype, rowmask=None, mask_period=0,
 
 
 def layernorm_bwd(dy, x2d, gamma, mean, rstd, rowmask=None, mask_period=0, dx_in=None, want_param_grads=True,
-                  m_live=None, dy_scale=1.0):
+                  m_live=None, dy_scale=1.0, dgb_out=None):
+    """dgb_out: optional (2, D) fp32 view that receives [dgamma; dbeta] (adjacent slots of a gradient bucket)."""
     m, d = x2d.shape
     dx = torch.empty(m, d, dtype=torch.float32, device=x2d.device)
-    dgb = torch.empty(2, d, dtype=torch.float32, device=x2d.device) if want_param_grads else None
+    if dgb_out is not None:
+        dgb = dgb_out
+    else:
+        dgb = torch.empty(2, d, dtype=torch.float32, device=x2d.device) if want_param_grads else None
     dg = dgb[0] if want_param_grads else None
     db = dgb[1] if want_param_grads else None
     ws = workspace(x2d.device, WS_ROWS * 2 * d)
@@ -192,11 +196,11 @@ def cast_rows(x2d, rowscale, dtype, m_live=None, scale=1.0):
     return out
 
 
-def cast_rows_colsum(x2d, rowscale, dtype, scale=1.0):
+def cast_rows_colsum(x2d, rowscale, dtype, scale=1.0, cs_out=None):
     """cast_rows + the column sums of its output (bias gradient, with the scale removed again) in the same pass."""
     m, d = x2d.shape
     out = torch.empty(m, d, dtype=dtype, device=x2d.device)
-    cs = torch.empty(d, dtype=torch.float32, device=x2d.device)
+    cs = cs_out if cs_out is not None else torch.empty(d, dtype=torch.float32, device=x2d.device)
     ws = workspace(x2d.device, WS_ROWS * d)
     call("editor_cast_rows_colsum", x2d, rowscale, m, d, out, _is_bf16(out), cs, ws, WS_ROWS, float(scale), 1.0 / float(scale))
     return out, cs

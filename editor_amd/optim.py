@@ -76,7 +76,10 @@ class FusedSGD:
     # -- torch.optim.Optimizer surface --------------------------------------------------------------------
     def zero_grad(self, set_to_none=True):
         for _, p in self.params:
-            if set_to_none or p.grad is None:
+            sink = getattr(p, "_grad_sink", None)
+            if sink is not None:
+                p.grad = sink                    # gradient lives in an all-reduce bucket slot that the backward overwrites
+            elif set_to_none or p.grad is None:
                 p.grad = None
             else:
                 p.grad.zero_()

@@ -104,3 +104,65 @@ def test_flat_all_reduce_world2():
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker_flat, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world))
+
+
+def _worker_buckets(rank, world, port, ret):
+    """GradBuckets (the in-backward, graph-capturable exchange bench.py times) on the REAL EDITOR parameter list: bucket
+    plan in gradient-ready order, in-place gradient slots, launch when a bucket's last block reports, tail bucket with
+    never-used parameters skipped, averaging."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import contextlib
+    import io
+    from editor_amd import config
+    from editor_amd.modeling import make_model
+    cfg, c, cams = config.preset("RGBNT100")              # AL = 0: AL_* absent, BACKBONE_HEAD / BN in use
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = make_model(cfg, c, cams)
+    gb = m.enable_grad_buckets(bucket_bytes=64 << 20)
+    ok = gb.active
+    segs, tail = m.grad_segments()
+    names = {id(p): n for n, p in m.named_parameters()}
+    ok &= [s[0] for s in segs][:5] == ["hma.joint", "hma.T", "hma.N", "hma.R", "backbone.11"] and segs[-1][0] == "backbone.0"
+    ok &= 6 <= len(gb.buckets) <= 9                                   # 16 blocks x 28.3 MB in <= 64 MiB buckets
+    total = sum(b["flat"].numel() for b in gb.buckets) + sum(p.numel() for p in tail if p.requires_grad)
+    ok &= total == sum(p.numel() for p in m.parameters() if p.requires_grad)
+    launched = []
+    orig = gb._launch
+    gb._launch = lambda b: (launched.append(id(b)), orig(b))[1]
+    for step in range(2):
+        # "backward": blocks report in ready order after writing rank-dependent gradients into their slots
+        for si, (name, params) in enumerate(segs):
+            sink = gb.sink(si)
+            for j, v in enumerate(sink.views):
+                if v is not None:
+                    v.fill_(float((rank + 1) * (si + 1) + j + step))
+            before = len(launched)
+            sink.done()
+            last_of_bucket = si == gb.buckets[gb.seg_bucket[si]]["segs"][-1]
+            ok &= (len(launched) == before + 1) == last_of_bucket     # collective issued exactly when the bucket is complete
+        for p in tail:                                                 # small parameters: ordinary .grad tensors
+            n = names[id(p)]
+            used = p.requires_grad and not n.startswith("BACKBONE.base.fc")
+            p.grad = torch.full_like(p, float(rank + 1 + step)) if used else None
+        gb.finish()
+        for si, (name, params) in enumerate(segs):
+            for j, p in enumerate(params):
+                if p is not None:
+                    want = sum((r + 1) * (si + 1) + j + step for r in range(world)) / world
+                    ok &= bool((p.grad == want).all()) and p.grad.data_ptr() == gb.sink(si).views[j].data_ptr()
+        for p in tail:
+            if p.grad is not None:
+                ok &= bool(torch.allclose(p.grad, torch.full_like(p, sum(r + 1 + step for r in range(world)) / world)))
+        ln = gb.sink(0).ln_pair(0)                                     # [dgamma; dbeta] of a LayerNorm are adjacent slots
+        ok &= ln.shape == (2, 768) and ln.data_ptr() == segs[0][1][0].grad.data_ptr()
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_grad_buckets_real_parameter_list_world2():
+    world = 2
+    port = _free_port()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker_buckets, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world))

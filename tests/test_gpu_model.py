@@ -185,7 +185,7 @@ def test_f16_grad_scale_is_transparent():
     grads = {}
     old = fnc.F16_GRAD_SCALE
     try:
-        for gs in (1024.0, 16384.0):
+        for gs in (2048.0, 32768.0):
             fnc.set_f16_grad_scale(gs)
             m, cfg, c, cams = _model("RGBNT201", seed, "f16", drop_path=0.0)
             m.train()
@@ -201,9 +201,9 @@ def test_f16_grad_scale_is_transparent():
                                                                   "FUSE_block.attn1.qkv.weight", "BACKBONE.base.cls_token")}
     finally:
         fnc.set_f16_grad_scale(old)
-    for k in grads[1024.0]:
-        assert torch.isfinite(grads[16384.0][k]).all()
-        assert rel_err(grads[1024.0][k], grads[16384.0][k]) < 2e-3, k
+    for k in grads[2048.0]:
+        assert torch.isfinite(grads[32768.0][k]).all()
+        assert rel_err(grads[2048.0][k], grads[32768.0][k]) < 2e-3, k
 
 
 def test_hma_compact_equals_dense_bf16():

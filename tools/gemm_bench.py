@@ -24,7 +24,24 @@ def bench(fn, iters=20):
     return e0.elapsed_time(e1) / iters
 
 
+def use_trace_build():
+    """EDITOR_GEMM_TRACE / EDITOR_GEMM_PP / EDITOR_GEMM_PP_STAGED are honoured by the DEBUG build of the GEMM only
+    (libeditor_gemm_trace.so, include/editor_debug.h): build it and route the two GEMM entry points there."""
+    from editor_amd import _lib, build
+    build.build(trace=True)
+    import ctypes
+    tr = ctypes.CDLL(build.LIB_TRACE)
+    lib = _lib.lib()
+    for name in ("editor_gemm_bf16", "editor_gemm_f16"):
+        fn = getattr(tr, name)
+        fn.argtypes = lib.protos[name]
+        fn.restype = ctypes.c_int
+        lib._fn[name] = fn
+
+
 def main():
+    if any(os.environ.get(k) for k in ("EDITOR_GEMM_TRACE", "EDITOR_GEMM_PP", "EDITOR_GEMM_PP_STAGED")):
+        use_trace_build()
     m = int(os.environ.get("GEMM_M", 3 * 128 * 129))
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
