@@ -58,6 +58,7 @@ struct GemmB16Args {
     float* colsum;                           // EDITOR_EPI_COLSUM: [tiles_m][N] column sums of the rounded output tile rows
     unsigned long long* trace;               // debug (EDITOR_GEMM_TRACE): per-workgroup s_memtime stamps
     int force_pp;                            // EDITOR_EPI_FORCE_PP: the 256x256 kernel whatever the heuristic says
+    int aux_grad;                            // EDITOR_EPI_AUX_GRAD: aux holds gelu'(pre-activation), not the pre-activation
 };
 
 // exact-erf GELU (nn.GELU default) for bf16 outputs, two values per instruction (v_pk_fma_f32 / v_pk_mul_f32):
@@ -217,12 +218,18 @@ __device__ __forceinline__ void epilogue_store(const GemmB16Args& g, float4_t (&
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             } else if (g.epilogue == EDITOR_EPI_GELU) {       // aux = v (pre-activation, bf16), C = gelu(v)
                 uint2 pre; pre.x = H16<F16>::pack2(v.x, v.y); pre.y = H16<F16>::pack2(v.z, v.w);
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = pre;
+                uint2 sv = pre;
+                if (g.aux_grad) {
+                    const v2f_t d0 = gelu_grad2(H16<F16>::unpack2(pre.x)), d1 = gelu_grad2(H16<F16>::unpack2(pre.y));
+                    sv.x = H16<F16>::pack2(d0.x, d0.y); sv.y = H16<F16>::pack2(d1.x, d1.y);
+                }
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = sv;
                 const v2f_t g0 = gelu2(H16<F16>::unpack2(pre.x)), g1 = gelu2(H16<F16>::unpack2(pre.y));
                 v.x = g0.x; v.y = g0.y; v.z = g1.x; v.w = g1.y;
             } else if (g.epilogue == EDITOR_EPI_GELU_BWD) {   // C = v * gelu'(aux), aux = saved pre-activation
                 const uint2 pre = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ldaux + n);
-                const v2f_t g0 = gelu_grad2(H16<F16>::unpack2(pre.x)), g1 = gelu_grad2(H16<F16>::unpack2(pre.y));
+                const v2f_t u0 = H16<F16>::unpack2(pre.x), u1 = H16<F16>::unpack2(pre.y);
+                const v2f_t g0 = g.aux_grad ? u0 : gelu_grad2(u0), g1 = g.aux_grad ? u1 : gelu_grad2(u1);
                 v.x *= g0.x; v.y *= g0.y; v.z *= g1.x; v.w *= g1.y;
             }
             if (C_F32) {
@@ -399,8 +406,14 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
             } else if (EPI == EDITOR_EPI_GELU) {                 // aux <- pre-activation (bf16), C <- gelu(rounded pre-activation)
                 uint4 p;
                 p.x = H16<F16>::pack2(x[0], x[1]); p.y = H16<F16>::pack2(x[2], x[3]); p.z = H16<F16>::pack2(x[4], x[5]); p.w = H16<F16>::pack2(x[6], x[7]);
-                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = p;
                 const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+                if (g.aux_grad) {                                // save gelu'(rounded pre-activation) for the backward instead
+                    uint32_t dw_[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const v2f_t dv = gelu_grad2(H16<F16>::unpack2(pw[e])); dw_[e] = H16<F16>::pack2(dv.x, dv.y); }
+                    p = make_uint4(dw_[0], dw_[1], dw_[2], dw_[3]);
+                }
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = p;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const v2f_t gv = gelu2(H16<F16>::unpack2(pw[e]));
@@ -411,7 +424,8 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
                 const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const v2f_t gv = gelu_grad2(H16<F16>::unpack2(pw[e]));
+                    const v2f_t uv = H16<F16>::unpack2(pw[e]);
+                    const v2f_t gv = g.aux_grad ? uv : gelu_grad2(uv);
                     x[2 * e] *= gv.x; x[2 * e + 1] *= gv.y;
                 }
             }
@@ -979,7 +993,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int nl = wc * 64 + j * 16 + lg * 4;
-                    const v2f_t g0 = gelu_grad2(H16<F16>::unpack2(pre[i][j].x)), g1 = gelu_grad2(H16<F16>::unpack2(pre[i][j].y));
+                    const v2f_t u0 = H16<F16>::unpack2(pre[i][j].x), u1 = H16<F16>::unpack2(pre[i][j].y);
+                    const v2f_t g0 = g.aux_grad ? u0 : gelu_grad2(u0), g1 = g.aux_grad ? u1 : gelu_grad2(u1);
                     uint2 o;
                     o.x = H16<F16>::pack2((acc[i][j][0] * g.alpha + bv[j].x) * rs * g0.x, (acc[i][j][1] * g.alpha + bv[j].y) * rs * g0.y);
                     o.y = H16<F16>::pack2((acc[i][j][2] * g.alpha + bv[j].z) * rs * g1.x, (acc[i][j][3] * g.alpha + bv[j].w) * rs * g1.y);
@@ -1015,8 +1030,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
             uint4 p = *reinterpret_cast<const uint4*>(smem + row * RB + cg * 16);
             if (m >= g.M || n >= g.N) continue;
             if (gelu) {
-                *reinterpret_cast<uint4*>(Ab + (long)m * g.ldaux + n) = p;
                 uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+                if (g.aux_grad) {        // the backward only needs gelu'(pre-activation): save THAT (one multiply there instead of
+                    uint32_t dw_[4];     // an erfc + exponential per element in the dgrad epilogue)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const v2f_t dv = gelu_grad2(H16<F16>::unpack2(pw[e])); dw_[e] = H16<F16>::pack2(dv.x, dv.y); }
+                    *reinterpret_cast<uint4*>(Ab + (long)m * g.ldaux + n) = make_uint4(dw_[0], dw_[1], dw_[2], dw_[3]);
+                } else {
+                    *reinterpret_cast<uint4*>(Ab + (long)m * g.ldaux + n) = p;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                 { const v2f_t gv = gelu2(H16<F16>::unpack2(pw[e])); pw[e] = H16<F16>::pack2(gv.x, gv.y); }
@@ -1217,7 +1239,9 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
         return (int)hipErrorInvalidValue;
     const bool want_colsum = (epilogue & EDITOR_EPI_COLSUM) != 0;
     const bool force_pp = (epilogue & EDITOR_EPI_FORCE_PP) != 0;
-    epilogue &= ~(EDITOR_EPI_COLSUM | EDITOR_EPI_FORCE_PP);
+    const bool aux_grad = (epilogue & EDITOR_EPI_AUX_GRAD) != 0;
+    epilogue &= ~(EDITOR_EPI_COLSUM | EDITOR_EPI_FORCE_PP | EDITOR_EPI_AUX_GRAD);
+    if (aux_grad && epilogue != EDITOR_EPI_GELU && epilogue != EDITOR_EPI_GELU_BWD) return (int)hipErrorInvalidValue;
     if (want_colsum && (c_f32 || epilogue == EDITOR_EPI_RESIDUAL || splitk > 1 || !splitk_ws || transA || M < 2048 || N < 512 ||
                         (N & 7) || (ldc & 7) || (ldaux & 7) || (K % BK) || beta != 0.f || m_live))
         return (int)hipErrorInvalidValue;                        // the column sums exist in the one-pass 256x256 epilogue only
@@ -1241,7 +1265,7 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
     GemmB16Args g{(const bf16_t*)A, (const bf16_t*)B, slabs ? (void*)splitk_ws : C, M, N, K, lda, ldb, ldc, alpha,
                   slabs ? 0.f : beta, bias, rowscale, splitk, (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux,
                   slabs ? 1 : 0,
-                  m_live, transA ? 1 : 0, 0, want_colsum ? splitk_ws : nullptr, nullptr, force_pp ? 1 : 0};
+                  m_live, transA ? 1 : 0, 0, want_colsum ? splitk_ws : nullptr, nullptr, force_pp ? 1 : 0, aux_grad ? 1 : 0};
     if (m_live && (!pipe || (splitk > 1 && !slabs))) return (int)hipErrorInvalidValue;   // live-row form: pipelined path only
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
     int rc;

@@ -50,10 +50,28 @@ def invalidate_weight_cache():
     _WEIGHT_EPOCH += 1
 
 
-def install_weight_copies(pairs):
-    """(parameter, bf16 tensor holding its current value) pairs -> entries of the operand cache for the current epoch."""
+def install_weight_copies(pairs, transposed=False):
+    """(parameter, 16-bit tensor holding its current value [transposed]) pairs -> entries of the operand cache for the
+    current epoch."""
     for w, h in pairs:
-        _BF16_CACHE[(id(w), h.dtype)] = (weakref.ref(w), w._version, h, w.data_ptr(), _WEIGHT_EPOCH)
+        key = (id(w), h.dtype, "T") if transposed else (id(w), h.dtype)
+        _BF16_CACHE[key] = (weakref.ref(w), w._version, h, w.data_ptr(), _WEIGHT_EPOCH)
+
+
+# dgrad products with BOTH operands k-major: needs W^T (K_in, N_out) next to W (N_out, K_in) - 2 400 instead of 2 840
+# cycles per K-tile in the 256x256 kernel (the row-k operand goes through ds_read_b64_tr_b16, twice the LDS instructions)
+DGRAD_KMAJOR = os.environ.get("EDITOR_DGRAD_KMAJOR", "1") != "0"
+
+
+def act_weight_t(w, dtype):
+    """16-bit W^T (contiguous) of a 2-D fp32 master weight, cached like act_weight (FusedSGD refreshes it in its own launch)."""
+    key = (id(w), dtype, "T")
+    ent = _BF16_CACHE.get(key)
+    ver = w._version
+    if ent is None or ent[0]() is not w or ent[1] != ver or ent[3] != w.data_ptr() or ent[4] != _WEIGHT_EPOCH:
+        ent = (weakref.ref(w), ver, act_weight(w, dtype).t().contiguous(), w.data_ptr(), _WEIGHT_EPOCH)
+        _BF16_CACHE[key] = ent
+    return ent[2]
 
 
 def act_weight(w, dtype):
@@ -110,7 +128,7 @@ def join_side_stream(device):
 
 
 def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None, gs=1.0, dw_out=None,
-                db_out=None, dxcs_out=None):
+                db_out=None, dxcs_out=None, w_t=None):
     """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy) (or the
     caller's, when the kernel that produced dy summed its columns on the way).  dx_colsum: also return colsum(dx) - the
     bias gradient of the layer BELOW - from the dgrad's own epilogue when it can deliver it (else None).
@@ -126,11 +144,14 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, 
     dxcs = None
     if dx_colsum and ops.gemm_colsum_ok(m, k, n, dx.dtype, 0, 1, m_live):
         dxcs = dxcs_out if dxcs_out is not None else torch.empty(k, dtype=torch.float32, device=dy.device)
+    # B = W stored (Kred=n, Nout=k): row-k operand (trans_b = 1); or its k-major copy W^T (Nout=k, Kred=n): trans_b = 0
+    wb, ldb, tb = (w_t, n, 0) if w_t is not None else (w_act, k, 1)
     if gelu_pre is None:
-        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, m_live=m_live, colsum=dxcs, colsum_scale=inv)    # B stored (Kred=n, Nout=k)
+        ops.gemm(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, m_live=m_live, colsum=dxcs, colsum_scale=inv)
     else:
-        ops.gemm(dy, w_act, dx, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=gelu_pre, m_live=m_live, colsum=dxcs,
-                 colsum_scale=inv)
+        ag = ops.EPI_AUX_GRAD if dy.dtype in ops.HALF_DTYPES else 0      # 16-bit: gelu_pre holds gelu'(pre-activation)
+        ops.gemm(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, epilogue=ops.EPI_GELU_BWD | ag, aux=gelu_pre, m_live=m_live,
+                 colsum=dxcs, colsum_scale=inv)
     dw = dw_out if dw_out is not None else torch.empty(n, k, dtype=torch.float32, device=dy.device)
     if need_bias and db is None:
         db = db_out if db_out is not None else torch.empty(n, dtype=torch.float32, device=dy.device)
@@ -214,7 +235,10 @@ class TransformerBlockFn(torch.autograd.Function):
         hidden = w1.shape[0]
         a = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
         g = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
-        ops.gemm(h2, w1, g, m, hidden, d, d, d, hidden, 0, 0, bias=fc1b, epilogue=ops.EPI_GELU, aux=a, m_live=m_live)
+        # 16-bit modes: `a` receives gelu'(pre-activation) - all the backward needs of it (one multiply in the fc2 dgrad
+        # epilogue instead of an erfc + exponential per element); the f32 parity kernels keep the pre-activation
+        ag = ops.EPI_AUX_GRAD if act_dtype in ops.HALF_DTYPES else 0
+        ops.gemm(h2, w1, g, m, hidden, d, d, d, hidden, 0, 0, bias=fc1b, epilogue=ops.EPI_GELU | ag, aux=a, m_live=m_live)
         x2 = torch.empty_like(x2d)
         ops.gemm(g, w2, x2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b, rowscale=rowscale_mlp,
                  epilogue=ops.EPI_RESIDUAL, aux=x1, m_live=m_live)
@@ -236,20 +260,22 @@ class TransformerBlockFn(torch.autograd.Function):
         hd = d // heads
         amask = None if cu is not None else mask
         wq, wp, w1, w2 = (act_weight(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w))
+        kmaj = DGRAD_KMAJOR and act_dtype in ops.HALF_DTYPES and m >= 2048
+        wqt, wpt, w1t, w2t = ((act_weight_t(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w)) if kmaj else (None,) * 4)
         dx2 = dx2.contiguous().view(m, d)
         # ---- MLP branch:  x2 = x1 + rs * fc2(gelu(fc1(LN2(x1))))
         dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2, gs, cs_out=sv[11])
         da, dw2, db2, da_cs = _linear_bwd(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live, db=dbias,
                                           dx_colsum=hb_fc1, gs=gs, dw_out=sv[10], db_out=sv[11],
-                                          dxcs_out=sv[9])                                # da = (dy W2) * gelu'(a)
-        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs, gs=gs, dw_out=sv[8], db_out=sv[9])
+                                          dxcs_out=sv[9], w_t=w2t)                       # da = (dy W2) * gelu'(a)
+        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs, gs=gs, dw_out=sv[8], db_out=sv[9], w_t=w1t)
         dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w, mean2, rstd2, mask, 0, dx_in=dx2, m_live=m_live,
                                             dy_scale=1.0 / gs, dgb_out=sink.ln_pair(6) if sink is not None else None)
         # ---- attention branch:  x1 = x + rs * proj(attn(qkv(LN1(x))))
         dy, dbias = _scaled_cast_colsum(dx1, rs_attn, act_dtype, m_live, hb_proj, gs, cs_out=sv[5])
-        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live, db=dbias, gs=gs, dw_out=sv[4], db_out=sv[5])
+        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live, db=dbias, gs=gs, dw_out=sv[4], db_out=sv[5], w_t=wpt)
         dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, amask, attn_saved, ao, cu=cu, scale=qk_scale)
-        dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live, gs=gs, dw_out=sv[2], db_out=sv[3])
+        dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live, gs=gs, dw_out=sv[2], db_out=sv[3], w_t=wqt)
         dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1, m_live=m_live,
                                            dy_scale=1.0 / gs, dgb_out=sink.ln_pair(0) if sink is not None else None)
         join_side_stream(dx.device)                  # the four weight gradients (side stream) are complete

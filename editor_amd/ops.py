@@ -269,6 +269,7 @@ EPI_NONE, EPI_RESIDUAL, EPI_GELU, EPI_GELU_BWD = 0, 1, 2, 3
 
 
 EPI_COLSUM = 0x100
+EPI_AUX_GRAD = 0x400          # with EPI_GELU / EPI_GELU_BWD (16-bit): aux = gelu'(pre-activation) instead of the pre-activation
 EPI_FORCE_PP = 0x200          # run the 256x256 ping-pong kernel whatever the shape heuristic says (tests)
 
 

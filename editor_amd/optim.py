@@ -61,6 +61,25 @@ class FusedSGD:
         self.shadows = [torch.empty(p.shape, dtype=shadow_dtype, device=dev) if (shadow_dtype is not None and p.dim() >= 2)
                         else None for _, p in self.params]
         self.h_ptrs = torch.tensor([0 if h is None else h.data_ptr() for h in self.shadows], dtype=torch.int64, device=dev)
+        # k-major (transposed) shadows of the 2-D GEMM weights for the dgrad products, refreshed by one multi-tensor
+        # transpose launch after the update (editor_transpose_multi)
+        self.shadows_t = [torch.empty(p.shape[1], p.shape[0], dtype=shadow_dtype, device=dev)
+                          if (h is not None and p.dim() == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0
+                              and p.numel() >= (1 << 18)) else None for (_, p), h in zip(self.params, self.shadows)]
+        tt = [i for i, h in enumerate(self.shadows_t) if h is not None]
+        self._tr = None
+        if tt:
+            tile_t, tile_r, tile_c = [], [], []
+            for j, i in enumerate(tt):
+                r, c = self.params[i][1].shape
+                for a in range(r // 64):
+                    for b_ in range(c // 64):
+                        tile_t.append(j); tile_r.append(a); tile_c.append(b_)
+            i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+            self._tr = dict(src=torch.tensor([self.shadows[i].data_ptr() for i in tt], dtype=torch.int64, device=dev),
+                            dst=torch.tensor([self.shadows_t[i].data_ptr() for i in tt], dtype=torch.int64, device=dev),
+                            rows=i32([self.params[i][1].shape[0] for i in tt]), cols=i32([self.params[i][1].shape[1] for i in tt]),
+                            tile_t=i32(tile_t), tile_r=i32(tile_r), tile_c=i32(tile_c), n=len(tile_t))
         self.p_ptrs = torch.tensor([p.data_ptr() for _, p in self.params], dtype=torch.int64, device=dev)
         self.m_ptrs = torch.tensor([b.data_ptr() for b in self.bufs], dtype=torch.int64, device=dev)
         # gradient tensors are new every step: their addresses go to the device through double-buffered pinned staging
@@ -180,5 +199,12 @@ class FusedSGD:
         from . import functional
         functional.invalidate_weight_cache()
         if self.shadow_dtype is not None:
+            if self._tr is not None:
+                tr = self._tr
+                with torch.cuda.device(self.device):
+                    _lib.call("editor_transpose_multi", tr["src"], tr["dst"], tr["rows"], tr["cols"], tr["tile_t"], tr["tile_r"],
+                              tr["tile_c"], tr["n"])
             functional.install_weight_copies((p, h) for (_, p), h in zip(self.params, self.shadows)
                                              if h is not None and p.grad is not None)
+            functional.install_weight_copies(((p, h) for (_, p), h in zip(self.params, self.shadows_t)
+                                              if h is not None and p.grad is not None), transposed=True)

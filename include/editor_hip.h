@@ -37,6 +37,9 @@ typedef struct ihipStream_t* editor_stream_t;   /* == hipStream_t */
 #define EDITOR_EPI_COLSUM 0x100 /* OR-able (editor_gemm_bf16, bf16 C, M >= 2048, N >= 512, A k-major, splitk 1): also write
                                  * the column sums of every 256-row tile of the ROUNDED C to splitk_ws[(M+255)/256][N] - the bias
                                  * gradient of the layer this gradient feeds, folded by editor_reduce_rows */
+#define EDITOR_EPI_AUX_GRAD 0x400 /* OR-able with EDITOR_EPI_GELU / _GELU_BWD (16-bit kernels): aux holds gelu'(pre-activation) instead
+                                   * of the pre-activation - the forward saves the derivative (the only thing the backward needs of it), so
+                                   * the dgrad epilogue is one multiply instead of an erfc + exponential per element */
 #define EDITOR_EPI_FORCE_PP 0x200 /* OR-able: run the 256x256 ping-pong kernel whatever the shape heuristic says (N >= 256,
                                    * whole 64-deep K-tiles); tests use it to reach that kernel's edge cases */
 
@@ -292,6 +295,11 @@ int editor_augment_u8(const uint8_t* in, const int* params, int B, int H, int W,
 int editor_sgd_multi(float* const* p_ptrs, const float* const* g_ptrs, float* const* m_ptrs, const int* chunk_tensor,
                      const long* chunk_off, const long* numel, const float* lr, const float* wd, float momentum,
                      long nchunks, uint16_t* const* h_ptrs, int shadow_dtype, editor_stream_t stream);
+/* dst[t] (cols x rows) = transpose of src[t] (rows x cols), 16-bit elements, for a table of tensors in ONE launch: the
+ * k-major copies W^T of the nn.Linear weights that the dgrad products read (both dims multiples of 64).  Tables are
+ * device arrays; tile i is the 64x64 tile (tile_r[i], tile_c[i]) of tensor tile_tensor[i]. */
+int editor_transpose_multi(const uint16_t* const* src, uint16_t* const* dst, const int* rows, const int* cols,
+                           const int* tile_tensor, const int* tile_r, const int* tile_c, long ntiles, editor_stream_t stream);
 /* per-row drop-path scales keep/keep_prob for L blocks x 2 branches x B samples, expanded over T tokens:
  * scales (L,2,B*T) fp32; rates (L) fp32 on device; counter-based RNG keyed by `seed`. */
 int editor_droppath_scales(const float* rates, int L, long B, int T, long seed, float* scales, editor_stream_t stream);

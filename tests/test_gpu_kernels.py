@@ -267,6 +267,18 @@ def test_gemm_epilogues(ops, dtype):
     out = torch.empty(m, k, dtype=dtype, device="cuda")
     ops.gemm(dy.cuda(), w.cuda(), out, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=pre2.cuda())
     assert rel_err(out.float().cpu(), pr.grad) < tol
+    if dtype != torch.float32:
+        # derivative-saving form (EPI_AUX_GRAD) on the small-tile kernels, and the k-major W^T form of the same dgrad
+        dsave = torch.empty(m, n, dtype=dtype, device="cuda")
+        ops.gemm(a.cuda(), w.cuda(), act, m, n, k, k, k, n, 0, 0, bias=bias.cuda(), epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, aux=dsave)
+        pq = pre.float().cpu().requires_grad_(True)
+        F.gelu(pq).sum().backward()
+        assert rel_err(dsave.float().cpu(), pq.grad) < tol
+        gsave = (pr.detach() * 0 + torch.autograd.functional.jacobian(lambda z: F.gelu(z).sum(), pre2.float())).to(dtype)
+        out2 = torch.empty(m, k, dtype=dtype, device="cuda")
+        ops.gemm(dy.cuda(), w.t().contiguous().cuda(), out2, m, k, n, n, n, k, 0, 0, epilogue=ops.EPI_GELU_BWD | ops.EPI_AUX_GRAD,
+                 aux=gsave.cuda())
+        assert rel_err(out2.float().cpu(), pr.grad) < 2 * tol
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -311,6 +323,24 @@ def test_gemm_h16_pingpong_kernel(ops, tb, m, n, k, dtype):
     out = torch.empty(m, n, dtype=dtype, device="cuda")
     gemm(ag, bg, out, m, n, k, k, ldb, n, 0, tb, epilogue=ops.EPI_GELU_BWD, aux=pre2.cuda())
     assert rel_err(out.float().cpu(), pr.grad) < 1.5 * tol
+    # the derivative-saving form the training step uses (EPI_AUX_GRAD): forward stores gelu'(rounded pre-activation),
+    # the dgrad epilogue multiplies by it - same result as the erfc form above up to one more 16-bit rounding
+    dsave = torch.empty(m, n, dtype=dtype, device="cuda")
+    gemm(ag, bg, act, m, n, k, k, ldb, n, 0, tb, bias=bias.cuda(), epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, aux=dsave)
+    pq = pre.float().cpu().requires_grad_(True)
+    F.gelu(pq).sum().backward()
+    assert rel_err(dsave.float().cpu(), pq.grad) < tol
+    assert rel_err(act.float().cpu(), F.gelu(pre.float().cpu())) < tol
+    out2 = torch.empty(m, n, dtype=dtype, device="cuda")
+    pre2_grad = torch.empty(m, n, dtype=dtype, device="cuda")
+    gemm(ag, bg, torch.empty_like(act), m, n, k, k, ldb, n, 0, tb, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, aux=pre2_grad)
+    pg = F.gelu  # (reference: gelu' of the rounded product)
+    prod = torch.empty(m, n, dtype=dtype, device="cuda")
+    gemm(ag, bg, prod, m, n, k, k, ldb, n, 0, tb)
+    pr2 = prod.float().cpu().requires_grad_(True)
+    F.gelu(pr2).sum().backward()
+    gemm(ag, bg, out2, m, n, k, k, ldb, n, 0, tb, epilogue=ops.EPI_GELU_BWD | ops.EPI_AUX_GRAD, aux=pre2_grad)
+    assert rel_err(out2.float().cpu(), ref * pr2.grad.double()) < 2 * tol
     # fp32 residual epilogue and fp32 plain
     res = torch.randn(m, n, generator=_g(4))
     cf = torch.empty(m, n, device="cuda")

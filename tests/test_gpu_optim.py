@@ -124,6 +124,8 @@ def test_fused_sgd_f16_shadows():
     from editor_amd import functional as fnc
     from editor_amd.optim import FusedSGD
     names, ps = _toy(7)
+    names = names + ["big.weight", "wide.weight"]
+    ps = ps + [torch.randn(768, 1024).cuda().requires_grad_(True), torch.randn(256, 3072).cuda().requires_grad_(True)]
     opt = FusedSGD(list(zip(names, ps)), base_lr=1e-2, momentum=0.9, shadow_dtype=torch.float16)
     for p in ps:
         p.grad = torch.randn_like(p)
@@ -132,3 +134,14 @@ def test_fused_sgd_f16_shadows():
         if h is not None:
             assert h.dtype == torch.float16 and torch.equal(h, p.detach().half())
             assert fnc.act_weight(p, torch.float16).data_ptr() == h.data_ptr()
+    # k-major (transposed) copies of the big 2-D weights, written by the multi-tensor transpose launch of the same step
+    nt = 0
+    for p, ht in zip(ps, opt.shadows_t):
+        if ht is not None:
+            nt += 1
+            assert ht.shape == (p.shape[1], p.shape[0]) and torch.equal(ht, p.detach().half().t())
+            assert fnc.act_weight_t(p, torch.float16).data_ptr() == ht.data_ptr()
+    assert nt == 2
+    # without an optimizer in the loop the cache builds the transpose itself
+    q = torch.randn(128, 256).cuda().requires_grad_(True)
+    assert torch.equal(fnc.act_weight_t(q, torch.bfloat16), q.detach().bfloat16().t())
