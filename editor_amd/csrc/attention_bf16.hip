@@ -15,6 +15,7 @@
 // follows.  Outputs are written as 8-byte (4 x bf16) stores.
 #include "common.h"
 #include "../../include/editor_hip.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((ext_vector_type(8))) short short8_t;
@@ -34,6 +35,9 @@ __device__ __forceinline__ float4_t mfma16(short8_t a, short8_t b, float4_t c)
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+#ifndef ATTN_UNROLL_BWD
+#define ATTN_UNROLL_BWD 1              // dense backward passes with compile-time trip counts (measured: tools/attn_bench.py)
+#endif
 constexpr int HD = 64;                 // head dim (ViT-B/L, DeiT-S backbones)
 constexpr int ROWB = HD * 2;           // bytes per LDS image row
 constexpr float kLog2e = 1.4426950408889634f;
@@ -41,16 +45,31 @@ constexpr float kLog2e = 1.4426950408889634f;
 // LDS image of (rows x 64) bf16: 16-byte chunk c of row r lives at r*128 + ((c ^ (r&7)) << 4)
 __device__ __forceinline__ int img_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
 
-// cooperative load of rows [0,T) of one head slice (64 columns starting at col0 of a row-major matrix with leading
-// dimension ld) into an LDS image of Tp rows; rows >= T are zero filled.
+// cooperative load of rows [0,T) of one head slice (64 columns starting at `base` of a row-major matrix with leading
+// dimension ld) into an LDS image of Tp rows (Tp a multiple of 8), as LDS-DMA (global_load_lds_dwordx4): no staging
+// registers and every piece in flight at once - the register-staged loop it replaces (load, wait, ds_write per 16 bytes,
+// seven times per thread and image) serialised HBM latencies in front of every workgroup's compute.  The DMA writes
+// lane l's 16 bytes at piece_base + 16 l, so the XOR swizzle is applied to the SOURCE chunk index (as in the GEMMs).
+// Rows >= T cannot be zero-filled by a DMA: they are loaded from row T-1 (finite data) - every consumer masks keys /
+// queries beyond the sequence end (scores -> -inf, lse -> +inf), so those rows only ever meet exact zeros.
 __device__ __forceinline__ void load_image(char* img, const bf16_t* __restrict__ base, long ld, int T, int Tp)
 {
-    for (int e = threadIdx.x; e < Tp * 8; e += blockDim.x) {
-        const int row = e >> 3, c = e & 7;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row < T) v = *reinterpret_cast<const uint4*>(base + (long)row * ld + c * 8);
-        *reinterpret_cast<uint4*>(img + img_off(row, c)) = v;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int r8 = lane >> 3, p = lane & 7;
+    for (int piece = w; piece < (Tp >> 3); piece += nw) {          // 8 rows x 128 B = 1 KiB per piece
+        const int row = piece * 8 + r8;
+        const int c = p ^ (row & 7);
+        const bf16_t* src = base + (long)min(row, T - 1) * ld + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(img + piece * 1024), 16, 0, 0);
     }
+}
+// the DMA counts on vmcnt: drain it before the barrier that publishes the images
+__device__ __forceinline__ void images_ready()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 }
 
 // k-major fragment: lane (i = l&15, g = l>>4) <- image[row0 + i][s*32 + g*8 .. +8]
@@ -124,7 +143,10 @@ __device__ __forceinline__ uint32_t nibble_of(const KeyBits& kb, int t)
 // FULL: every sequence fills all NT key tiles (dense backbone calls): the tile loops then have compile-time trip counts,
 // so the compiler batches the LDS fragment reads of many tiles ahead of the MFMAs instead of serialising
 // "read -> wait -> MFMA" behind a branch per tile (that serialisation made the forward LDS-latency-bound).
-template <int NT, bool BWD, bool FULL, bool F16>
+// MASKED: a token mask is present (dense-masked HMA form); false for the backbone and the packed sequences, where a key
+// is valid iff it lies inside the sequence - then validity is one integer compare per key against a per-lane limit
+// instead of a per-lane bitmap (whose 64-bit shifts and SGPR traffic were ~1/3 of the forward's VALU + SALU work).
+template <int NT, bool BWD, bool FULL, bool F16, bool MASKED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_q_pass_kernel(AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -140,21 +162,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const bf16_t* qbase = a.qkv + row0 * ld + hh * HD;
     load_image(kimg, qbase + D, ld, T, nt * 16);
     load_image(vimg, qbase + 2 * D, ld, T, nt * 16);
-    __syncthreads();
+    images_ready();
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    const uint8_t* mk = a.mask ? a.mask + (long)b * T : nullptr;
-    // validity bits of this lane's keys: key(t, r) = 16t + 4g + r
+    const uint8_t* mk = (MASKED && a.mask) ? a.mask + (long)b * T : nullptr;
+    // validity of this lane's keys: key(t, r) = 16t + 4g + r
     KeyBits kb{{0ull, 0ull, 0ull}};
+    if constexpr (MASKED) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = 16 * t + 4 * lg + r;
-            const bool ok = key < T && (!mk || mk[key]);
-            if (ok) kb.w[t >> 4] |= 1ull << (4 * (t & 15) + r);
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * t + 4 * lg + r;
+                const bool ok = key < T && (!mk || mk[key]);
+                if (ok) kb.w[t >> 4] |= 1ull << (4 * (t & 15) + r);
+            }
+    }
+    const int klim = T - 4 * lg;                                    // unmasked: key(t, r) valid  <=>  16t + r < klim
+    auto vbits = [&](int t) -> uint32_t {
+        if constexpr (MASKED) return nibble_of(kb, t);
+        else {
+            const int rem = klim - 16 * t;                           // valid keys of this lane in tile t (<= 0: none, >= 4: all)
+            return rem >= 4 ? 0xfu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
         }
+    };
     const float sc = a.scale * kLog2e;
     const long row_idx0 = (long)hh * a.Mtot + row0;                // lse / delta index of row 0
     const long prow0 = ((long)b * a.heads + hh) * a.T;             // probability rows (dense mode only)
@@ -184,7 +216,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     acc1 = mfma16<F16>(b0, qf[0], acc1);
                     acc0 = mfma16<F16>(a1, qf[1], acc0);
                     acc1 = mfma16<F16>(b1, qf[1], acc1);
-                    const uint32_t vb0 = nibble_of(kb, t), vb1 = nibble_of(kb, t + 1);
+                    // FULL launches are unmasked and populate all NT tiles (T > 16 (NT - 2)): only the last two tiles can
+                    // hold keys beyond the sequence end; the others take no compare / select at all
+                    const uint32_t vb0 = (t < NT - 2) ? 0xfu : vbits(t), vb1 = (t + 1 < NT - 2) ? 0xfu : vbits(t + 1);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         sreg[t][r] = (vb0 >> r) & 1u ? acc0[r] * sc : -INFINITY;
@@ -202,7 +236,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
                         acc = mfma16<F16>(frag_k(kimg, t * 16, s, lane), qf[s], acc);
-                    const uint32_t vb = nibble_of(kb, t);
+                    const uint32_t vb = vbits(t);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         sreg[t][r] = (vb >> r) & 1u ? acc[r] * sc : -INFINITY;
@@ -264,7 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 for (int s = 0; s < 2; ++s)
                     acc = mfma16<F16>(frag_k(kimg, t * 16, s, lane), qf[s], acc);
                 float sv[4], tm = -INFINITY;
-                const uint32_t vb = nibble_of(kb, t);
+                const uint32_t vb = vbits(t);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     sv[r] = (vb >> r) & 1u ? acc[r] * sc : -INFINITY;
@@ -303,8 +337,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         float4_t o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int s2 = 0; s2 < nt / 2; ++s2) {
+        // one pair of key tiles; CHECK = false for pairs that cannot hold a key beyond the sequence end (unmasked sequences:
+        // every pair but the last) - no compare / select per key there
+        auto pair = [&](int s2, auto chk) {
+            constexpr bool CHECK = decltype(chk)::value;
             uint2 pk[2];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -316,10 +352,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     if (BWD) dp = mfma16<F16>(frag_k(vimg, t * 16, s, lane), dof[s], dp);
                 }
                 float pv[4];
-                const uint32_t vb = nibble_of(kb, t);
+                const uint32_t vb = CHECK ? vbits(t) : 0xfu;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    pv[r] = __builtin_amdgcn_exp2f((vb >> r) & 1u ? acc[r] * sc - lse : -INFINITY);
+                    pv[r] = __builtin_amdgcn_exp2f((!CHECK || ((vb >> r) & 1u)) ? acc[r] * sc - lse : -INFINITY);
                 if (!BWD) {
                     if (pr && 16 * t + 4 * lg < a.ldp)
                         *reinterpret_cast<float4*>(pr + 16 * t + 4 * lg) = make_float4(pv[0], pv[1], pv[2], pv[3]);
@@ -334,6 +370,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 o[dt] = mfma16<F16>(frag_t(timg, s2, dt, lane), pf, o[dt]);
+        };
+        const int npair = nt / 2;
+        if constexpr (FULL && !MASKED && ATTN_UNROLL_BWD) {
+            // dense backbone call: all NT tiles populated -> compile-time trip count, so that the fragment reads of the next
+            // pair are issued under the MFMAs / exponentials of this one (the rolled loop serialises read -> wait -> MFMA)
+#pragma unroll
+            for (int s2 = 0; s2 < NT / 2 - 1; ++s2) { pair(s2, std::false_type{}); __builtin_amdgcn_sched_barrier(0); }
+            pair(NT / 2 - 1, std::true_type{});
+        } else if constexpr (MASKED) {
+#pragma unroll 1
+            for (int s2 = 0; s2 < npair; ++s2) pair(s2, std::true_type{});
+        } else {
+#pragma unroll 1
+            for (int s2 = 0; s2 + 1 < npair; ++s2) pair(s2, std::false_type{});
+            if (npair > 0) pair(npair - 1, std::true_type{});
         }
         if (q < T) {
             bf16_t* orow = BWD ? a.dqkv + (row0 + q) * ld + hh * HD + 4 * lg
@@ -348,7 +399,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // ---------------------------------------------------------------------------------------------------------
 // DKV pass (own = keys; LDS holds the Q and dO images + lse/delta of every query)
 // ---------------------------------------------------------------------------------------------------------
-template <int NT, bool F16>
+template <int NT, bool F16, bool FULL>
 __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -373,7 +424,7 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
         lse_s[t] = ok ? a.lse[idx] : INFINITY;
         dl_s[t] = ok ? a.delta[idx] : 0.f;
     }
-    __syncthreads();
+    images_ready();
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
@@ -391,12 +442,8 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
         float4_t dv[4], dk[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dv[dt] = float4_t{0.f, 0.f, 0.f, 0.f}; dk[dt] = dv[dt]; }
-#pragma unroll 1
-        for (int u2 = 0; u2 < nt / 2; ++u2) {
-            uint2 pk[2], dsk[2];
-            // the eight k-major fragments of this pair of query tiles are requested together, ahead of the eight MFMAs
-            // (left to itself the compiler reads one fragment ahead: read -> wait -> MFMA, LDS latency each time)
-            short8_t fq[2][2], fd[2][2];
+        // k-major fragments of one pair of query tiles (8 x ds_read_b128)
+        auto qload = [&](int u2, short8_t (&fq)[2][2], short8_t (&fd)[2][2]) {
 #pragma unroll
             for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -404,7 +451,9 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
                     fq[half][s] = frag_k(qimg, (2 * u2 + half) * 16, s, lane);
                     fd[half][s] = frag_k(doimg, (2 * u2 + half) * 16, s, lane);
                 }
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto qcompute = [&](int u2, short8_t (&fq)[2][2], short8_t (&fd)[2][2]) {
+            uint2 pk[2], dsk[2];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int u = 2 * u2 + half;
@@ -435,6 +484,29 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
             for (int dt = 0; dt < 4; ++dt) {
                 dv[dt] = mfma16<F16>(frag_t(doimg, u2, dt, lane), pf, dv[dt]);
                 dk[dt] = mfma16<F16>(frag_t(qimg, u2, dt, lane), df, dk[dt]);
+            }
+        };
+        if constexpr (FULL && ATTN_UNROLL_BWD) {
+            // dense backbone call: compile-time trip count and the fragments double-buffered in registers - the reads of
+            // pair u2+1 are in flight under the MFMAs / exponentials of pair u2 (the rolled loop: read -> wait -> MFMA)
+            short8_t fq[2][2][2], fd[2][2][2];
+            qload(0, fq[0], fd[0]);
+#pragma unroll
+            for (int u2 = 0; u2 < NT / 2; ++u2) {
+                if (u2 + 1 < NT / 2) qload(u2 + 1, fq[(u2 + 1) & 1], fd[(u2 + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                qcompute(u2, fq[u2 & 1], fd[u2 & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll 1
+            for (int u2 = 0; u2 < nt / 2; ++u2) {
+                // the eight k-major fragments of this pair of query tiles are requested together, ahead of the eight MFMAs
+                // (left to itself the compiler reads one fragment ahead: read -> wait -> MFMA, LDS latency each time)
+                short8_t fq[2][2], fd[2][2];
+                qload(u2, fq, fd);
+                __builtin_amdgcn_sched_barrier(0);
+                qcompute(u2, fq, fd);
             }
         }
         if (key < T) {
@@ -476,7 +548,7 @@ __global__ __launch_bounds__(256) void attn_rollout_step_kernel(const bf16_t* __
         lse_s[t] = t < T ? lse[(long)hh * Mtot + row0 + t] : INFINITY;
         w_s[t] = t < T ? (r_in ? r_in[(long)blockIdx.x * T + t] : (t == 0 ? 1.f : 0.f)) : 0.f;
     }
-    __syncthreads();
+    images_ready();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const float sc = scale * kLog2e;
@@ -549,7 +621,7 @@ __global__ __launch_bounds__(256) void attn_q_long_kernel(AttnArgs a)
             const int len = min(LCH, T - c0), ntc = ((len + 31) >> 5) << 1;
             __syncthreads();
             load_image(kimg, qbase + D + (long)c0 * ld, ld, len, ntc * 16);
-            __syncthreads();
+            images_ready();
 #pragma unroll 2
             for (int t = 0; t < ntc; ++t) {
                 float4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -596,7 +668,7 @@ __global__ __launch_bounds__(256) void attn_q_long_kernel(AttnArgs a)
         __syncthreads();
         load_image(kimg, qbase + D + (long)c0 * ld, ld, len, ntc * 16);
         load_image(vimg, qbase + 2 * D + (long)c0 * ld, ld, len, ntc * 16);
-        __syncthreads();
+        images_ready();
 #pragma unroll 1
         for (int s2 = 0; s2 < ntc / 2; ++s2) {
             uint2 pk[2];
@@ -675,7 +747,7 @@ __global__ __launch_bounds__(256) void attn_kv_long_kernel(AttnArgs a)
             lse_s[t] = ok ? a.lse[idx] : INFINITY;
             dl_s[t] = ok ? a.delta[idx] : 0.f;
         }
-        __syncthreads();
+        images_ready();
 #pragma unroll 1
         for (int u2 = 0; u2 < ntc / 2; ++u2) {
             uint2 pk[2], dsk[2];
@@ -749,26 +821,49 @@ int launch_all(const AttnArgs& a, int B, int mode, hipStream_t stream)
     const dim3 grid(B * a.heads);
     int rc;
     if (mode == 0) {
-        const bool full = !a.cu && (((a.T + 31) >> 5) << 1) >= NT && NT <= 14;
+        const bool full = !a.cu && !a.mask && (((a.T + 31) >> 5) << 1) >= NT && NT <= 14;
         if (full) {
-            auto k = attn_q_pass_kernel<NT, false, true, F16>;
+            auto k = attn_q_pass_kernel<NT, false, true, F16, false>;
             if ((rc = set_lds(k, img))) return rc;
             hipLaunchKernelGGL(k, grid, dim3(threads), img, stream, a);
         } else {
-            auto k = attn_q_pass_kernel<NT, false, false, F16>;
-            if ((rc = set_lds(k, img))) return rc;
-            hipLaunchKernelGGL(k, grid, dim3(threads), img, stream, a);
+            if (a.mask) {
+                auto k = attn_q_pass_kernel<NT, false, false, F16, true>;
+                if ((rc = set_lds(k, img))) return rc;
+                hipLaunchKernelGGL(k, grid, dim3(threads), img, stream, a);
+            } else {
+                auto k = attn_q_pass_kernel<NT, false, false, F16, false>;
+                if ((rc = set_lds(k, img))) return rc;
+                hipLaunchKernelGGL(k, grid, dim3(threads), img, stream, a);
+            }
         }
         EDITOR_LAUNCH_CHECK();
     } else {
-        auto k1 = attn_q_pass_kernel<NT, true, false, F16>;
-        if ((rc = set_lds(k1, img))) return rc;
-        hipLaunchKernelGGL(k1, grid, dim3(threads), img, stream, a);
+        const bool full = !a.cu && !a.mask && (((a.T + 31) >> 5) << 1) >= NT && NT <= 14;
+        if (a.mask) {
+            auto k1 = attn_q_pass_kernel<NT, true, false, F16, true>;
+            if ((rc = set_lds(k1, img))) return rc;
+            hipLaunchKernelGGL(k1, grid, dim3(threads), img, stream, a);
+        } else if (full) {
+            auto k1 = attn_q_pass_kernel<NT, true, true, F16, false>;
+            if ((rc = set_lds(k1, img))) return rc;
+            hipLaunchKernelGGL(k1, grid, dim3(threads), img, stream, a);
+        } else {
+            auto k1 = attn_q_pass_kernel<NT, true, false, F16, false>;
+            if ((rc = set_lds(k1, img))) return rc;
+            hipLaunchKernelGGL(k1, grid, dim3(threads), img, stream, a);
+        }
         EDITOR_LAUNCH_CHECK();
-        auto k2 = attn_kv_pass_kernel<NT, F16>;
         const size_t lds2 = img + (size_t)2 * NT * 16 * sizeof(float);
-        if ((rc = set_lds(k2, lds2))) return rc;
-        hipLaunchKernelGGL(k2, grid, dim3(threads), lds2, stream, a);
+        if (full) {
+            auto k2 = attn_kv_pass_kernel<NT, F16, true>;
+            if ((rc = set_lds(k2, lds2))) return rc;
+            hipLaunchKernelGGL(k2, grid, dim3(threads), lds2, stream, a);
+        } else {
+            auto k2 = attn_kv_pass_kernel<NT, F16, false>;
+            if ((rc = set_lds(k2, lds2))) return rc;
+            hipLaunchKernelGGL(k2, grid, dim3(threads), lds2, stream, a);
+        }
         EDITOR_LAUNCH_CHECK();
     }
     return 0;

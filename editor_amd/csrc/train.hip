@@ -15,7 +15,7 @@ template <bool F16>
 __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict__ p_ptrs, const float* const* __restrict__ g_ptrs,
     float* const* __restrict__ m_ptrs, const int* __restrict__ chunk_tensor, const long* __restrict__ chunk_off,
     const long* __restrict__ numel, const float* __restrict__ lr, const float* __restrict__ wd, float momentum,
-    uint16_t* const* __restrict__ h_ptrs)
+    uint16_t* const* __restrict__ h_ptrs, int* __restrict__ nonfinite)
 {
     const int t = chunk_tensor[blockIdx.x];
     const long off = chunk_off[blockIdx.x];
@@ -28,10 +28,12 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict
     // optional bf16 shadow of the updated parameter (the GEMM operand copy), written in the same pass
     uint16_t* __restrict__ h = (h_ptrs && h_ptrs[t]) ? h_ptrs[t] + off : nullptr;
     const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m)) & 15) == 0;
+    bool bad = false;                                         // a non-finite gradient element (f16 loss-scale overflow)
     if (vec) {
         for (long i = threadIdx.x * 4L; i + 3 < n; i += 1024) {
             float4 pv = *reinterpret_cast<float4*>(p + i);
             const float4 gv = *reinterpret_cast<const float4*>(g + i);
+            bad |= !(isfinite(gv.x) && isfinite(gv.y) && isfinite(gv.z) && isfinite(gv.w));
             float4 mv = *reinterpret_cast<float4*>(m + i);
             const float4 d = make_float4(gv.x + w * pv.x, gv.y + w * pv.y, gv.z + w * pv.z, gv.w + w * pv.w);
             mv = make_float4(momentum * mv.x + d.x, momentum * mv.y + d.y, momentum * mv.z + d.z, momentum * mv.w + d.w);
@@ -41,6 +43,7 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict
             if (h) { uint2 o; o.x = H16<F16>::pack2(pv.x, pv.y); o.y = H16<F16>::pack2(pv.z, pv.w); *reinterpret_cast<uint2*>(h + i) = o; }
         }
         for (long i = (n & ~3L) + threadIdx.x; i < n; i += 256) {
+            bad |= !isfinite(g[i]);
             const float d = g[i] + w * p[i];
             const float mv = momentum * m[i] + d;
             m[i] = mv; p[i] -= l * mv;
@@ -48,12 +51,14 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict
         }
     } else {
         for (long i = threadIdx.x; i < n; i += 256) {
+            bad |= !isfinite(g[i]);
             const float d = g[i] + w * p[i];
             const float mv = momentum * m[i] + d;
             m[i] = mv; p[i] -= l * mv;
             if (h) h[i] = H16<F16>::from_f32(p[i]);
         }
     }
+    if (nonfinite && bad) atomicOr(nonfinite, 1);
 }
 
 // Transposed 16-bit copies of the GEMM weights for the dgrad products: dx = dy W reduces over the ROWS of the nn.Linear
@@ -135,16 +140,16 @@ __global__ void advance_state_kernel(long* state) { state[0] += 1; }
 
 extern "C" int editor_sgd_multi(float* const* p_ptrs, const float* const* g_ptrs, float* const* m_ptrs,
     const int* chunk_tensor, const long* chunk_off, const long* numel, const float* lr, const float* wd, float momentum,
-    long nchunks, uint16_t* const* h_ptrs, int shadow_dtype, hipStream_t stream)
+    long nchunks, uint16_t* const* h_ptrs, int shadow_dtype, int* nonfinite, hipStream_t stream)
 {
     if (nchunks < 1) return 0;
     if (h_ptrs && shadow_dtype != 1 && shadow_dtype != 2) return (int)hipErrorInvalidValue;
     if (shadow_dtype == 2)
         hipLaunchKernelGGL(sgd_multi_kernel<true>, dim3((unsigned)nchunks), dim3(256), 0, stream, p_ptrs, g_ptrs, m_ptrs,
-                           chunk_tensor, chunk_off, numel, lr, wd, momentum, h_ptrs);
+                           chunk_tensor, chunk_off, numel, lr, wd, momentum, h_ptrs, nonfinite);
     else
         hipLaunchKernelGGL(sgd_multi_kernel<false>, dim3((unsigned)nchunks), dim3(256), 0, stream, p_ptrs, g_ptrs, m_ptrs,
-                           chunk_tensor, chunk_off, numel, lr, wd, momentum, h_ptrs);
+                           chunk_tensor, chunk_off, numel, lr, wd, momentum, h_ptrs, nonfinite);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

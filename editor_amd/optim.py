@@ -91,6 +91,9 @@ class FusedSGD:
         self._ev = [None, None]
         self._slot = 0
         self._keep = [None, None]
+        # set by the update kernel when it meets a non-finite gradient element (f16 mode: the static loss scale of
+        # editor_amd.functional overflowed half somewhere in the backward); read with found_inf()
+        self._nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
 
     # -- torch.optim.Optimizer surface --------------------------------------------------------------------
     def zero_grad(self, set_to_none=True):
@@ -122,6 +125,15 @@ class FusedSGD:
         self.wd.copy_(self._hyper_host[1], non_blocking=True)
         self._hyper_cached = vals
         return True
+
+    def found_inf(self, reset=True):
+        """True if any step since the last reset saw an inf / nan gradient (synchronises: call it every N steps, as the
+        reference's GradScaler bookkeeping does once per step, engine/processor.py:95-96).  The update is NOT skipped:
+        lower cfg.MODEL.GRAD_SCALE and restart from the last checkpoint."""
+        bad = bool(self._nonfinite.item())
+        if reset:
+            self._nonfinite.zero_()
+        return bad
 
     def set_lr(self, lr):
         """lr: one float for every group, or one value per group (same order as param_groups)."""
@@ -190,7 +202,7 @@ class FusedSGD:
         with torch.cuda.device(self.device):
             _lib.call("editor_sgd_multi", self.p_ptrs, dev_tab, self.m_ptrs, self.chunk_t, self.chunk_o, self.numel,
                       self.lr, self.wd, float(self.momentum), self.nchunks, self.h_ptrs,
-                      2 if self.shadow_dtype == torch.float16 else 1)
+                      2 if self.shadow_dtype == torch.float16 else 1, self._nonfinite)
         if not capturing:
             self._ev[k] = torch.cuda.Event()
             self._ev[k].record()

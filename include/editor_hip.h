@@ -294,7 +294,9 @@ int editor_augment_u8(const uint8_t* in, const int* params, int B, int H, int W,
  * a captured hipGraph would bake in). */
 int editor_sgd_multi(float* const* p_ptrs, const float* const* g_ptrs, float* const* m_ptrs, const int* chunk_tensor,
                      const long* chunk_off, const long* numel, const float* lr, const float* wd, float momentum,
-                     long nchunks, uint16_t* const* h_ptrs, int shadow_dtype, editor_stream_t stream);
+                     long nchunks, uint16_t* const* h_ptrs, int shadow_dtype,
+                     int* nonfinite /* device flag, OR-ed with 1 when a gradient element is inf / nan; may be NULL */,
+                     editor_stream_t stream);
 /* dst[t] (cols x rows) = transpose of src[t] (rows x cols), 16-bit elements, for a table of tensors in ONE launch: the
  * k-major copies W^T of the nn.Linear weights that the dgrad products read (both dims multiples of 64).  Tables are
  * device arrays; tile i is the 64x64 tile (tile_r[i], tile_c[i]) of tensor tile_tensor[i]. */

@@ -16,8 +16,10 @@ pytestmark = pytest.mark.gpu
 B = 128
 TOL = {
     "f32": dict(cls4t=1e-3, loss=1e-4, grad=2e-3),
-    "f16": dict(agree=0.995, cls4t=1.0e-3, loss=5e-4, grad=5.5e-3, grad_pe=3.5e-2),
-    "bf16": dict(agree=0.97, cls4t=1.0e-2, loss=4e-3, grad=5e-2, grad_pe=0.3),
+    # measured (profiles/r02_parity_table.txt): f16 agree .9996 cls4t 8.4e-4 loss 2.4e-6 grad 3.6e-3 / 2.3e-2 (patch embed);
+    #                                           bf16 agree .9971 cls4t 6.5e-3 loss 1.2e-4 grad 1.85e-2 / 7.1e-2
+    "f16": dict(agree=0.999, cls4t=1.0e-3, loss=1e-5, grad=5.5e-3, grad_pe=3.5e-2),
+    "bf16": dict(agree=0.995, cls4t=1.0e-2, loss=3e-4, grad=2.8e-2, grad_pe=0.11),
 }
 
 

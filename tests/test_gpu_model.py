@@ -112,9 +112,11 @@ def test_forward_rejects_cpu():
 #         that meets the north-star's 1e-3 on the features at full speed (f32 parity mode: exact-f32 MFMA, 1/16 rate)
 # Bounds = measured on MI355X (tools/parity_table.py, profiles/r02_parity_table.txt) x 1.5.
 # ---------------------------------------------------------------------------------------------------
+# measured: bf16 eval 6.5e-3, train features 7.1e-3 / scores 1.16e-2, grad 1.7e-2; f16 eval 7.9e-4, train features 8.6e-4 /
+# scores 1.41e-3, grad 2.3e-3  (features = cls4t and the per-modality cls features; scores = classifier logits after BN)
 TOL = {
-    "bf16": dict(agree=0.95, eval_cls4t=1.0e-2, train_out=1.8e-2, grad=3.0e-2),
-    "f16": dict(agree=0.99, eval_cls4t=1.0e-3, train_out=1.5e-3, grad=4.0e-3),
+    "bf16": dict(agree=0.95, eval_cls4t=1.0e-2, train_feat=1.1e-2, train_score=1.8e-2, grad=2.6e-2),
+    "f16": dict(agree=0.99, eval_cls4t=1.0e-3, train_feat=1.0e-3, train_score=2.1e-3, grad=3.5e-3),
 }
 
 
@@ -159,7 +161,9 @@ def test_train_16bit_teacher_forced(dtype):
     out = m(img, label=label, cam_label=cam, view_label=view, writer=_Writer(), epoch=1)
     errs = [rel_err(o.detach().float().cpu(), g["out%d" % i]) for i, o in enumerate(out)]
     print(dtype, "train outputs rel err:", errs)
-    assert max(errs) < TOL[dtype]["train_out"]
+    assert max(errs[1:-1:2]) < TOL[dtype]["train_feat"]           # features (north-star bound for f16: 1e-3)
+    assert max(errs[0:-1:2]) < TOL[dtype]["train_score"]          # classifier scores
+    assert errs[-1] < TOL[dtype]["train_feat"]                    # loss_bcc + loss_ocfr
     total = out[-1]
     for i, o in enumerate(out[:-1]):
         total = total + (o * synth.uniform(5, "proj/%d" % i, tuple(o.shape)).cuda()).mean()

@@ -67,6 +67,7 @@ def test_fused_sgd_follows_param_groups_and_checkpoints():
             assert rel_err(p.detach().cpu(), r.detach().cpu()) < 1e-6
     fopt.set_lr(5e-3)
     assert torch.allclose(fopt.lr.cpu(), torch.full((len(ps),), 5e-3))
+    assert not fopt.found_inf()
     # checkpoint round trip: momentum buffers + groups restore an optimizer that continues identically
     sd = fopt.state_dict()
     assert set(sd) == {"state", "param_groups"} and len(sd["state"]) == len(ps)
@@ -118,6 +119,19 @@ def test_fused_sgd_first_step_under_capture_keeps_momentum():
     torch.cuda.synchronize()
     for p, b in zip(ps, before):
         assert torch.equal(p.detach(), b)
+
+
+def test_fused_sgd_flags_nonfinite_gradients():
+    from editor_amd.optim import FusedSGD
+    names, ps = _toy(13)
+    opt = FusedSGD(list(zip(names, ps)), base_lr=1e-2, momentum=0.9)
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    opt.step()
+    assert not opt.found_inf()
+    ps[2].grad[5, 7] = float("inf")
+    opt.step()
+    assert opt.found_inf() and not opt.found_inf()          # reported once, then reset
 
 
 def test_fused_sgd_f16_shadows():

@@ -18,3 +18,7 @@ print("fwd no probs    %.1f us" % bench(lambda: ops.attention_fwd(qkv, b, t, hea
 o, lse = ops.attention_fwd(qkv, b, t, heads, hd, None, None)
 do = torch.randn_like(o)
 print("bwd (dq + dk/dv)  %.1f us" % bench(lambda: ops.attention_bwd(qkv, do, b, t, heads, hd, None, lse, o)))
+print("rollout step      %.1f us" % bench(lambda: ops.attn_rollout_qk([(qkv, lse)], b, t, heads, hd)))
+for tt in (193,):
+    q2 = (torch.randn(b * tt, 3 * heads * hd, device='cuda') * 0.5).bfloat16()
+    print("T=%d fwd no probs %.1f us" % (tt, bench(lambda: ops.attention_fwd(q2, b, tt, heads, hd, None, None))))
