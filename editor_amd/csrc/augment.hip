@@ -54,7 +54,86 @@ __global__ void augment_kernel(const uint8_t* __restrict__ in, const int* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// T.Resize on decoded uint8 images = Pillow's ImagingResample, 8-bit path (src/libImaging/Resample.c; torchvision 0.14.1
+// calls PIL.Image.resize for PIL inputs): separable, horizontal pass then vertical pass, 22-bit fixed-point weights from
+// a host-built table (window start, tap count, taps per output coordinate), accumulator seeded with 1 << 21, result
+// clip8(acc >> 22); the intermediate image is uint8, as in Pillow.  Integer arithmetic: bit-exact by construction.
+// One thread per output pixel (3 channels); HBM-bound byte work - taps of neighbouring outputs overlap in L1/L2.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t clip8(int v) { v >>= 22; return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// out[b, y, xx, c] = sum_k in[b, y, x0[xx] + k, c] * w[xx][k]          (in: (B,H,Win,3), out: (B,H,Wout,3))
+__global__ void resize_h_kernel(const uint8_t* __restrict__ in, int B, int H, int Win, int Wout, const int* __restrict__ bounds,
+                                const int* __restrict__ kk, int ksize, uint8_t* __restrict__ out)
+{
+    const long n = (long)B * H * Wout;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int xx = (int)(e % Wout);
+        const long row = e / Wout;                                   // b * H + y
+        const int x0 = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+        const uint8_t* src = in + (row * Win + x0) * 3;
+        const int* w = kk + (long)xx * ksize;
+        int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+        for (int k = 0; k < cnt; ++k) {
+            const int wk = w[k];
+            a0 += src[3 * k] * wk; a1 += src[3 * k + 1] * wk; a2 += src[3 * k + 2] * wk;
+        }
+        uint8_t* o = out + e * 3;
+        o[0] = clip8(a0); o[1] = clip8(a1); o[2] = clip8(a2);
+    }
+}
+// out[b, yy, x, c] = sum_k in[b, y0[yy] + k, x, c] * w[yy][k]          (in: (B,Hin,W,3), out: (B,Hout,W,3))
+__global__ void resize_v_kernel(const uint8_t* __restrict__ in, int B, int Hin, int Hout, int W, const int* __restrict__ bounds,
+                                const int* __restrict__ kk, int ksize, uint8_t* __restrict__ out)
+{
+    const long n = (long)B * Hout * W;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(e % W);
+        const int yy = (int)((e / W) % Hout);
+        const long b = e / ((long)W * Hout);
+        const int y0 = bounds[2 * yy], cnt = bounds[2 * yy + 1];
+        const uint8_t* src = in + ((b * Hin + y0) * W + x) * 3;
+        const int* w = kk + (long)yy * ksize;
+        int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+        for (int k = 0; k < cnt; ++k) {
+            const int wk = w[k];
+            const uint8_t* s = src + (long)k * W * 3;
+            a0 += s[0] * wk; a1 += s[1] * wk; a2 += s[2] * wk;
+        }
+        uint8_t* o = out + e * 3;
+        o[0] = clip8(a0); o[1] = clip8(a1); o[2] = clip8(a2);
+    }
+}
+
 }  // namespace
+
+extern "C" int editor_resize_u8(const uint8_t* in, int B, int Hin, int Win, int Hout, int Wout, const int* xbounds,
+                                const int* xk, int xksize, const int* ybounds, const int* yk, int yksize, uint8_t* tmp,
+                                uint8_t* out, editor_stream_t stream)
+{
+    if (B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || !in || !out) return (int)hipErrorInvalidValue;
+    const bool need_h = Wout != Win, need_v = Hout != Hin;
+    if ((need_h && (!xbounds || !xk || xksize < 1)) || (need_v && (!ybounds || !yk || yksize < 1)) || (need_h && need_v && !tmp))
+        return (int)hipErrorInvalidValue;
+    auto blocks = [](long n) { long b = (n + 255) / 256; return (unsigned)(b > 65536 ? 65536 : b); };
+    if (!need_h && !need_v) {
+        hipError_t e = hipMemcpyAsync(out, in, (size_t)B * Hin * Win * 3, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        return (int)e;
+    }
+    const uint8_t* vsrc = in;
+    if (need_h) {
+        uint8_t* hdst = need_v ? tmp : out;                           // (B, Hin, Wout, 3)
+        resize_h_kernel<<<blocks((long)B * Hin * Wout), 256, 0, (hipStream_t)stream>>>(in, B, Hin, Win, Wout, xbounds, xk, xksize, hdst);
+        EDITOR_LAUNCH_CHECK();
+        vsrc = hdst;
+    }
+    if (need_v) {
+        resize_v_kernel<<<blocks((long)B * Hout * Wout), 256, 0, (hipStream_t)stream>>>(vsrc, B, Hin, Hout, Wout, ybounds, yk, yksize, out);
+        EDITOR_LAUNCH_CHECK();
+    }
+    return 0;
+}
 
 extern "C" int editor_augment_u8(const uint8_t* in, const int* params, int B, int H, int W, int pad, const float* mean,
                                  const float* stdv, const float* noise, unsigned long long seed, float* out,

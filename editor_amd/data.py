@@ -170,6 +170,71 @@ class ErasingParams:
         return (0, 0, 0, 0, 0)
 
 
+def resize_coeffs(in_size, out_size, interpolation=3):
+    """Tap table of one axis of T.Resize on uint8 images - Pillow's precompute_coeffs + normalize_coeffs_8bpc
+    (src/libImaging/Resample.c; torchvision 0.14.1 resizes PIL images with PIL.Image.resize): per output coordinate the
+    window [xmin, xmin + count) and its 22-bit fixed-point weights.  interpolation: 3 = bicubic (a = -0.5, support 2; the
+    train transform, make_dataloader.py:246), 2 = bilinear (support 1; the val transform, :256).  All in float64 in the
+    order Pillow's C doubles take, vectorised over the output coordinates -> (bounds (out,2) int32, k (out,ksize) int32)."""
+    fsupport = {2: 1.0, 3: 2.0}[interpolation]
+    scale = float(in_size) / out_size
+    fscale = max(scale, 1.0)
+    support = fsupport * fscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    center = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)                 # C (int): truncation (values >= -0.5)
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    j = np.arange(ksize, dtype=np.float64)[None, :]
+    x = np.abs((j + xmin[:, None] - center[:, None] + 0.5) * (1.0 / fscale))
+    if interpolation == 3:
+        a = -0.5
+        w = np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1, np.where(x < 2.0, (((x - 5) * x + 8) * x - 4) * a, 0.0))
+    else:
+        w = np.where(x < 1.0, 1.0 - x, 0.0)
+    w = np.where(j < xmax[:, None], w, 0.0)
+    ww = np.zeros(out_size, dtype=np.float64)
+    for c in range(ksize):                                                          # Pillow sums the taps left to right
+        ww = ww + w[:, c]
+    wn = np.where(ww[:, None] != 0.0, w / np.where(ww == 0.0, 1.0, ww)[:, None], w)
+    fixed = wn * float(1 << 22)
+    kk = np.where(wn < 0, (-0.5 + fixed).astype(np.int64), (0.5 + fixed).astype(np.int64)).astype(np.int32)
+    kk = np.where(j < xmax[:, None], kk, 0).astype(np.int32)
+    return np.stack([xmin, xmax], axis=1).astype(np.int32), kk
+
+
+class DeviceResize:
+    """T.Resize(size, interpolation) for a batch of decoded uint8 (B,H,W,3) images on the device (editor_resize_u8):
+    bit-exact with what the reference's PIL pipeline produces for the same pixels.  JPEG decode stays on the host."""
+
+    def __init__(self, size, interpolation=3):
+        self.size = (int(size[0]), int(size[1]))
+        self.interpolation = interpolation
+        self._tabs = {}
+
+    def _tables(self, n_in, n_out, device):
+        key = (n_in, n_out, device)
+        t = self._tabs.get(key)
+        if t is None:
+            b, k = resize_coeffs(n_in, n_out, self.interpolation)
+            t = self._tabs[key] = (torch.from_numpy(b).to(device).contiguous(), torch.from_numpy(k).to(device).contiguous(),
+                                   int(k.shape[1]))
+        return t
+
+    def __call__(self, images_u8):
+        if not images_u8.is_cuda:
+            raise RuntimeError("DeviceResize: images are not on the GPU (no CPU fallback)")
+        b, h, w, c = images_u8.shape
+        assert c == 3 and images_u8.dtype == torch.uint8
+        oh, ow = self.size
+        dev = images_u8.device
+        out = torch.empty(b, oh, ow, 3, dtype=torch.uint8, device=dev)
+        xb, xk, xks = self._tables(w, ow, dev) if ow != w else (None, None, 1)
+        yb, yk, yks = self._tables(h, oh, dev) if oh != h else (None, None, 1)
+        tmp = torch.empty(b, h, ow, 3, dtype=torch.uint8, device=dev) if (ow != w and oh != h) else None
+        call("editor_resize_u8", images_u8.contiguous(), b, h, w, oh, ow, xb, xk, xks, yb, yk, yks, tmp, out)
+        return out
+
+
 class DeviceTrainTransform:
     """The train transform of make_dataloader.py:245-253 after the resize, for a batch, on the device."""
 

@@ -283,6 +283,15 @@ int editor_augment_u8(const uint8_t* in, const int* params, int B, int H, int W,
                       const float* stdv, const float* noise, unsigned long long seed, float* out,
                       editor_stream_t stream);
 
+/* T.Resize(size, interpolation) of decoded uint8 images (make_dataloader.py:246,256; torchvision 0.14.1 ->
+ * PIL.Image.resize = Pillow ImagingResample, 8-bit path): horizontal pass then vertical pass with 22-bit fixed-point taps.
+ * in (B,Hin,Win,3) -> out (B,Hout,Wout,3); bounds: (n_out,2) int32 {window start, tap count}; k: (n_out, ksize) int32
+ * taps (device arrays, built on the host: editor_amd.data.resize_coeffs); tmp: (B,Hin,Wout,3) bytes, needed when both
+ * axes change.  Bit-exact with Pillow (integer arithmetic). */
+int editor_resize_u8(const uint8_t* in, int B, int Hin, int Win, int Hout, int Wout, const int* xbounds, const int* xk,
+                     int xksize, const int* ybounds, const int* yk, int yksize, uint8_t* tmp, uint8_t* out,
+                     editor_stream_t stream);
+
 /* ---- training-step kernels (drop-path RNG of vit_pytorch.py:52-69) ----------------------- */
 
 /* torch.optim.SGD(momentum, weight_decay, dampening 0) over many tensors in one launch.  Pointer tables and per-tensor

@@ -433,3 +433,25 @@ def f6_blocks_large(seed=43):
 
 if __name__ == "__main__" and "f6L" in sys.argv[1:]:
     f6_blocks_large()
+
+
+def f13_resize(seed=131):
+    """F13 (row N3): T.Resize of the train / val transforms (make_dataloader.py:246,256) = PIL.Image.resize (the path
+    torchvision 0.14.1 takes for PIL inputs) on seeded uint8 images: Pillow itself is the reference implementation here."""
+    from PIL import Image
+    rec = {}
+    cases = [((300, 150), (256, 128), 3), ((128, 256), (128, 256), 3), ((97, 61), (256, 128), 3), ((517, 233), (384, 128), 3),
+             ((200, 400), (128, 256), 2), ((64, 32), (256, 128), 2)]
+    for i, ((h, w), (oh, ow), ip) in enumerate(cases):
+        a = (synth.integers(seed, "resize/%d" % i, (h, w, 3), 256)).numpy().astype(np.uint8)
+        r = np.asarray(Image.fromarray(a).resize((ow, oh), ip))
+        rec["case%d" % i] = np.asarray([h, w, oh, ow, ip], dtype=np.int32)
+        rec["out%d" % i] = r[::3, ::3].copy()                       # subsample + checksum keep the fixture small
+        rec["sum%d" % i] = np.int64(r.astype(np.int64).sum())
+        rec["xor%d" % i] = np.int64(np.bitwise_xor.reduce(r.astype(np.int64).ravel() * (np.arange(r.size) % 251 + 1)))
+    import PIL
+    save("f13_resize", seed=seed, n=len(cases), pillow=np.array(PIL.__version__), **rec)
+
+
+if __name__ == "__main__" and "f13" in sys.argv[1:]:
+    f13_resize()

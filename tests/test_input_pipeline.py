@@ -69,3 +69,64 @@ def test_device_train_transform_matches_oracle(h, w, b):
     assert abs(z.mean().item()) < 0.02 and abs(z.std().item() - 1) < 0.02
     with pytest.raises(RuntimeError):
         tf(img, params, noise)
+
+
+# ---- T.Resize (Pillow ImagingResample) ----------------------------------------------------------------------------
+def _resize_cases():
+    g = load_golden("f13_resize")
+    for i in range(int(g["n"])):
+        h, w, oh, ow, ip = [int(v) for v in g["case%d" % i]]
+        a = synth.integers(int(g["seed"]), "resize/%d" % i, (h, w, 3), 256).numpy().astype(np.uint8)
+        yield i, g, a, (oh, ow), ip
+
+
+def _resize_matches_golden(out, g, i):
+    assert np.array_equal(out[::3, ::3], g["out%d" % i])
+    assert int(out.astype(np.int64).sum()) == int(g["sum%d" % i])
+    assert int(np.bitwise_xor.reduce(out.astype(np.int64).ravel() * (np.arange(out.size) % 251 + 1))) == int(g["xor%d" % i])
+
+
+def test_resize_oracle_matches_pillow_golden():
+    """oracle/resize_ref.py (restated Pillow algorithm) == outputs Pillow produced (fixture), bit for bit."""
+    from oracle import resize_ref
+    for i, g, a, size, ip in _resize_cases():
+        _resize_matches_golden(resize_ref.resize(a, size, ip), g, i)
+
+
+def test_resize_oracle_matches_pillow_live():
+    """...and == Pillow run here, when it is importable (it is in this image), on more shapes."""
+    PIL = pytest.importorskip("PIL.Image")
+    from oracle import resize_ref
+    rng = np.random.default_rng(3)
+    for (h, w), (oh, ow) in [((300, 150), (256, 128)), ((40, 500), (128, 256)), ((1000, 400), (384, 128)), ((256, 128), (512, 256))]:
+        for ip in (2, 3):
+            a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            assert np.array_equal(resize_ref.resize(a, (oh, ow), ip), np.asarray(PIL.fromarray(a).resize((ow, oh), ip)))
+
+
+def test_resize_coefficient_tables_match_oracle():
+    """the product's host-side tap tables (editor_amd.data.resize_coeffs, vectorised) == the oracle's scalar restatement"""
+    from editor_amd.data import resize_coeffs
+    from oracle import resize_ref
+    for n_in, n_out in [(256, 256), (150, 128), (64, 128), (233, 128), (517, 384), (61, 128), (1000, 256), (128, 512)]:
+        for ip in (2, 3):
+            b0, k0 = resize_ref.precompute_coeffs(n_in, n_out, ip)
+            b1, k1 = resize_coeffs(n_in, n_out, ip)
+            assert np.array_equal(b0, b1) and np.array_equal(k0, k1), (n_in, n_out, ip)
+
+
+@pytest.mark.gpu
+def test_device_resize_bit_exact():
+    """editor_resize_u8 == the oracle == Pillow: golden cases + batched random cases incl. single-axis and identity sizes."""
+    from editor_amd.data import DeviceResize
+    from oracle import resize_ref
+    for i, g, a, size, ip in _resize_cases():
+        out = DeviceResize(size, ip)(torch.from_numpy(a)[None].cuda())[0].cpu().numpy()
+        _resize_matches_golden(out, g, i)
+    rng = np.random.default_rng(5)
+    for (h, w), size in [((300, 150), (256, 128)), ((256, 64), (256, 128)), ((100, 128), (256, 128)), ((256, 128), (256, 128)),
+                         ((517, 233), (384, 128))]:
+        batch = rng.integers(0, 256, (5, h, w, 3), dtype=np.uint8)
+        out = DeviceResize(size, 3)(torch.from_numpy(batch).cuda()).cpu().numpy()
+        for j in range(5):
+            assert np.array_equal(out[j], resize_ref.resize(batch[j], size, 3)), (h, w, size, j)
