@@ -69,7 +69,7 @@ class _GemmProbe:
             if probe.recording and a.dtype in (torch.bfloat16, torch.float16):
                 ta = args[3] if len(args) > 3 else kw.get("trans_a", 0)
                 tb = args[4] if len(args) > 4 else kw.get("trans_b", 0)
-                kind = "fwd" if not ta and not tb else ("dgrad" if not ta else "wgrad")
+                kind = kw.get("tag") or ("fwd" if not ta and not tb else ("dgrad" if not ta else "wgrad"))
                 # compacted HMA launches are sized for the worst case; count only the live rows (device scalar,
                 # read after the timed region) as algorithmic work
                 probe.calls.append([kind, (m, n, k, kw.get("m_live"), bool(ta)), (a, b, c, m, n, k) + args, dict(kw)])

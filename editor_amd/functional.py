@@ -147,11 +147,11 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, 
     # B = W stored (Kred=n, Nout=k): row-k operand (trans_b = 1); or its k-major copy W^T (Nout=k, Kred=n): trans_b = 0
     wb, ldb, tb = (w_t, n, 0) if w_t is not None else (w_act, k, 1)
     if gelu_pre is None:
-        ops.gemm(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, m_live=m_live, colsum=dxcs, colsum_scale=inv)
+        ops.gemm(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, m_live=m_live, colsum=dxcs, colsum_scale=inv, tag="dgrad")
     else:
         ag = ops.EPI_AUX_GRAD if dy.dtype in ops.HALF_DTYPES else 0      # 16-bit: gelu_pre holds gelu'(pre-activation)
         ops.gemm(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, epilogue=ops.EPI_GELU_BWD | ag, aux=gelu_pre, m_live=m_live,
-                 colsum=dxcs, colsum_scale=inv)
+                 colsum=dxcs, colsum_scale=inv, tag="dgrad")
     dw = dw_out if dw_out is not None else torch.empty(n, k, dtype=torch.float32, device=dy.device)
     if need_bias and db is None:
         db = db_out if db_out is not None else torch.empty(n, dtype=torch.float32, device=dy.device)

@@ -280,8 +280,9 @@ def gemm_colsum_ok(m, n, k, c_dtype, trans_a, splitk, m_live):
 
 
 def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=0.0, bias=None, rowscale=None,
-         splitk=1, a_off=0, b_off=0, c_off=0, epilogue=0, aux=None, m_live=None, colsum=None, colsum_scale=1.0):
-    """c = alpha * op(a) op(b) (+bias) (+beta*c) (*rowscale); dtype picks the kernel family
+         splitk=1, a_off=0, b_off=0, c_off=0, epilogue=0, aux=None, m_live=None, colsum=None, colsum_scale=1.0, tag=None):
+    """c = alpha * op(a) op(b) (+bias) (+beta*c) (*rowscale); dtype picks the kernel family.  tag: free-form label
+    ("dgrad", ...) for measurement wrappers (bench.py's probe); not used here.
     (fp32 -> exact-f32 MFMA, bf16 -> bf16 MFMA with fp32 accumulate; c may be fp32 for bf16 inputs)."""
     if a.dtype == torch.float32:
         assert b.dtype == torch.float32 and c.dtype == torch.float32 and m_live is None

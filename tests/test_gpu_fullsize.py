@@ -16,9 +16,12 @@ pytestmark = pytest.mark.gpu
 B = 128
 TOL = {
     "f32": dict(cls4t=1e-3, loss=1e-4, grad=2e-3),
-    # measured (profiles/r02_parity_table.txt): f16 agree .9996 cls4t 8.4e-4 loss 2.4e-6 grad 3.6e-3 / 2.3e-2 (patch embed);
-    #                                           bf16 agree .9971 cls4t 6.5e-3 loss 1.2e-4 grad 1.85e-2 / 7.1e-2
-    "f16": dict(agree=0.999, cls4t=1.0e-3, loss=1e-5, grad=5.5e-3, grad_pe=3.5e-2),
+    # measured (profiles/r02_parity_table.txt): f16 agree .9996 cls4t 8.4e-4 loss 2.4e-6..6.8e-6 grad 3.6e-3..5.9e-3 / 1.7e-2..2.3e-2
+    # (patch embed); bf16 agree .9971 cls4t 6.5e-3 loss 1.2e-4 grad 1.85e-2 / 7.1e-2.  The gradient figures move by up to 1.6x
+    # between builds whose attention outputs differ by ONE unit in the last place (bit-compared, tools/attn_bitcmp.py): the
+    # reference's loss mines the hardest positive / negative per anchor (triplet_loss.py:84-85), a discrete choice that
+    # near-ties flip, and one flipped pair shifts every upstream gradient together.  Bounds = worst observed x 1.5.
+    "f16": dict(agree=0.999, cls4t=1.0e-3, loss=1.2e-5, grad=9e-3, grad_pe=3.5e-2),
     "bf16": dict(agree=0.995, cls4t=1.0e-2, loss=3e-4, grad=2.8e-2, grad_pe=0.11),
 }
 

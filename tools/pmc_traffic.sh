@@ -49,7 +49,7 @@ wgrad = blocks * ((M * D + M * H) * 2 * 2 + 2 * D * H * 4 + (M * D * 2) * 2 + D 
 alg = fwd + dgrad + wgrad
 res = {"gemm_hbm_bytes_per_step": int(fetch + write), "gemm_fetch_bytes_per_step": int(fetch), "gemm_write_bytes_per_step": int(write),
        "gemm_launches_per_step": launches, "gemm_alg_bytes_per_step": int(alg),
-       "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --no-graph`, GEMM-family "
+       "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the eager bench command (bench.py --no-graph), GEMM-family "
                "kernels summed per step; FETCH_SIZE x2 (gfx950) and KB->bytes; memory-side request counters include Infinity-Cache "
                "hits (upper bound on HBM bytes); alg bytes = backbone blocks only (operands once + outputs once)"}
 json.dump(res, open("gpurun_out/r02_pmc_traffic.json", "w"), indent=1)
