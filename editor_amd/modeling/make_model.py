@@ -467,11 +467,19 @@ class EDITOR(nn.Module):
             raise RuntimeError("EDITOR (MI355X build): inputs must be on the GPU; there is no CPU fallback path")
         b = rgb.shape[0]
         dim = self.BACKBONE.token_dim
-        with torch.no_grad():
+        # The frequency branch (wavelet counts + the serial top-10 selection, ~0.25 ms of mostly latency) depends only on the
+        # images and is needed only when the masks are OR-ed after the backbone: it runs on the side stream, beside the
+        # patch embedding and the first blocks (a parallel branch of the captured graph as well).
+        cur = torch.cuda.current_stream(rgb.device)
+        side = fn._side_stream(rgb.device)
+        side.wait_stream(cur)
+        with torch.no_grad(), torch.cuda.stream(side):
             mask_fre, _ = ops.frequency_mask(mods[0], mods[1], mods[2], self.FREQ_INDEX.keep, mods[3] if nmod > 3 else None)
+            fre_done = side.record_event()
         imgs = torch.cat(mods, dim=0)
         feats, probs = self._backbone(imgs, cam_label)
         t = feats.shape[1]
+        cur.wait_event(fre_done)
         with torch.no_grad():
             index = self._select(probs, mask_fre, b)
             if self.teacher_index is not None:
