@@ -112,6 +112,37 @@ __device__ __forceinline__ short8_t join(uint2 lo, uint2 hi)
     x.u[0] = lo.x; x.u[1] = lo.y; x.u[2] = hi.x; x.u[3] = hi.y;
     return x.s;
 }
+// Output tiles leave through LDS.  The accumulators hold a TRANSPOSED 16 x 64 tile (lane (i, g): element (row i, column
+// dt*16 + 4g + r)); stored directly, one instruction writes 8-byte pieces of 16 different rows (32 contiguous bytes per row)
+// and a 128-byte row needs four instructions - the kernels were bound by the number of partial-line requests, not by bytes
+// (block size, occupancy and 20 % less arithmetic all left their time unchanged; without the global loads / stores of the
+// own side they ran 15-25 % faster).  Here the tile is parked in 2.5 KiB of the wave's own LDS (rows padded to 160 bytes:
+// the 8-byte column writes of 8 rows hit disjoint banks) and leaves as 16 bytes per lane, 8 lanes per full 128-byte row.
+constexpr int STG_ROW = 160, STG_BYTES = 16 * STG_ROW;
+template <bool F16>
+__device__ __forceinline__ void store_tile(char* stg, const float4_t (&o)[4], bf16_t* dst, long ldo, int nrows, int lane)
+{
+    const int li = lane & 15, lg = lane >> 4;
+    if (!stg) {                                      // no LDS left for staging (608-token images), or forward (see launch_all)
+        if (li < nrows) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<uint2*>(dst + (long)li * ldo + dt * 16 + 4 * lg) = pack4<F16>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<uint2*>(stg + li * STG_ROW + dt * 32 + lg * 8) = pack4<F16>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+    // (same wave wrote and reads: the compiler's lgkmcnt wait orders the two; no barrier)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int row = pass * 8 + (lane >> 3), ch = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + row * STG_ROW + ch * 16);
+        if (row < nrows) *reinterpret_cast<uint4*>(dst + (long)row * ldo + ch * 8) = v;
+    }
+}
+
 __device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
@@ -123,6 +154,7 @@ struct AttnArgs {
     int ldp;                              // row stride (floats) of the probability output, multiple of 4
     const int* cu;                        // varlen: sequence b owns packed rows [cu[b], cu[b+1]); NULL = dense (b*T)
     long Mtot;                            // total packed rows (lse / delta are laid out [heads][Mtot])
+    int stage_out;                        // outputs leave through per-wave LDS staging (store_tile); 0: direct 8-byte stores
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -190,6 +222,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const float sc = a.scale * kLog2e;
     const long row_idx0 = (long)hh * a.Mtot + row0;                // lse / delta index of row 0
     const long prow0 = ((long)b * a.heads + hh) * a.T;             // probability rows (dense mode only)
+    char* stg = a.stage_out ? smem + 2 * Tp * ROWB + w * STG_BYTES : nullptr;     // this wave's output staging (store_tile)
 
     for (int q0 = w * 16; q0 < T; q0 += nw * 16) {
         const int q = q0 + li;
@@ -280,12 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                         o[dt] = mfma16<F16>(frag_t(vimg, s2, dt, lane), pf, o[dt]);
                     if (FULL) __builtin_amdgcn_sched_barrier(0);
                 }
-            if (q < T) {
-                bf16_t* orow = a.out + (row0 + q) * D + hh * HD + 4 * lg;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    *reinterpret_cast<uint2*>(orow + dt * 16) = pack4<F16>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
-            }
+            store_tile<F16>(stg, o, a.out + (row0 + q0) * D + hh * HD, D, T - q0, lane);
             continue;
         }
         if (!BWD) {
@@ -386,13 +414,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             for (int s2 = 0; s2 + 1 < npair; ++s2) pair(s2, std::false_type{});
             if (npair > 0) pair(npair - 1, std::true_type{});
         }
-        if (q < T) {
-            bf16_t* orow = BWD ? a.dqkv + (row0 + q) * ld + hh * HD + 4 * lg
-                               : a.out + (row0 + q) * D + hh * HD + 4 * lg;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<uint2*>(orow + dt * 16) = pack4<F16>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
-        }
+        if (BWD) store_tile<F16>(stg, o, a.dqkv + (row0 + q0) * ld + hh * HD, ld, T - q0, lane);
+        else store_tile<F16>(stg, o, a.out + (row0 + q0) * D + hh * HD, D, T - q0, lane);
     }
 }
 
@@ -509,13 +532,11 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
                 qcompute(u2, fq, fd);
             }
         }
-        if (key < T) {
-            bf16_t* krow = a.dqkv + (row0 + key) * ld + D + hh * HD + 4 * lg;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                *reinterpret_cast<uint2*>(krow + dt * 16) = pack4<F16>(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
-                *reinterpret_cast<uint2*>(krow + D + dt * 16) = pack4<F16>(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
-            }
+        {
+            char* stg = a.stage_out ? smem + 2 * Tp * ROWB + 2 * Tp * sizeof(float) + w * STG_BYTES : nullptr;
+            bf16_t* kdst = a.dqkv + (row0 + k0) * ld + D + hh * HD;
+            store_tile<F16>(stg, dk, kdst, ld, T - k0, lane);
+            store_tile<F16>(stg, dv, kdst + D, ld, T - k0, lane);
         }
     }
 }
@@ -814,10 +835,17 @@ inline int pick_nt(int T) { return T <= 160 ? 10 : (T <= 224 ? 14 : (T <= 416 ? 
 inline int pick_threads(int T) { const int tiles = (T + 15) / 16; return (tiles % 3 == 0) ? 192 : 256; }
 
 template <int NT, bool F16>
-int launch_all(const AttnArgs& a, int B, int mode, hipStream_t stream)
+int launch_all(const AttnArgs& a_in, int B, int mode, hipStream_t stream)
 {
+    AttnArgs a = a_in;
     const int threads = pick_threads(a.T);
-    const size_t img = (size_t)2 * NT * 16 * ROWB;
+    // Per-wave output staging (store_tile) for the backward passes, when the LDS has room for it next to the images.
+    // Measured (tools/attn_prof.sh, T = 129): dK/dV 136 -> 126 us, dQ 111 -> 109 us; the forward gets SLOWER with it
+    // (86 -> 95 us: 47.7 instead of 40 KiB per workgroup drops a resident workgroup), so it keeps the direct stores.
+    size_t stg = (size_t)(threads / 64) * STG_BYTES;
+    if (mode == 0 || (size_t)2 * NT * 16 * ROWB + (size_t)2 * NT * 16 * sizeof(float) + stg > 160 * 1024) stg = 0;
+    a.stage_out = stg ? 1 : 0;
+    const size_t img = (size_t)2 * NT * 16 * ROWB + stg;
     const dim3 grid(B * a.heads);
     int rc;
     if (mode == 0) {
@@ -854,7 +882,7 @@ int launch_all(const AttnArgs& a, int B, int mode, hipStream_t stream)
             hipLaunchKernelGGL(k1, grid, dim3(threads), img, stream, a);
         }
         EDITOR_LAUNCH_CHECK();
-        const size_t lds2 = img + (size_t)2 * NT * 16 * sizeof(float);
+        const size_t lds2 = img + (size_t)2 * NT * 16 * sizeof(float);          // images | lse, delta | staging
         if (full) {
             auto k2 = attn_kv_pass_kernel<NT, F16, true>;
             if ((rc = set_lds(k2, lds2))) return rc;
@@ -915,7 +943,7 @@ int attention_fwd_h16(const uint16_t* qkv, int B, int T, int heads, int hd, floa
     if (probs && (ldp < T || (ldp & 3) || (reinterpret_cast<uintptr_t>(probs) & 15) || cu)) return (int)hipErrorInvalidValue;
     if (cu && mask) return (int)hipErrorInvalidValue;             // packed sequences hold only live tokens
     if (!cu) Mtot = (long)B * T;
-    AttnArgs a{qkv, nullptr, nullptr, out, nullptr, probs, lse, nullptr, mask, T, heads, scale, ldp, cu, Mtot};
+    AttnArgs a{qkv, nullptr, nullptr, out, nullptr, probs, lse, nullptr, mask, T, heads, scale, ldp, cu, Mtot, 0};
     return dispatch<F16>(a, B, 0, stream);
 }
 
@@ -926,7 +954,7 @@ int attention_bwd_h16(const uint16_t* qkv, const uint16_t* dout, const uint16_t*
 {
     if (hd != HD || T < 1 || B < 1 || !workspace || !lse || (cu && mask)) return (int)hipErrorInvalidValue;
     if (!cu) Mtot = (long)B * T;
-    AttnArgs a{qkv, dout, out, nullptr, dqkv, nullptr, const_cast<float*>(lse), workspace, mask, T, heads, scale, 0, cu, Mtot};
+    AttnArgs a{qkv, dout, out, nullptr, dqkv, nullptr, const_cast<float*>(lse), workspace, mask, T, heads, scale, 0, cu, Mtot, 0};
     return dispatch<F16>(a, B, 1, stream);
 }
 

@@ -2,7 +2,7 @@
 # SQ wave-time breakdown of the attention kernels (tools/attn_bench.py) - one --pmc pass, --kernel-trace only
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/pmc_attn
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --output-format csv -d /tmp/pmc_attn -o pmc -- python tools/attn_variants.py > /tmp/pmc_attn.log 2>&1
+rocprofv3 --kernel-trace --pmc ${ATTN_PMC:-SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES} --output-format csv -d /tmp/pmc_attn -o pmc -- python tools/attn_variants.py > /tmp/pmc_attn.log 2>&1
 tail -2 /tmp/pmc_attn.log
 python - <<PY
 import csv, collections, glob
