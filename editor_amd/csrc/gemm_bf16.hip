@@ -947,6 +947,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
 #undef PP_MMA
 #undef PP_WAIT_LGKM0
 
+    // A raw s_barrier does not wait for the wave's own outstanding LDS operations (gfx950 backs off barriers instead of
+    // draining before them) and LDS queues are per SIMD pair: another wave's read can overtake a write that was issued
+    // before the barrier.  The epilogue's barriers are therefore preceded by lgkmcnt(0).
+#define PP_EBAR() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PP_BAR(); } while (0)
     const bool staged = g.pp_staged && g.beta == 0.f && (g.splitk == 1 || g.slabs) && (g.N & 7) == 0 && (g.ldc & 7) == 0 &&
                         (g.ldaux & 7) == 0;
     if (staged && !C_F32 && (g.epilogue == EDITOR_EPI_NONE || g.epilogue == EDITOR_EPI_GELU || g.epilogue == EDITOR_EPI_GELU_BWD)) {
@@ -955,7 +959,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
         // staged value is the (rounded) pre-activation, which is an output anyway; the activation is computed from it
         // on the way out, as the unfused form would.
         constexpr int RB = 256 * 2 + 16;
-        PP_BAR();
+        PP_EBAR();
         const bool add_bias = g.bias && blockIdx.y == 0;
         float4 bv[4];                                          // this lane's four column groups: loaded once, not per row
         float rsv[8];
@@ -1016,7 +1020,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
                 }
             }
         }
-        PP_BAR();
+        PP_EBAR();
         PP_STAMP(3);
         bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
         bf16_t* Ab = reinterpret_cast<bf16_t*>(g.aux);
@@ -1052,11 +1056,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
             *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = p;
         }
         if (g.colsum) {       // 16 threads share each column group: fold through LDS (the tile image is no longer needed)
-            PP_BAR();
+            PP_EBAR();
             float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[(threadIdx.x >> 5) * 256 + (threadIdx.x & 31) * 8 + e] = cs[e];
-            PP_BAR();
+            PP_EBAR();
             if (threadIdx.x < 256 && n0 + (int)threadIdx.x < g.N) {
                 float t = 0.f;
 #pragma unroll
@@ -1070,7 +1074,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
         constexpr int RBP = 256 * 4 + 16;
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
-            PP_BAR();
+            PP_EBAR();
             if (wr == pass) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
@@ -1078,7 +1082,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
                     for (int j = 0; j < 4; ++j)
                         *reinterpret_cast<float4_t*>(smem + (i * 16 + li) * RBP + (wc * 64 + j * 16 + lg * 4) * 4) = acc[i][j];
             }
-            PP_BAR();
+            PP_EBAR();
             const int mp = m0 + pass * 128;
             switch (g.epilogue) {
                 case EDITOR_EPI_RESIDUAL: epilogue_copy_out<F16, C_F32, EDITOR_EPI_RESIDUAL, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
@@ -1093,6 +1097,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
     }
     if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(5); }
 #undef PP_STAMP
+#undef PP_EBAR
 #undef PP_BAR
 }
 

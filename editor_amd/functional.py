@@ -158,6 +158,7 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, 
         need_colsum = True
     else:
         need_colsum = False
+    sk, skf = _splitk_for(n, k, m)
     if use_side:
         side = _side_stream(dy.device)
         side.wait_event(dy_ready)                    # dy is complete; the dgrad above runs concurrently
@@ -166,11 +167,11 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, 
         # allocator hold blocks back and cost 3 ms per eager step)
         _SIDE_KEEP.append((dy, x2d))
         with torch.cuda.stream(side):
-            ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, alpha=inv, splitk=_splitk_for(n, k, m), m_live=m_live)
+            ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, alpha=inv, splitk=sk, epilogue=skf, m_live=m_live)
             if need_colsum:
                 ops.colsum(dy, out=db, scale=inv)
     else:
-        ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, alpha=inv, splitk=_splitk_for(n, k, m), m_live=m_live)   # both stored (Kred=m, .)
+        ops.gemm(dy, x2d, dw, n, k, m, n, k, k, 1, 1, alpha=inv, splitk=sk, epilogue=skf, m_live=m_live)   # both stored (Kred=m, .)
         if need_colsum:
             ops.colsum(dy, out=db, scale=inv)
     if dx_colsum is not None:
@@ -179,20 +180,26 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, 
 
 
 def _splitk_for(n_out, k_out, m_red, cus=256):
-    """wgrad has few output tiles and a long reduction: split the reduction over workgroups.  Cost model fitted to
-    tools/gemm_bench.py on the four hot-path shapes (units = one 64-deep K-tile of a 256x128 output tile, ~1.3 us):
-    rounds of `cus` workgroups x (K-tiles per split + 15 for the tile prologue / epilogue) + 3.3 per split for its
-    fp32 partial tile and its slab in the reduction kernel.  E.g. (2304,768): 4 splits (one 84 %-full round) beat 9
-    (two full rounds); (3072,768): 7 beat 3."""
-    tiles = ((n_out + 255) // 256) * ((k_out + 127) // 128)
+    """Split count AND kernel of a weight gradient (few output tiles, reduction over all token rows): (splitk, flags).
+    Outputs that tile into 256 x 256 (every linear layer of the path) take the ping-pong kernel with ONE round of
+    workgroups - splitk = CUs // tiles - measured with tools/gemm_bench.py on M = 49 536 token rows against the 256 x 128
+    three-stage kernel at ITS best split: (2304,768) 1 026 vs 729 TFLOP/s, (3072,768) 1 117 vs 751, (768,3072) 1 145 vs
+    862, (768,768) 659 vs 604 (both waves of a SIMD sit at the same barrier in the three-stage kernel; the ping-pong
+    kernel's two wave groups alternate on the matrix core).  Half or double that split loses 25-45 %.
+    Other shapes: the 256 x 128 kernel with the cost model fitted in round 1 (units = one 64-deep K-tile of a 256x128
+    tile, ~1.3 us): rounds of `cus` workgroups x (K-tiles per split + 15) + 3.3 per split for its slab."""
     nk = max(1, m_red // 64)
+    if n_out % 256 == 0 and k_out % 256 == 0:
+        tiles = (n_out // 256) * (k_out // 256)
+        return max(1, min(cus // tiles, nk // 8)), ops.EPI_FORCE_PP
+    tiles = ((n_out + 255) // 256) * ((k_out + 127) // 128)
     best, best_cost = 1, float("inf")
     for sk in range(1, max(1, min(32, nk // 16)) + 1):
         rounds = (tiles * sk + cus - 1) // cus
         cost = rounds * (nk / sk + 15.0) + 3.3 * sk
         if cost < best_cost - 1e-9:
             best, best_cost = sk, cost
-    return best
+    return best, 0
 
 
 class TransformerBlockFn(torch.autograd.Function):
@@ -333,7 +340,8 @@ class PatchEmbedFn(torch.autograd.Function):
         kdim = cols.shape[1]
         mrows = cols.shape[0]
         dw = torch.empty(d, kdim, dtype=torch.float32, device=dx.device)
-        ops.gemm(dpatch, cols, dw, d, kdim, mrows, d, kdim, kdim, 1, 1, alpha=1.0 / gs, splitk=_splitk_for(d, kdim, mrows))
+        sk, skf = _splitk_for(d, kdim, mrows)
+        ops.gemm(dpatch, cols, dw, d, kdim, mrows, d, kdim, kdim, 1, 1, alpha=1.0 / gs, splitk=sk, epilogue=skf)
         db = ops.colsum(dpatch, scale=1.0 / gs)
         dcls = dpos[0].clone().view(cls_shape)
         return (None, dw.view(conv_w.shape), db, dcls, dpos.view(pos_shape),

@@ -302,7 +302,7 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
             return
         call("editor_gemm_f32", _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), m, n, k, lda, ldb, ldc,
              int(trans_a), int(trans_b), 1, 0, 0, 0, 1, 0, 0, 0, float(alpha), float(beta), bias, rowscale, int(splitk),
-             int(epilogue), aux, n)
+             int(epilogue) & 0xFF, aux, n)          # (kernel-selection flags are a 16-bit-family matter)
     elif a.dtype in HALF_DTYPES:
         assert b.dtype == a.dtype
         entry = _h16(a, "gemm")
@@ -313,7 +313,8 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
             # kernel (LDS-DMA, deterministic split-K slabs) takes the whole tiles and a single-split product adds the
             # < 64-row tail - instead of the generic kernel with fp32-atomic split-K for the whole reduction
             k0 = (k // 64) * 64
-            gemm(a, b, c, m, n, k0, lda, ldb, ldc, 1, 1, alpha=alpha, splitk=splitk, a_off=a_off, b_off=b_off, c_off=c_off)
+            gemm(a, b, c, m, n, k0, lda, ldb, ldc, 1, 1, alpha=alpha, splitk=splitk, a_off=a_off, b_off=b_off, c_off=c_off,
+                 epilogue=epilogue)
             gemm(a, b, c, m, n, k - k0, lda, ldb, ldc, 1, 1, alpha=alpha, beta=1.0, splitk=1, a_off=a_off + k0 * lda,
                  b_off=b_off + k0 * ldb, c_off=c_off)
             return

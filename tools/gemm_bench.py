@@ -84,9 +84,9 @@ def main():
         if not only or kind_only == "dgrad":
             t = bench(lambda: ops.gemm(dy, w, dx, m, k, n, n, k, k, 0, 1), iters)
             rows.append(("dgrad", n, k, fl / t / 1e9))
-        sk = _splitk_for(n, k, m)
+        sk, skf = _splitk_for(n, k, m)
         if not only or kind_only == "wgrad":
-            t = bench(lambda: ops.gemm(dy, x, dw, n, k, m, n, k, k, 1, 1, splitk=sk), iters)
+            t = bench(lambda: ops.gemm(dy, x, dw, n, k, m, n, k, k, 1, 1, splitk=sk, epilogue=skf), iters)
             rows.append((f"wgrad(sk={sk})", n, k, fl / t / 1e9))
     for r in rows:
         print("%-14s N=%-5d K=%-5d %8.1f TFLOP/s" % r)
