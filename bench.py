@@ -451,8 +451,8 @@ def main():
                 "frac": round(achieved / PEAK_TFLOPS, 4),
                 "traffic": None if traffic is None else traffic.get("gemm_hbm_bytes_per_step"),
                 "traffic_note": None if traffic is None else traffic.get("note"),
-                "kernel": "16-bit GEMM family: gemm_bf16_pp_kernel (256x256x64 ping-pong, fwd + dgrad) and gemm_bf16_pipe_kernel "
-                          "(256x128x64, 3 LDS-DMA stages, wgrad), v_mfma_f32_16x16x32_" + ("f16" if args.dtype == "f16" else "bf16"),
+                "kernel": "16-bit GEMM family: gemm_bf16_pp_kernel (256x256x64 ping-pong; fwd, dgrad, and wgrad as one round of "
+                          "split-K workgroups + slab reduction), v_mfma_f32_16x16x32_" + ("f16" if args.dtype == "f16" else "bf16"),
                 "launches_per_step": launches, "gemm_ms_per_step": round(ms, 3),
                 "alg_tflop_per_step": round(flops / 1e12, 2),
                 "alg_bytes_per_step": None if traffic is None else traffic.get("gemm_alg_bytes_per_step"),
