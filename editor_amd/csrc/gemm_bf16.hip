@@ -59,6 +59,7 @@ struct GemmB16Args {
     unsigned long long* trace;               // debug (EDITOR_GEMM_TRACE): per-workgroup s_memtime stamps
     int force_pp;                            // EDITOR_EPI_FORCE_PP: the 256x256 kernel whatever the heuristic says
     int aux_grad;                            // EDITOR_EPI_AUX_GRAD: aux holds gelu'(pre-activation), not the pre-activation
+    int tile_frags;                          // EDITOR_EPI_TILE_ROWS: 16-row fragments per tile of the ping-pong kernel (13; 0 = 16)
 };
 
 // exact-erf GELU (nn.GELU default) for bf16 outputs, two values per instruction (v_pk_fma_f32 / v_pk_mul_f32):
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB16Args g)
 // unrolled per-fragment epilogue is ~10k straight-line instructions executed once per tile, i.e. always instruction-cache
 // cold (measured: ~5.5 us per tile even with the global stores removed).
 template <bool F16, bool C_F32, int EPI, int PBM, int PBN, int NTHREADS>
-__device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const char* lds, int m0, int n0, int split)
+__device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const char* lds, int m0, int n0, int split, int mlim)
 {
     constexpr int RBP = PBN * 4 + 16;
     constexpr int GPR = PBN / 8;                                // 8-column groups per tile row
@@ -390,7 +391,7 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
             const int c = threadIdx.x + (half * (ITERS / 2) + it) * NTHREADS;
             const int row = c / GPR, cg = c % GPR;
             const int m = m0 + row, n = n0 + cg * 8;
-            if (m >= g.M || n >= g.N) continue;                  // N is a multiple of 8 on this path (checked on the host)
+            if (m >= mlim || n >= g.N) continue;                 // N is a multiple of 8 on this path (checked on the host)
             float x[8] = {lo[it].x, lo[it].y, lo[it].z, lo[it].w, hi[it].x, hi[it].y, hi[it].z, hi[it].w};
             const float rs = g.rowscale ? g.rowscale[m] : 1.f;
             float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -456,10 +457,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmB16Args& g, float4_t (
             *reinterpret_cast<float4_t*>(lds + (wm + i * 16 + li) * RBP + (wn + j * 16 + lg * 4) * 4) = acc[i][j];
     __syncthreads();
     switch (g.epilogue) {
-        case EDITOR_EPI_RESIDUAL: epilogue_copy_out<F16, C_F32, EDITOR_EPI_RESIDUAL, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
-        case EDITOR_EPI_GELU:     epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
-        case EDITOR_EPI_GELU_BWD: epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU_BWD, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
-        default:                  epilogue_copy_out<F16, C_F32, EDITOR_EPI_NONE, PBM, PBN, NTHREADS>(g, lds, m0, n0, split); break;
+        case EDITOR_EPI_RESIDUAL: epilogue_copy_out<F16, C_F32, EDITOR_EPI_RESIDUAL, PBM, PBN, NTHREADS>(g, lds, m0, n0, split, g.M); break;
+        case EDITOR_EPI_GELU:     epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU, PBM, PBN, NTHREADS>(g, lds, m0, n0, split, g.M); break;
+        case EDITOR_EPI_GELU_BWD: epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU_BWD, PBM, PBN, NTHREADS>(g, lds, m0, n0, split, g.M); break;
+        default:                  epilogue_copy_out<F16, C_F32, EDITOR_EPI_NONE, PBM, PBN, NTHREADS>(g, lds, m0, n0, split, g.M); break;
     }
 }
 
@@ -748,14 +749,15 @@ __device__ __forceinline__ short8_t lds_rdtr(uint32_t addr)
 // k0 = 0 position.  SPAN = 64 (A: rows per wave-row half) or 32 (B); image index rho in [0,128) -> tile-local index
 // (rho / SPAN) * 2*SPAN + sub*SPAN + rho % SPAN.  The K-tile position is a wave-uniform offset added at issue time.
 template <bool KMAJOR, int SPAN>
-__device__ __forceinline__ void pp_unit_offsets(long ld, int r0, int R, int sub, int wu, int lane, uint32_t (&vo)[2])
+__device__ __forceinline__ void pp_unit_offsets(long ld, int r0, int R, int sub, int wu, int lane, uint32_t (&vo)[2], int g1base = 128)
 {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int piece = wu * 2 + j;
         if (KMAJOR) {
             const int rho = piece * 8 + (lane >> 3);
-            const int loc = (rho / SPAN) * (2 * SPAN) + sub * SPAN + (rho % SPAN);
+            int loc = (rho / SPAN) * (2 * SPAN) + sub * SPAN + (rho % SPAN);
+            if (loc >= 128) loc += g1base - 128;                // (A only: short tiles, see the kernel's F0 / F1)
             const int c = (lane & 7) ^ (rho & 7);
             vo[j] = (uint32_t)(((long)min(r0 + loc, R - 1) * ld + c * 8) * 2);
         } else {
@@ -768,9 +770,21 @@ __device__ __forceinline__ void pp_unit_offsets(long ld, int r0, int R, int sub,
     }
 }
 
-template <bool F16, bool A_KMAJOR, bool B_KMAJOR, bool C_F32>
+// SHORT TILES (F0 + F1 < 16).  The hot path's M = 49 536 token rows make 194 x 3 = 582 tiles of a 768-wide output: 2.27
+// rounds of 256 workgroups, i.e. three rounds with the last one 27 % full.  F0 / F1 = number of live 16-row fragments of
+// wave group 0 / 1 (8 / 8 = the full 256-row tile): with 7 / 6 the tile is 208 rows, 239 x 3 = 717 tiles = 2.8 rounds of
+// 0.81-size tiles - 2.44 full-tile rounds of work and of epilogue traffic instead of 3.  Group 1's rows start at F0*16
+// (its LDS image rows still at 128); the dead fragments of the A1 units are neither read nor multiplied, the two groups
+// keep alternating on the matrix core with 16+16+12+12 / 16+16+8+8 MFMAs per K-tile.  Staged epilogues only.
+// Measured: a 208-row tile takes 0.95 of a full tile's time, not 0.81 - each of the eight barrier intervals of a K-tile
+// costs ~300 cycles whatever the MFMA count of its phase (16 MFMAs = 256) - so this buys +4-7 % on the 768-wide products
+// (7 / 6 is the only short shape instantiated; 8 / 7 = 240 rows for N = 3072 measured 4-8 % SLOWER than full tiles).
+template <bool F16, bool A_KMAJOR, bool B_KMAJOR, bool C_F32, int F0 = 8, int F1 = 8>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
 {
+    static_assert(F0 >= 5 && F0 <= 8 && F1 >= 5 && F1 <= F0, "live fragments per wave group");
+    static_assert((F0 == 8 && F1 == 8) || A_KMAJOR, "short tiles: k-major A only");
+    constexpr int TH = (F0 + F1) * 16;                          // tile height
     constexpr int UNIT = 16384, KTB = 4 * UNIT;                 // per K-tile buffer: A0 | A1 | B0 | B1
     constexpr int UA0 = 0, UA1 = UNIT, UB0 = 2 * UNIT, UB1 = 3 * UNIT;
     constexpr int GM = 4;
@@ -783,7 +797,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
     const int gm0 = (wgid / grp) * GM, rem = wgid % grp;
     const int gsz = min(GM, g.tiles_m - gm0);
     const int tile_m = gm0 + rem % gsz, tile_n = rem / gsz;
-    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int m0 = tile_m * TH, n0 = tile_n * 256;
     int ktiles = g.K / BK;
     if (g.m_live) {
         const int live = *g.m_live;
@@ -797,6 +811,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const int wr = wu >> 2, wc = wu & 3;
+    const int gb = wr ? F0 * 16 : 0;                            // tile row of this wave group's first row
+    const int fg = wr ? F1 : F0;                                // ... and its live fragments
     const int li = lane & 15, lg = lane >> 4;
 #define PP_STAMP(k) do { if (g.trace && threadIdx.x == 0) g.trace[(long)(blockIdx.y * gridDim.x + bid) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     PP_STAMP(0);
@@ -831,8 +847,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
     }
     // LDS-DMA source offsets of this wave's two pieces of each unit (A0, A1, B0, B1)
     uint32_t voA[2][2], voB[2][2];
-    pp_unit_offsets<A_KMAJOR, 64>(g.lda, m0, g.M, 0, wu, lane, voA[0]);
-    pp_unit_offsets<A_KMAJOR, 64>(g.lda, m0, g.M, 1, wu, lane, voA[1]);
+    pp_unit_offsets<A_KMAJOR, 64>(g.lda, m0, g.M, 0, wu, lane, voA[0], F0 * 16);
+    pp_unit_offsets<A_KMAJOR, 64>(g.lda, m0, g.M, 1, wu, lane, voA[1], F0 * 16);
     pp_unit_offsets<B_KMAJOR, 32>(g.ldb, n0, g.N, 0, wu, lane, voB[0]);
     pp_unit_offsets<B_KMAJOR, 32>(g.ldb, n0, g.N, 1, wu, lane, voB[1]);
     const long kstepA = A_KMAJOR ? (long)BK * 2 : (long)BK * g.lda * 2;       // bytes per K-tile
@@ -842,9 +858,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
     short8_t fa[4][2], fb0[2][2], fb1[2][2];
 
     // (DS immediate offsets are 16 bits: the second K-tile buffer, 64 KiB up, goes through the address register)
-    auto read_a = [&](auto U, auto BUF) {
+    auto read_a = [&](auto U, auto BUF, auto LIVE) {           // LIVE: fragments of the unit this wave group uses
         constexpr int base = decltype(U)::value, bo = decltype(BUF)::value * KTB;
-        static_for<0, 4>([&](auto i) {
+        static_for<0, decltype(LIVE)::value>([&](auto i) {
             static_for<0, 2>([&](auto s) {
                 constexpr int I = decltype(i)::value, S = decltype(s)::value;
                 if constexpr (A_KMAJOR) fa[I][S] = lds_rd128<base + I * 2048>(adA[S] + bo);
@@ -862,12 +878,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
             });
         });
     };
-    auto mma_q = [&](short8_t (&fbv)[2][2], auto MI, auto NJ) {
+    auto mma_q = [&](short8_t (&fbv)[2][2], auto MI, auto NJ, auto LIVE) {
         constexpr int mi = decltype(MI)::value, nj = decltype(NJ)::value;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < decltype(LIVE)::value; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[mi * 4 + i][nj * 2 + j] =
@@ -889,31 +905,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
     using c1 = std::integral_constant<int, 1>;
 #define PP_WAIT_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PP_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PP_MMA(fbv, MI, NJ) do { __builtin_amdgcn_s_setprio(1); mma_q(fbv, MI{}, NJ{}); __builtin_amdgcn_s_setprio(0); } while (0)
+#define PP_MMA(fbv, MI, NJ, LIVE) do { __builtin_amdgcn_s_setprio(1); mma_q(fbv, MI{}, NJ{}, LIVE{}); __builtin_amdgcn_s_setprio(0); } while (0)
 
     // one K-tile (four phases) out of buffer BUF.  Units: A0,B0 are read in P1, B1 in P2, A1 in P3; each is refilled
     // for K-tile t+2 in the phase after (A1: two phases after, at P1 of t+1).
-    auto ktile = [&](int t, auto BUF) {
+    using c4 = std::integral_constant<int, 4>;
+    // FG: live fragments of this wave group (4 in A0 + FG-4 in A1).  (always_inline: an out-of-line copy would take the
+    // accumulators by reference, i.e. through scratch memory)
+    auto ktile = [&](int t, auto BUF, auto FG) __attribute__((always_inline)) {
         using B = decltype(BUF);
+        using L1 = std::integral_constant<int, decltype(FG)::value - 4>;
         // P1
         read_b(fb0, std::integral_constant<int, UB0>{}, B{});
         __builtin_amdgcn_sched_barrier(0);
-        read_a(std::integral_constant<int, UA0>{}, B{});
+        read_a(std::integral_constant<int, UA0>{}, B{}, c4{});
         if (t + 1 < nk) stage_a(t + 1, 1);
         PP_WAIT_LGKM0(); PP_BAR();
-        PP_MMA(fb0, c0, c0);
+        PP_MMA(fb0, c0, c0, c4);
         PP_BAR();
         // P2
         read_b(fb1, std::integral_constant<int, UB1>{}, B{});
         if (t + 2 < nk) stage_a(t + 2, 0);
         PP_WAIT_LGKM0(); PP_BAR();
-        PP_MMA(fb1, c0, c1);
+        PP_MMA(fb1, c0, c1, c4);
         PP_BAR();
         // P3
-        read_a(std::integral_constant<int, UA1>{}, B{});
+        read_a(std::integral_constant<int, UA1>{}, B{}, L1{});
         if (t + 2 < nk) stage_b(t + 2, 0);
         PP_WAIT_LGKM0(); PP_BAR();
-        PP_MMA(fb1, c1, c1);
+        PP_MMA(fb1, c1, c1, L1);
         PP_BAR();
         // P4
         if (t + 2 < nk) {
@@ -923,7 +943,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         PP_BAR();
-        PP_MMA(fb0, c1, c0);
+        PP_MMA(fb0, c1, c0, L1);
         PP_BAR();
     };
 
@@ -939,9 +959,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
     PP_BAR();
     PP_STAMP(1);
     if (wr == 1) PP_BAR();                                              // group 1 runs one barrier behind group 0
-    int t = 0;
-    for (; t + 1 < nk; t += 2) { ktile(t, c0{}); ktile(t + 1, c1{}); }
-    if (t < nk) ktile(t, c0{});
+    auto run = [&](auto FG) __attribute__((always_inline)) {
+        int t = 0;
+        for (; t + 1 < nk; t += 2) { ktile(t, c0{}, FG); ktile(t + 1, c1{}, FG); }
+        if (t < nk) ktile(t, c0{}, FG);
+    };
+    if constexpr (F0 == F1) run(std::integral_constant<int, F0>{});
+    else if (wr == 0) run(std::integral_constant<int, F0>{});
+    else run(std::integral_constant<int, F1>{});
     if (wr == 0) PP_BAR();                                              // re-align the two groups
     PP_STAMP(2);
 #undef PP_MMA
@@ -970,8 +995,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int ml = wr * 128 + i * 16 + li;
-            rsv[i] = (g.rowscale && m0 + ml < g.M) ? g.rowscale[m0 + ml] : 1.f;
+            const int ml = gb + i * 16 + li;                     // tile row (= row of the staged image)
+            rsv[i] = (g.rowscale && i < fg && m0 + ml < g.M) ? g.rowscale[m0 + ml] : 1.f;
         }
         if (g.epilogue == EDITOR_EPI_GELU_BWD) {
             // C = value * gelu'(saved pre-activation): the operand is fetched in the ACCUMULATOR layout (8 bytes per lane
@@ -983,7 +1008,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
             uint2 pre[8][4];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int m = min(m0 + wr * 128 + i * 16 + li, g.M - 1);
+                if (i >= fg) continue;
+                const int m = min(m0 + gb + i * 16 + li, g.M - 1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int n = min(n0 + wc * 64 + j * 16 + lg * 4, g.N - 4);
@@ -992,7 +1018,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int ml = wr * 128 + i * 16 + li;
+                if (i >= fg) continue;
+                const int ml = gb + i * 16 + li;
                 const float rs = rsv[i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1008,7 +1035,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int ml = wr * 128 + i * 16 + li;
+                if (i >= fg) continue;
+                const int ml = gb + i * 16 + li;
                 const float rs = rsv[i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1032,7 +1060,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
             const int row = c >> 5, cg = c & 31;
             const int m = m0 + row, n = n0 + cg * 8;
             uint4 p = *reinterpret_cast<const uint4*>(smem + row * RB + cg * 16);
-            if (m >= g.M || n >= g.N) continue;
+            if (row >= TH || m >= g.M || n >= g.N) continue;
             if (gelu) {
                 uint32_t pw[4] = {p.x, p.y, p.z, p.w};
                 if (g.aux_grad) {        // the backward only needs gelu'(pre-activation): save THAT (one multiply there instead of
@@ -1077,23 +1105,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
             PP_EBAR();
             if (wr == pass) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < 8; ++i) {
+                    if (i >= fg) continue;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         *reinterpret_cast<float4_t*>(smem + (i * 16 + li) * RBP + (wc * 64 + j * 16 + lg * 4) * 4) = acc[i][j];
+                }
             }
             PP_EBAR();
-            const int mp = m0 + pass * 128;
+            const int mp = m0 + (pass ? F0 * 16 : 0);                      // the pass's wave group: first row, row limit
+            const int ml = min(g.M, mp + (pass ? F1 : F0) * 16);
             switch (g.epilogue) {
-                case EDITOR_EPI_RESIDUAL: epilogue_copy_out<F16, C_F32, EDITOR_EPI_RESIDUAL, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
-                case EDITOR_EPI_GELU:     epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
-                case EDITOR_EPI_GELU_BWD: epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU_BWD, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
-                default:                  epilogue_copy_out<F16, C_F32, EDITOR_EPI_NONE, 128, 256, 512>(g, smem, mp, n0, blockIdx.y); break;
+                case EDITOR_EPI_RESIDUAL: epilogue_copy_out<F16, C_F32, EDITOR_EPI_RESIDUAL, 128, 256, 512>(g, smem, mp, n0, blockIdx.y, ml); break;
+                case EDITOR_EPI_GELU:     epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU, 128, 256, 512>(g, smem, mp, n0, blockIdx.y, ml); break;
+                case EDITOR_EPI_GELU_BWD: epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU_BWD, 128, 256, 512>(g, smem, mp, n0, blockIdx.y, ml); break;
+                default:                  epilogue_copy_out<F16, C_F32, EDITOR_EPI_NONE, 128, 256, 512>(g, smem, mp, n0, blockIdx.y, ml); break;
             }
             PP_STAMP(3 + pass);
         }
     } else {
-        epilogue_store<F16, C_F32, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, blockIdx.y == 0);
+        epilogue_store<F16, C_F32, 8>(g, acc, m0 + gb, n0 + wc * 64, lane, blockIdx.y == 0);   // (full tiles only: host)
     }
     if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(5); }
 #undef PP_STAMP
@@ -1124,14 +1155,24 @@ int launch(const GemmB16Args& g, hipStream_t stream)
     return 0;
 }
 
-// out[e] = beta*out[e] + sum_s slab[s][e]   (split-K reduction, deterministic order)
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, long n4, float* __restrict__ out, float beta)
+// out[e] = beta*out[e] + sum_s slab[s][e]   (split-K reduction, fixed order s = 0, 1, ...).  Eight slabs are requested
+// before the first is added: with a rolled loop (one load, one dependent add per trip) the 9 - 28 slabs of a weight
+// gradient were nine to twenty-eight serialised HBM latencies per thread (37 us for 71 MB).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, long n4, float* __restrict__ out,
+                                                          float beta)
 {
+    const float4* __restrict__ sl = reinterpret_cast<const float4*>(slabs);
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
-        float4 a = reinterpret_cast<const float4*>(slabs)[e];
-        for (int s = 1; s < nsplit; ++s) {
-            const float4 b = reinterpret_cast<const float4*>(slabs)[(long)s * n4 + e];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = 0; s0 < nsplit; s0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = s0 + j < nsplit ? sl[(long)(s0 + j) * n4 + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (s0 + j < nsplit) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+            }
         }
         if (beta != 0.f) {
             const float4 o = reinterpret_cast<float4*>(out)[e];
@@ -1159,18 +1200,18 @@ int launch_pipe_t(GemmB16Args g, hipStream_t stream)
     return 0;
 }
 
-template <bool F16, bool AK, bool BK_, bool CF>
-int launch_pp(GemmB16Args g, hipStream_t stream)
+template <bool F16, bool AK, bool BK_, bool CF, int F0, int F1>
+int launch_pp_t(GemmB16Args g, hipStream_t stream)
 {
     constexpr int LDS = 256 * (256 * 2 + 16);                   // >= 2 K-tile buffers, the fp32 half-tile image and the bf16 tile image
-    auto kern = gemm_bf16_pp_kernel<F16, AK, BK_, CF>;
+    auto kern = gemm_bf16_pp_kernel<F16, AK, BK_, CF, F0, F1>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    g.tiles_m = (g.M + 255) / 256;
+    g.tiles_m = (g.M + (F0 + F1) * 16 - 1) / ((F0 + F1) * 16);
     g.tiles_n = (g.N + 255) / 256;
     // measured: the LDS-staged epilogue (full-line 16-byte stores) beats the direct one on every layout here
     // (fwd N=2304,K=768: 701 vs 530 TFLOP/s; dgrad 974 vs 905)
@@ -1212,14 +1253,25 @@ int launch_pp(GemmB16Args g, hipStream_t stream)
 }
 
 template <bool F16, bool AK, bool BK_, bool CF>
+int launch_pp(const GemmB16Args& g, hipStream_t stream)
+{
+    if constexpr (AK && BK_) {
+        // short tiles (EDITOR_EPI_TILE_ROWS, see the kernel): both operands k-major and a staged epilogue (checked by the caller)
+        if (g.tile_frags == 13) return launch_pp_t<F16, AK, BK_, CF, 7, 6>(g, stream);
+    }
+    return launch_pp_t<F16, AK, BK_, CF, 8, 8>(g, stream);
+}
+
+template <bool F16, bool AK, bool BK_, bool CF>
 int launch_pipe(const GemmB16Args& g, hipStream_t stream)
 {
     // 256x256 ping-pong kernel where it measures faster (tools/gemm_bench.py with GEMM_EPI=1, M = 49 536 token rows,
     // TFLOP/s 256x128 -> 256x256): qkv+bias 596 -> 828, fc1+bias+GELU 412 -> 516, proj+residual 344 -> 448, fc2+residual
     // 702 -> 865, dgrads 777 -> 896, 850 -> 974, 604 -> 624, 649 -> 747, fc2 dgrad+GELU' 460 -> 507.  wgrad (both operands
-    // through ds_read_b64_tr_b16, twice the LDS instructions per phase, and few output tiles) is slower (742 vs 792) and
-    // stays on 256x128 with split-K slabs.
-    int pp_mode = g.force_pp ? 1 : -1;                                   // 1 force, 0 off (debug build only)
+    // through ds_read_b64_tr_b16, few output tiles): the CALLER picks - at the 256x128 kernel's best split the ping-pong
+    // kernel is slower (742 vs 792), at its own (one round of 256x256 tiles x splits) faster (979-1140 vs 729-862); see
+    // editor_amd.functional._splitk_for, which passes EDITOR_EPI_FORCE_PP with that split.
+    int pp_mode = (g.force_pp || g.tile_frags == 13) ? 1 : -1;          // 1 force, 0 off (debug build only)
 #ifdef EDITOR_DEBUG_TRACE
     if (const char* e = getenv("EDITOR_GEMM_PP")) pp_mode = atoi(e);
 #endif
@@ -1245,7 +1297,9 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
     const bool want_colsum = (epilogue & EDITOR_EPI_COLSUM) != 0;
     const bool force_pp = (epilogue & EDITOR_EPI_FORCE_PP) != 0;
     const bool aux_grad = (epilogue & EDITOR_EPI_AUX_GRAD) != 0;
-    epilogue &= ~(EDITOR_EPI_COLSUM | EDITOR_EPI_FORCE_PP | EDITOR_EPI_AUX_GRAD);
+    const int tile_frags = (epilogue >> 12) & 15;                       // EDITOR_EPI_TILE_ROWS(h): h / 16, 0 = full tiles
+    if (tile_frags != 0 && tile_frags != 13) return (int)hipErrorInvalidValue;
+    epilogue &= ~(EDITOR_EPI_COLSUM | EDITOR_EPI_FORCE_PP | EDITOR_EPI_AUX_GRAD | 0xF000);
     if (aux_grad && epilogue != EDITOR_EPI_GELU && epilogue != EDITOR_EPI_GELU_BWD) return (int)hipErrorInvalidValue;
     if (want_colsum && (c_f32 || epilogue == EDITOR_EPI_RESIDUAL || splitk > 1 || !splitk_ws || transA || M < 2048 || N < 512 ||
                         (N & 7) || (ldc & 7) || (ldaux & 7) || (K % BK) || beta != 0.f || m_live))
@@ -1259,6 +1313,9 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
     const bool glds = (K % BK == 0) && M >= 8 && N >= 8;
     // large problems: 3-stage LDS-DMA pipeline (256x128 tiles)
     const bool pipe = glds && M >= 256 && N >= 128;
+    const bool short_tiles = tile_frags == 13;
+    if (short_tiles && (transA || transB || splitk != 1 || beta != 0.f || (N & 7) || (ldc & 7) || (ldaux & 7) || !pipe || N < 256))
+        return (int)hipErrorInvalidValue;                       // (an error, not a fallback: the column-sum layout depends on h)
     // split-K: per-split slabs in the workspace + a reduction kernel (pipelined path), else fp32 atomics into C
     const bool slabs = splitk > 1 && pipe && (transA || transB) && splitk_ws && ldc == N && (((long)M * N) & 3) == 0 &&
                        (reinterpret_cast<uintptr_t>(splitk_ws) & 15) == 0;
@@ -1270,7 +1327,8 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
     GemmB16Args g{(const bf16_t*)A, (const bf16_t*)B, slabs ? (void*)splitk_ws : C, M, N, K, lda, ldb, ldc, alpha,
                   slabs ? 0.f : beta, bias, rowscale, splitk, (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux,
                   slabs ? 1 : 0,
-                  m_live, transA ? 1 : 0, 0, want_colsum ? splitk_ws : nullptr, nullptr, force_pp ? 1 : 0, aux_grad ? 1 : 0};
+                  m_live, transA ? 1 : 0, 0, want_colsum ? splitk_ws : nullptr, nullptr, force_pp ? 1 : 0, aux_grad ? 1 : 0,
+                  tile_frags};
     if (m_live && (!pipe || (splitk > 1 && !slabs))) return (int)hipErrorInvalidValue;   // live-row form: pipelined path only
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
     int rc;

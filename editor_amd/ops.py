@@ -1,6 +1,8 @@
 """Thin tensor-level wrappers over the C ABI (include/editor_hip.h).  No math happens here: each
 function allocates outputs with torch (device memory plumbing) and launches HIP kernels on the
 current stream.  Every function raises on CPU tensors - there is no fallback path."""
+import os
+
 import torch
 
 from . import _lib
@@ -271,6 +273,29 @@ EPI_NONE, EPI_RESIDUAL, EPI_GELU, EPI_GELU_BWD = 0, 1, 2, 3
 EPI_COLSUM = 0x100
 EPI_AUX_GRAD = 0x400          # with EPI_GELU / EPI_GELU_BWD (16-bit): aux = gelu'(pre-activation) instead of the pre-activation
 EPI_FORCE_PP = 0x200          # run the 256x256 ping-pong kernel whatever the shape heuristic says (tests)
+SHORT_TILES = os.environ.get("EDITOR_SHORT_TILES", "1") != "0"      # gemm_tile_rows below (measurement switch)
+
+
+def EPI_TILE_ROWS(h):
+    """OR-able: rows per output tile of the ping-pong kernel (208 | 256), include/editor_hip.h."""
+    return ((h // 16) & 15) << 12
+
+
+def gemm_tile_rows(m, n, cus=256):
+    """Tile height for a forward / dgrad product on the ping-pong kernel (k-major operands, staged epilogue): 208 when that
+    does not add a round of `cus` workgroups, else 256.  The path's M = 49 536 rows x 768 columns: 582 full tiles = 2.27
+    rounds -> 717 short tiles = 2.8 rounds, still three.  Measured (tools/gemm_bench.py): a 208-row tile takes 0.95 of a
+    256-row tile's time, not 0.81 - the main loop is bound by its eight barrier intervals per K-tile (~300 cycles each
+    whatever the MFMA count of the phase) - so the gain is +4-7 % on the 768-wide products (proj+residual 480 -> 517,
+    fc2+residual 912 -> 962 TFLOP/s) and a 240-row tile (N = 3072: 10 rounds either way) LOSES 4-8 %."""
+    tn = (n + 255) // 256
+    best, best_cost = 256, None
+    for h in (256, 208):
+        rounds = -(-(-(-m // h) * tn) // cus)
+        cost = rounds * (0.77 + 0.23 * h / 256.0)
+        if best_cost is None or cost < best_cost * 0.99:
+            best, best_cost = h, cost
+    return best
 
 
 def gemm_colsum_ok(m, n, k, c_dtype, trans_a, splitk, m_live):
@@ -318,11 +343,17 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
             gemm(a, b, c, m, n, k - k0, lda, ldb, ldc, 1, 1, alpha=alpha, beta=1.0, splitk=1, a_off=a_off + k0 * lda,
                  b_off=b_off + k0 * ldb, c_off=c_off)
             return
+        th = ((int(epilogue) >> 12) & 15) * 16 or 256            # explicit EPI_TILE_ROWS, else the shape heuristic
+        if (SHORT_TILES and not trans_a and not trans_b and splitk == 1 and beta == 0.0 and m_live is None and m >= 2048
+                and n >= 512 and n % 8 == 0 and ldc % 8 == 0 and k % 64 == 0 and not (int(epilogue) & 0xF000)):
+            th = gemm_tile_rows(m, n)
+            if th != 256:
+                epilogue = int(epilogue) | EPI_TILE_ROWS(th)
         if colsum is not None:
             # colsum (n) fp32 <- column sums of the rounded output (bias gradient of the layer this gradient feeds):
             # per-tile-row partials from the GEMM epilogue, folded in a fixed order
             assert gemm_colsum_ok(m, n, k, c.dtype, trans_a, splitk, m_live) and ldc == n
-            tiles_m = (m + 255) // 256
+            tiles_m = (m + th - 1) // th
             part = workspace(a.device, tiles_m * n)
             call(entry, _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), 0, m, n, k, lda, ldb, ldc,
                  int(trans_a), int(trans_b), float(alpha), float(beta), bias, rowscale, 1, int(epilogue) | EPI_COLSUM, aux,

@@ -367,6 +367,57 @@ def test_gemm_h16_pingpong_kernel(ops, tb, m, n, k, dtype):
     assert float((c[1024:] - 7.0).abs().max()) == 0.0          # 256-row tiles from row 1024 on were never touched
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("h", [208])
+@pytest.mark.parametrize("m,n,k", [(3 * 128 * 129, 768, 768), (5000, 1024, 128), (2049, 512, 192)])
+def test_gemm_h16_short_tiles(ops, m, n, k, h, dtype, monkeypatch):
+    """EDITOR_EPI_TILE_ROWS (208-row tiles of the ping-pong kernel, chosen by ops.gemm_tile_rows to fill the last
+    round of workgroups): every epilogue gives the SAME BITS as the full 256-row tiles - the accumulation order along K is
+    unchanged - and the per-tile column sums fold to the same totals (different grouping: fp32 rounding only)."""
+    a = torch.randn(m, k, generator=_g(1)).to(dtype).cuda()
+    b = (torch.randn(n, k, generator=_g(2)) * 0.1).to(dtype).cuda()
+    bias = (torch.randn(n, generator=_g(3)) * 0.1).cuda()
+    rs = (torch.rand(m, generator=_g(5)) + 0.5).cuda()
+    res = torch.randn(m, n, generator=_g(4)).cuda()
+    dsave = torch.randn(m, n, generator=_g(7)).to(dtype).cuda()
+
+    def run(flag):
+        outs = []
+        c = torch.full((m, n), float("nan"), dtype=dtype, device="cuda")
+        ops.gemm(a, b, c, m, n, k, k, k, n, 0, 0, alpha=0.5, bias=bias, rowscale=rs, epilogue=flag)
+        outs.append(c)
+        act, sav = torch.full_like(c, float("nan")), torch.full_like(c, float("nan"))
+        ops.gemm(a, b, act, m, n, k, k, k, n, 0, 0, bias=bias, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD | flag, aux=sav)
+        outs += [act, sav]
+        d = torch.full_like(c, float("nan"))
+        ops.gemm(a, b, d, m, n, k, k, k, n, 0, 0, epilogue=ops.EPI_GELU_BWD | ops.EPI_AUX_GRAD | flag, aux=dsave)
+        outs.append(d)
+        cf = torch.full((m, n), float("nan"), device="cuda")
+        ops.gemm(a, b, cf, m, n, k, k, k, n, 0, 0, bias=bias, rowscale=rs, epilogue=ops.EPI_RESIDUAL | flag, aux=res)
+        outs.append(cf)
+        cs = None
+        if ops.gemm_colsum_ok(m, n, k, dtype, 0, 1, None):
+            cs = torch.zeros(n, device="cuda")
+            c2 = torch.full_like(c, float("nan"))
+            ops.gemm(a, b, c2, m, n, k, k, k, n, 0, 0, epilogue=flag, colsum=cs)
+            outs.append(c2)
+        torch.cuda.synchronize()
+        return outs, cs
+
+    monkeypatch.setattr(ops, "SHORT_TILES", False)               # explicit flag below instead of the shape heuristic
+    full, cs_full = run(ops.EPI_FORCE_PP)
+    short, cs_short = run(ops.EPI_TILE_ROWS(h))
+    for x, y in zip(full, short):
+        assert not torch.isnan(y.float()).any()
+        assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
+    if cs_full is not None:
+        assert rel_err(cs_short.cpu(), cs_full.cpu().double()) < 1e-5
+        assert rel_err(cs_full.cpu(), full[-1].double().sum(0).cpu()) < 1e-5
+    # invalid uses are errors, not silent full tiles (the column-sum layout depends on h)
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, b.t().contiguous(), full[0], m, n, k, k, n, n, 0, 1, epilogue=ops.EPI_TILE_ROWS(h))
+
+
 def test_attention_varlen_matches_dense_reference(ops):
     """Compacted (variable-length) attention == per-sequence dense softmax attention (fp32 reference)."""
     heads, hd = 12, 64
