@@ -89,24 +89,33 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if (lane == 0) { if (mean_out) mean_out[row] = mean; if (rstd_out) rstd_out[row] = rstd; }
 }
 
+__device__ __forceinline__ float round_like(float v, float) { return v; }
+__device__ __forceinline__ float round_like(float v, bf16_t) { return bf16_to_f32(f32_to_bf16(v)); }
+__device__ __forceinline__ float round_like(float v, f16_t) { return f16_to_f32(f32_to_f16(v)); }
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm backward.  dx_out = dx_in (optional residual-branch gradient) + d/dx LN;  per-block partial
 // dgamma/dbeta rows go to `partials` [gridDim.x][2][D] and are folded by reduce_rows_kernel (deterministic).
+// Optional second output (cast_out != NULL): the 16-bit, row-scaled copy of dx_out the NEXT linear layer's backward
+// consumes - cast_out = round(dx_out * cast_rowscale[row] * cast_scale), with the column sums of the rounded values
+// (that layer's bias gradient) as per-block partial rows in cast_partials [gridDim.x][D] - i.e. what
+// cast_rows_colsum_kernel would produce from dx_out in a second pass over it (152 MB re-read per call at D = 768).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ mean_in, const float* __restrict__ rstd_in, long M, int D,
     const uint8_t* __restrict__ rowmask, int mask_period, const float* __restrict__ dx_in, float* __restrict__ dx_out,
-    float* __restrict__ partials, const int* __restrict__ m_live, float dy_scale)
+    float* __restrict__ partials, const int* __restrict__ m_live, float dy_scale, T* __restrict__ cast_out,
+    const float* __restrict__ cast_rowscale, float cast_scale, float* __restrict__ cast_partials)
 {
     __shared__ float red[4][2][1024];
     if (m_live) M = min(M, (long)((*m_live + 63) & ~63));
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nv = D >> 8;
-    float4 g[kMaxV], dg[kMaxV], db[kMaxV];
+    float4 g[kMaxV], dg[kMaxV], db[kMaxV], ccs[kMaxV];
 #pragma unroll
     for (int i = 0; i < kMaxV; ++i) {
-        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i];
+        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i]; ccs[i] = dg[i];
         if (i < nv) g[i] = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
     }
     for (long row = (long)blockIdx.x * 4 + w; row < M; row += (long)gridDim.x * 4) {
@@ -142,7 +151,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
             *reinterpret_cast<float4*>(dx_out + row * D + c0) = o;
+            if (cast_out) {
+                const float r = (cast_rowscale ? cast_rowscale[row] : 1.f) * cast_scale;
+                o.x *= r; o.y *= r; o.z *= r; o.w *= r;
+                Vec4<T>::st(cast_out + row * D + c0, o);
+                ccs[i].x += round_like(o.x, T{}); ccs[i].y += round_like(o.y, T{});
+                ccs[i].z += round_like(o.z, T{}); ccs[i].w += round_like(o.w, T{});
+            }
         }
+    }
+    if (cast_partials) {                                 // (block-uniform)
+#pragma unroll
+        for (int i = 0; i < kMaxV; ++i) if (i < nv) *reinterpret_cast<float4*>(&red[w][0][(i * 64 + lane) * 4]) = ccs[i];
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256)
+            cast_partials[(long)blockIdx.x * D + c] = (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]);
+        __syncthreads();
     }
     if (!partials) return;
 #pragma unroll
@@ -269,9 +293,6 @@ __global__ void cast_rows_kernel(const float* __restrict__ in, const float* __re
 // The same cast with the COLUMN SUMS of its (rounded) output on the side: the bias gradient of the nn.Linear this
 // gradient feeds (db = colsum(dy)) otherwise costs one more pass over dy.  One wave per row, lanes own fixed columns,
 // per-block partial rows -> reduce_rows_kernel (fixed order).  D a multiple of 256, D <= 256 * kMaxV.
-__device__ __forceinline__ float round_like(float v, float) { return v; }
-__device__ __forceinline__ float round_like(float v, bf16_t) { return bf16_to_f32(f32_to_bf16(v)); }
-__device__ __forceinline__ float round_like(float v, f16_t) { return f16_to_f32(f32_to_f16(v)); }
 template <typename TO>
 __global__ __launch_bounds__(256) void cast_rows_colsum_kernel(const float* __restrict__ in, const float* __restrict__ rowscale,
     long M, int D, TO* __restrict__ out, float* __restrict__ partials, float scale)
@@ -567,16 +588,26 @@ extern "C" int editor_layernorm_fwd(const float* x, const float* gamma, const fl
     return 0;
 }
 
-extern "C" int editor_layernorm_bwd(const void* dy, int dy_bf16, float dy_scale, const float* x, const float* gamma, const float* mean,
+namespace {
+int layernorm_bwd_impl(const void* dy, int dy_bf16, float dy_scale, const float* x, const float* gamma, const float* mean,
     const float* rstd, long M, int D, const uint8_t* rowmask, int mask_period, const float* dx_in, float* dx_out,
-    float* dgamma, float* dbeta, float* workspace, int ws_rows, const int* m_live, hipStream_t stream)
+    float* dgamma, float* dbeta, float* workspace, int ws_rows, const int* m_live, void* cast_out, const float* cast_rowscale,
+    float cast_scale, float* cast_colsum, float cast_colsum_scale, hipStream_t stream)
 {
     if (D % 256 || D > 1024 || M <= 0 || ws_rows < 1) return (int)hipErrorInvalidValue;
+    if (cast_out && (dy_bf16 == 0 || m_live || rowmask)) return (int)hipErrorInvalidValue;    // dense 16-bit rows only
     long blocks = (M + 3) / 4;
     if (blocks > ws_rows) blocks = ws_rows;
+    float* cast_partials = (cast_out && cast_colsum) ? workspace + (long)ws_rows * 2 * D : nullptr;   // third [ws_rows][D] region
     DISPATCH_T(dy_bf16, hipLaunchKernelGGL(layernorm_bwd_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, stream,
-               (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out, dgamma ? workspace : nullptr, m_live, dy_scale));
+               (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out, dgamma ? workspace : nullptr, m_live, dy_scale,
+               (TT*)cast_out, cast_rowscale, cast_scale, cast_partials));
     EDITOR_LAUNCH_CHECK();
+    if (cast_partials) {
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((D + 63) / 64), dim3(1024), 0, stream, cast_partials, (int)blocks, (long)D,
+                           cast_colsum, 0, cast_colsum_scale);
+        EDITOR_LAUNCH_CHECK();
+    }
     if (dgamma) {
         // workspace rows are [block][2][D] = P rows of 2D columns; dgamma and dbeta must be ONE (2,D) buffer
         // (dbeta == dgamma + D) so the reduction writes both without extra copies
@@ -586,6 +617,25 @@ extern "C" int editor_layernorm_bwd(const void* dy, int dy_bf16, float dy_scale,
         EDITOR_LAUNCH_CHECK();
     }
     return 0;
+}
+}  // namespace
+
+extern "C" int editor_layernorm_bwd(const void* dy, int dy_bf16, float dy_scale, const float* x, const float* gamma, const float* mean,
+    const float* rstd, long M, int D, const uint8_t* rowmask, int mask_period, const float* dx_in, float* dx_out,
+    float* dgamma, float* dbeta, float* workspace, int ws_rows, const int* m_live, hipStream_t stream)
+{
+    return layernorm_bwd_impl(dy, dy_bf16, dy_scale, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out, dgamma, dbeta,
+                              workspace, ws_rows, m_live, nullptr, nullptr, 1.f, nullptr, 1.f, stream);
+}
+
+extern "C" int editor_layernorm_bwd_cast(const void* dy, int dy_bf16, float dy_scale, const float* x, const float* gamma,
+    const float* mean, const float* rstd, long M, int D, const float* dx_in, float* dx_out, float* dgamma, float* dbeta,
+    float* workspace, int ws_rows, void* cast_out, const float* cast_rowscale, float cast_scale, float* cast_colsum,
+    float cast_colsum_scale, hipStream_t stream)
+{
+    if (!cast_out) return (int)hipErrorInvalidValue;
+    return layernorm_bwd_impl(dy, dy_bf16, dy_scale, x, gamma, mean, rstd, M, D, nullptr, 0, dx_in, dx_out, dgamma, dbeta, workspace,
+                              ws_rows, nullptr, cast_out, cast_rowscale, cast_scale, cast_colsum, cast_colsum_scale, stream);
 }
 
 extern "C" int editor_colsum(const void* dy, int dy_bf16, long M, int N, long ld, float* out, float* workspace,

@@ -119,6 +119,9 @@ def _side_stream(device):
     return st
 
 
+FUSE_LN_CAST = os.environ.get("EDITOR_FUSE_LN_CAST", "1") != "0"      # measurement switch (TransformerBlockFn.backward)
+
+
 def join_side_stream(device):
     """Main stream waits for every weight-gradient launch issued so far (call before handing gradients to autograd)."""
     st = _SIDE.get(device.index)
@@ -276,10 +279,19 @@ class TransformerBlockFn(torch.autograd.Function):
                                           dx_colsum=hb_fc1, gs=gs, dw_out=sv[10], db_out=sv[11],
                                           dxcs_out=sv[9], w_t=w2t)                       # da = (dy W2) * gelu'(a)
         dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs, gs=gs, dw_out=sv[8], db_out=sv[9], w_t=w1t)
-        dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w, mean2, rstd2, mask, 0, dx_in=dx2, m_live=m_live,
-                                            dy_scale=1.0 / gs, dgb_out=sink.ln_pair(6) if sink is not None else None)
-        # ---- attention branch:  x1 = x + rs * proj(attn(qkv(LN1(x))))
-        dy, dbias = _scaled_cast_colsum(dx1, rs_attn, act_dtype, m_live, hb_proj, gs, cs_out=sv[5])
+        fuse_cast = (FUSE_LN_CAST and m_live is None and mask is None and act_dtype in ops.HALF_DTYPES
+                     and d % 256 == 0 and d <= 1024)
+        if fuse_cast:
+            # LN2's backward also writes the 16-bit, drop-path-scaled copy of dx1 (and its column sums = proj's bias
+            # gradient) that the attention branch's backward starts from: no second pass over dx1
+            dx1, dn2w, dn2b, dy, dbias = ops.layernorm_bwd_cast(
+                dh2, x1, n2w, mean2, rstd2, dx2, rs_attn, gs, dy_scale=1.0 / gs,
+                dgb_out=sink.ln_pair(6) if sink is not None else None, want_colsum=hb_proj, cs_out=sv[5])
+        else:
+            dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w, mean2, rstd2, mask, 0, dx_in=dx2, m_live=m_live,
+                                                dy_scale=1.0 / gs, dgb_out=sink.ln_pair(6) if sink is not None else None)
+            # ---- attention branch:  x1 = x + rs * proj(attn(qkv(LN1(x))))
+            dy, dbias = _scaled_cast_colsum(dx1, rs_attn, act_dtype, m_live, hb_proj, gs, cs_out=sv[5])
         dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live, db=dbias, gs=gs, dw_out=sv[4], db_out=sv[5], w_t=wpt)
         dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, amask, attn_saved, ao, cu=cu, scale=qk_scale)
         dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live, gs=gs, dw_out=sv[2], db_out=sv[3], w_t=wqt)

@@ -152,6 +152,23 @@ def layernorm_bwd(dy, x2d, gamma, mean, rstd, rowmask=None, mask_period=0, dx_in
     return dx, dg, db
 
 
+def layernorm_bwd_cast(dy, x2d, gamma, mean, rstd, dx_in, rowscale, scale=1.0, dy_scale=1.0, dgb_out=None, want_colsum=True,
+                       cs_out=None):
+    """layernorm_bwd (dense 16-bit rows) that also hands out what cast_rows_colsum(dx, rowscale, dy.dtype, scale) would:
+    -> dx, dgamma, dbeta, dx16, colsum(dx16) / scale (None unless want_colsum)."""
+    m, d = x2d.shape
+    dx = torch.empty(m, d, dtype=torch.float32, device=x2d.device)
+    dgb = dgb_out if dgb_out is not None else torch.empty(2, d, dtype=torch.float32, device=x2d.device)
+    dx16 = torch.empty(m, d, dtype=dy.dtype, device=x2d.device)
+    cs = None
+    if want_colsum:
+        cs = cs_out if cs_out is not None else torch.empty(d, dtype=torch.float32, device=x2d.device)
+    ws = workspace(x2d.device, WS_ROWS * 3 * d)
+    call("editor_layernorm_bwd_cast", dy, _is_bf16(dy), float(dy_scale), x2d, gamma, mean, rstd, m, d, dx_in, dx, dgb[0], dgb[1],
+         ws, WS_ROWS, dx16, rowscale, float(scale), cs, 1.0 / float(scale))
+    return dx, dgb[0], dgb[1], dx16, cs
+
+
 def colsum(dy, out=None, scale=1.0):
     m, n = dy.shape
     if out is None:

@@ -93,6 +93,16 @@ int editor_layernorm_bwd(const void* dy, int dy_bf16, float dy_scale /* dy is mu
                          const float* rstd, long M, int D, const uint8_t* rowmask, int mask_period,
                          const float* dx_in, float* dx_out, float* dgamma, float* dbeta, float* workspace,
                          int ws_rows, const int* m_live, editor_stream_t stream);
+/* The same (dense 16-bit dy, no row mask) with the consumer's cast fused in: also writes cast_out (dtype of dy) =
+ * round(dx_out * cast_rowscale[row] * cast_scale) - the drop-path-scaled, loss-scaled 16-bit gradient the previous linear
+ * layer's backward takes (vit_pytorch.py:217-218 backward) - and, when cast_colsum != NULL, cast_colsum[n] =
+ * cast_colsum_scale * sum_m cast_out[m,n] (that layer's bias gradient): what editor_cast_rows_colsum would compute in a
+ * second pass over dx_out.  workspace: ws_rows*3*D floats. */
+int editor_layernorm_bwd_cast(const void* dy, int dy_bf16, float dy_scale, const float* x, const float* gamma,
+                              const float* mean, const float* rstd, long M, int D, const float* dx_in, float* dx_out,
+                              float* dgamma, float* dbeta, float* workspace, int ws_rows, void* cast_out,
+                              const float* cast_rowscale, float cast_scale, float* cast_colsum, float cast_colsum_scale,
+                              editor_stream_t stream);
 /* out[n] = scale * sum_m dy[m,n]  (bias gradients of every nn.Linear).  workspace: ws_rows*N floats. */
 int editor_colsum(const void* dy, int dy_bf16, long M, int N, long ld, float* out, float* workspace, int ws_rows,
                   float scale, editor_stream_t stream);

@@ -53,6 +53,29 @@ def test_layernorm_fwd_bwd(ops, dtype, d):
         assert rel_err(db.cpu(), br.grad) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,d", [(5161, 768), (517, 1024), (3, 256)])
+def test_layernorm_bwd_cast_fused(ops, m, d, dtype):
+    """editor_layernorm_bwd_cast = editor_layernorm_bwd followed by editor_cast_rows_colsum on its dx: the same bits for dx,
+    the 16-bit copy and the LN parameter gradients; the column sums (different per-block grouping) to fp32 rounding."""
+    x = (torch.randn(m, d, generator=_g(1)) * 2 + 0.3).cuda()
+    w = (torch.rand(d, generator=_g(2)) + 0.5).cuda()
+    dy = torch.randn(m, d, generator=_g(5)).to(dtype).cuda()
+    res = torch.randn(m, d, generator=_g(6)).cuda()
+    rs = (torch.rand(m, generator=_g(7)) + 0.5).cuda()
+    _, mean, rstd = ops.layernorm_fwd(x, w, torch.zeros_like(w), 1e-6, dtype, None, 0)
+    for rowscale, scale in ((rs, 1.0), (None, 4.0), (rs, 1.0 / 8)):
+        dx0, dg0, db0 = ops.layernorm_bwd(dy, x, w, mean, rstd, None, 0, dx_in=res, dy_scale=0.5)
+        c0, cs0 = ops.cast_rows_colsum(dx0, rowscale, dtype, scale)
+        dx1, dg1, db1, c1, cs1 = ops.layernorm_bwd_cast(dy, x, w, mean, rstd, res, rowscale, scale, dy_scale=0.5)
+        for a, b in ((dx0, dx1), (dg0, dg1), (db0, db1), (c0, c1)):
+            assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+        assert rel_err(cs1.cpu(), cs0.cpu().double()) < 1e-5
+        assert rel_err(cs1.cpu(), c1.double().sum(0).cpu() / scale) < 1e-5
+        _, _, _, c2, cs2 = ops.layernorm_bwd_cast(dy, x, w, mean, rstd, res, rowscale, scale, dy_scale=0.5, want_colsum=False)
+        assert cs2 is None and torch.equal(c2.view(torch.uint8), c1.view(torch.uint8))
+
+
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_f32_layouts(ops, ta, tb):
     m, n, k = 197, 171, 203

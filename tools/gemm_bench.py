@@ -79,11 +79,17 @@ def main():
             rows.append(("fwd+resid", n, k, fl / t / 1e9))
             dpre = torch.empty(m, k, device=dev, dtype=torch.bfloat16)
             prek = torch.randn(m, k, device=dev, generator=g).bfloat16()
-            t = bench(lambda: ops.gemm(dy, w, dpre, m, k, n, n, k, k, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=prek), iters)
+            # as the training step runs it: aux = gelu'(pre-activation) saved by the forward, B = the k-major W^T copy
+            wt = w.t().contiguous()
+            t = bench(lambda: ops.gemm(dy, wt, dpre, m, k, n, n, n, k, 0, 0, epilogue=ops.EPI_GELU_BWD | ops.EPI_AUX_GRAD,
+                                       aux=prek), iters)
             rows.append(("dgrad+gelu'", n, k, fl / t / 1e9))
         if not only or kind_only == "dgrad":
-            t = bench(lambda: ops.gemm(dy, w, dx, m, k, n, n, k, k, 0, 1), iters)
+            wt = w.t().contiguous()
+            t = bench(lambda: ops.gemm(dy, wt, dx, m, k, n, n, n, k, 0, 0), iters)
             rows.append(("dgrad", n, k, fl / t / 1e9))
+            t = bench(lambda: ops.gemm(dy, w, dx, m, k, n, n, k, k, 0, 1), iters)
+            rows.append(("dgrad(row-k W)", n, k, fl / t / 1e9))
         sk, skf = _splitk_for(n, k, m)
         if not only or kind_only == "wgrad":
             t = bench(lambda: ops.gemm(dy, x, dw, n, k, m, n, k, k, 1, 1, splitk=sk, epilogue=skf), iters)
