@@ -895,7 +895,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + vo[j]),
                                              (__attribute__((address_space(3))) void*)(unit + (wu * 2 + j) * 1024), 16, 0, 0);
     };
+    // short tiles: the two pieces this wave stages of an A1 unit are rows (wu & 3) * 16 .. + 15 of its group's second 64 rows;
+    // beyond the group's live fragments nobody reads them (waves 3, 6, 7 of the 7 + 6 tile) - and a wave that issues none
+    // still counts right: vmcnt(6) always spans the A0 / B0 / B1 pieces issued after the A1 ones
+    const bool a1_live = (wu & 3) < (wr ? F1 : F0) - 4;
     auto stage_a = [&](int t, int sub) {   // unit A<sub> of K-tile t
+        if (sub && !a1_live) return;
         dma2(baseA + t * kstepA, voA[sub], smem + (t & 1) * KTB + (sub ? UA1 : UA0));
     };
     auto stage_b = [&](int t, int sub) {
