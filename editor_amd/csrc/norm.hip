@@ -101,8 +101,10 @@ __device__ __forceinline__ float round_like(float v, f16_t) { return f16_to_f32(
 // (that layer's bias gradient) as per-block partial rows in cast_partials [gridDim.x][D] - i.e. what
 // cast_rows_colsum_kernel would produce from dx_out in a second pass over it (152 MB re-read per call at D = 768).
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
+// NV = D / 256 (float4 column groups per lane) and CAST (the second output) are compile-time: with worst-case-sized arrays
+// and the cast accumulators always present the kernel needed 150 registers (3 waves per SIMD) instead of <= 128.
+template <typename T, int NV, bool CAST>
+__global__ __launch_bounds__(256, NV <= 3 ? 4 : 3) void layernorm_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ mean_in, const float* __restrict__ rstd_in, long M, int D,
     const uint8_t* __restrict__ rowmask, int mask_period, const float* __restrict__ dx_in, float* __restrict__ dx_out,
     float* __restrict__ partials, const int* __restrict__ m_live, float dy_scale, T* __restrict__ cast_out,
@@ -111,20 +113,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     __shared__ float red[4][2][1024];
     if (m_live) M = min(M, (long)((*m_live + 63) & ~63));
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int nv = D >> 8;
-    float4 g[kMaxV], dg[kMaxV], db[kMaxV], ccs[kMaxV];
+    float4 g[NV], dg[NV], db[NV], ccs[CAST ? NV : 1];
 #pragma unroll
-    for (int i = 0; i < kMaxV; ++i) {
-        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i]; ccs[i] = dg[i];
-        if (i < nv) g[i] = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
+    for (int i = 0; i < NV; ++i) {
+        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i];
+        if (CAST) ccs[i] = dg[i];
+        g[i] = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
     }
     for (long row = (long)blockIdx.x * 4 + w; row < M; row += (long)gridDim.x * 4) {
         const bool keep = !(rowmask && !rowmask[mask_period ? row % mask_period : row]);
         const float mean = mean_in[row], rstd = rstd_in[row];
-        float4 xh[kMaxV], d[kMaxV];
+        float4 xh[NV], d[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+        for (int i = 0; i < NV; ++i) {
             const int c0 = (i * 64 + lane) * 4;
             const float4 xv = *reinterpret_cast<const float4*>(x + row * D + c0);
             d[i] = keep ? Vec4<T>::ld(dy + row * D + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         s1 = wave_sum(s1) / (float)D;
         s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-        for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+        for (int i = 0; i < NV; ++i) {
             const int c0 = (i * 64 + lane) * 4;
             float4 o;
             o.x = rstd * (d[i].x - s1 - xh[i].x * s2);
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
             *reinterpret_cast<float4*>(dx_out + row * D + c0) = o;
-            if (cast_out) {
+            if constexpr (CAST) {
                 const float r = (cast_rowscale ? cast_rowscale[row] : 1.f) * cast_scale;
                 o.x *= r; o.y *= r; o.z *= r; o.w *= r;
                 Vec4<T>::st(cast_out + row * D + c0, o);
@@ -160,9 +162,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             }
         }
     }
-    if (cast_partials) {                                 // (block-uniform)
+    if (CAST && cast_partials) {                         // (block-uniform)
 #pragma unroll
-        for (int i = 0; i < kMaxV; ++i) if (i < nv) *reinterpret_cast<float4*>(&red[w][0][(i * 64 + lane) * 4]) = ccs[i];
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(&red[w][0][(i * 64 + lane) * 4]) = ccs[CAST ? i : 0];
         __syncthreads();
         for (int c = threadIdx.x; c < D; c += 256)
             cast_partials[(long)blockIdx.x * D + c] = (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
     if (!partials) return;
 #pragma unroll
-    for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+    for (int i = 0; i < NV; ++i) {
         const int c0 = (i * 64 + lane) * 4;
         *reinterpret_cast<float4*>(&red[w][0][c0]) = dg[i];
         *reinterpret_cast<float4*>(&red[w][1][c0]) = db[i];
@@ -599,9 +601,20 @@ int layernorm_bwd_impl(const void* dy, int dy_bf16, float dy_scale, const float*
     long blocks = (M + 3) / 4;
     if (blocks > ws_rows) blocks = ws_rows;
     float* cast_partials = (cast_out && cast_colsum) ? workspace + (long)ws_rows * 2 * D : nullptr;   // third [ws_rows][D] region
-    DISPATCH_T(dy_bf16, hipLaunchKernelGGL(layernorm_bwd_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, stream,
-               (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out, dgamma ? workspace : nullptr, m_live, dy_scale,
-               (TT*)cast_out, cast_rowscale, cast_scale, cast_partials));
+#define LN_BWD_LAUNCH(NVv, CASTv) DISPATCH_T(dy_bf16, hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NVv, CASTv>), dim3((unsigned)blocks), \
+        dim3(256), 0, stream, (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out,                            \
+        dgamma ? workspace : nullptr, m_live, dy_scale, (TT*)cast_out, cast_rowscale, cast_scale, cast_partials))
+    switch ((D >> 8) * 2 + (cast_out ? 1 : 0)) {
+        case 2: LN_BWD_LAUNCH(1, false); break;
+        case 3: LN_BWD_LAUNCH(1, true); break;
+        case 4: LN_BWD_LAUNCH(2, false); break;
+        case 5: LN_BWD_LAUNCH(2, true); break;
+        case 6: LN_BWD_LAUNCH(3, false); break;
+        case 7: LN_BWD_LAUNCH(3, true); break;
+        case 8: LN_BWD_LAUNCH(4, false); break;
+        default: LN_BWD_LAUNCH(4, true); break;
+    }
+#undef LN_BWD_LAUNCH
     EDITOR_LAUNCH_CHECK();
     if (cast_partials) {
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((D + 63) / 64), dim3(1024), 0, stream, cast_partials, (int)blocks, (long)D,
