@@ -327,7 +327,8 @@ class PatchEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, img, conv_w, conv_b, cls, pos, sie, cam, coef, act_dtype):
-        btot = img.shape[0]
+        # img: the stacked (Btot,3,H,W) batch, or the list of per-modality (B,3,H,W) tensors (no stacking copy)
+        btot = sum(i.shape[0] for i in img) if isinstance(img, (list, tuple)) else img.shape[0]
         d = conv_w.shape[0]
         kdim = conv_w[0].numel()
         cols = ops.im2col16(img, act_dtype)
@@ -536,6 +537,28 @@ class GatherRowsFn(torch.autograd.Function):
     def backward(ctx, dy):
         (src,) = ctx.saved_tensors
         return ops.scatter_rows(dy.contiguous(), src, ctx.rows_in), None, None, None, None
+
+
+class GatherPairFn(torch.autograd.Function):
+    """The two gathers of the compacted HMA head that read the SAME packed tensor - the cls rows of every (modality, sample)
+    for OCFR, and the sample-major layout B of the joint block - as one node: backward is one zero-fill + scatter plus a
+    384-row add, where two GatherRowsFn nodes made autograd zero-fill a second (rows, D) tensor for the cls rows and add
+    the two (2 x 152 MB per step)."""
+
+    @staticmethod
+    def forward(ctx, x2d, src_cls, src_b, live, live_mul, live_stride):
+        x2d = x2d.contiguous()
+        ctx.save_for_backward(src_cls, src_b)
+        ctx.rows_in = x2d.shape[0]
+        return ops.gather_rows(x2d, src_cls), ops.gather_rows(x2d, src_b, live, live_mul, live_stride)
+
+    @staticmethod
+    def backward(ctx, dcls, dxb):
+        src_cls, src_b = ctx.saved_tensors
+        dx = ops.scatter_rows(dxb.contiguous(), src_b, ctx.rows_in)
+        if dcls is not None:
+            dx.index_add_(0, src_cls.long(), dcls.contiguous())      # (every cls row once: deterministic)
+        return dx, None, None, None, None, None
 
 
 class PoolPackedFn(torch.autograd.Function):

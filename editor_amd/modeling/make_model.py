@@ -337,13 +337,16 @@ class EDITOR(nn.Module):
 
     # -- stages ------------------------------------------------------------------------------------
     def _backbone(self, imgs, cam):
-        """Trans.forward (vit_pytorch.py:623-644) on the stacked (3B,3,H,W) batch.  Returns final-LN
-        tokens (3B,T,D) fp32 and the (L,3B,h,T,T) softmax buffer."""
+        """Trans.forward (vit_pytorch.py:623-644) on the modalities' (B,3,H,W) batches as if stacked to (3B,3,H,W) (the
+        patch embedding writes their im2col rows side by side; no stacking copy).  Returns final-LN tokens (3B,T,D) fp32
+        and the (L,3B,h,T,T) softmax buffer."""
         base = self.BACKBONE.base
-        if tuple(imgs.shape[-2:]) != base.img_size:
-            raise AssertionError(f"Input image size ({imgs.shape[-2]}*{imgs.shape[-1]}) doesn't match model "
-                                 f"({base.img_size[0]}*{base.img_size[1]}).")
-        btot = imgs.shape[0]
+        dev = imgs[0].device
+        for im in imgs:
+            if tuple(im.shape[-2:]) != base.img_size:
+                raise AssertionError(f"Input image size ({im.shape[-2]}*{im.shape[-1]}) doesn't match model "
+                                     f"({base.img_size[0]}*{base.img_size[1]}).")
+        btot = sum(im.shape[0] for im in imgs)
         t = base.num_patches + 1
         sie = base.sie_embed if base.cam_num > 1 else None
         x = fn.PatchEmbedFn.apply(imgs, base.patch_embed.proj.weight, base.patch_embed.proj.bias, base.cls_token,
@@ -356,14 +359,14 @@ class EDITOR(nn.Module):
         recompute = self.act_dtype != torch.float32 and not self.rollout_probs
         ldp = t if self.act_dtype == torch.float32 else (t + 3) // 4 * 4
         probs = [] if recompute else torch.empty(base.depth, btot, base.heads, t, ldp, dtype=torch.float32,
-                                                 device=imgs.device)
+                                                 device=dev)
         scales = None
         if self.training and max(base.drop_rates) > 0.0:                       # vit_pytorch.py:52-69: one launch for all
-            if self._drop_rates_dev is None or self._drop_rates_dev.device != imgs.device:
-                self._drop_rates_dev = torch.tensor(base.drop_rates, dtype=torch.float32, device=imgs.device)
-            if self._drop_state is None or self._drop_state.device != imgs.device:      # device-resident RNG counter
+            if self._drop_rates_dev is None or self._drop_rates_dev.device != dev:
+                self._drop_rates_dev = torch.tensor(base.drop_rates, dtype=torch.float32, device=dev)
+            if self._drop_state is None or self._drop_state.device != dev:      # device-resident RNG counter
                 seed0 = (int(torch.initial_seed()) * 1000003) & 0x3FFFFFFFFFFFFFFF
-                self._drop_state = torch.full((1,), seed0, dtype=torch.int64, device=imgs.device)
+                self._drop_state = torch.full((1,), seed0, dtype=torch.int64, device=dev)
             scales = ops.droppath_scales_dev(self._drop_rates_dev, btot, t, self._drop_state)
         for i, blk in enumerate(base.blocks):
             rs_a = rs_m = None
@@ -441,9 +444,10 @@ class EDITOR(nn.Module):
         xa = torch.cat(mods, dim=0)
         loss_ocfr = None
         if self.training:
-            cls = fn.GatherRowsFn.apply(xa, plan.map_cls).view(nmod, b, d)
-            loss_ocfr = self._ocfr(list(cls.unbind(0)), label)
-        xb = fn.GatherRowsFn.apply(xa, plan.map_b, plan.live_a, nmod, plan.mb)             # layout B (MB, D)
+            cls, xb = fn.GatherPairFn.apply(xa, plan.map_cls, plan.map_b, plan.live_a, nmod, plan.mb)   # cls rows; layout B (MB, D)
+            loss_ocfr = self._ocfr(list(cls.view(nmod, b, d).unbind(0)), label)
+        else:
+            xb = fn.GatherRowsFn.apply(xa, plan.map_b, plan.live_a, nmod, plan.mb)
         xb = fn.TransformerBlockFn.apply(xb, *_block_args(fb.norm1, fb.attn1, fb.norm2, fb.mlp), plan.mask_b, None,
                                          self.hma_heads, 1e-5, self.act_dtype, None, None, plan.cu3, nmod * t, plan.live_b,
                                          None, self._sink("hma.joint"))
@@ -476,8 +480,7 @@ class EDITOR(nn.Module):
         with torch.no_grad(), torch.cuda.stream(side):
             mask_fre, _ = ops.frequency_mask(mods[0], mods[1], mods[2], self.FREQ_INDEX.keep, mods[3] if nmod > 3 else None)
             fre_done = side.record_event()
-        imgs = torch.cat(mods, dim=0)
-        feats, probs = self._backbone(imgs, cam_label)
+        feats, probs = self._backbone(mods, cam_label)
         t = feats.shape[1]
         cur.wait_event(fre_done)
         with torch.no_grad():

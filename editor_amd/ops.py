@@ -226,9 +226,16 @@ def cast_rows_colsum(x2d, rowscale, dtype, scale=1.0, cs_out=None):
 
 
 def im2col16(img, dtype):
-    b, c, h, w = img.shape
-    out = torch.empty(b * (h // 16) * (w // 16), c * 256, dtype=dtype, device=img.device)
-    call("editor_im2col16", img, b, c, h, w, out, _is_bf16(out))
+    """img: (B,C,H,W) fp32, or a list of such tensors (the modalities) laid out as if stacked on the batch axis - without
+    the 151 MB `torch.cat` that stacking them costs per step."""
+    imgs = list(img) if isinstance(img, (list, tuple)) else [img]
+    b, c, h, w = imgs[0].shape
+    rows = b * (h // 16) * (w // 16)
+    out = torch.empty(len(imgs) * rows, c * 256, dtype=dtype, device=imgs[0].device)
+    for i, im in enumerate(imgs):
+        if tuple(im.shape) != (b, c, h, w):
+            raise ValueError("im2col16: modality tensors of different shapes")
+        call("editor_im2col16", im, b, c, h, w, _ptr(out, i * rows * c * 256), _is_bf16(out))
     return out
 
 
