@@ -389,8 +389,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                         *reinterpret_cast<float4*>(pr + 16 * t + 4 * lg) = make_float4(pv[0], pv[1], pv[2], pv[3]);
                     pk[half] = pack4<F16>(pv[0], pv[1], pv[2], pv[3]);
                 } else {
-                    pk[half] = pack4<F16>(pv[0] * (dp[0] - dl) * a.scale, pv[1] * (dp[1] - dl) * a.scale,
-                                     pv[2] * (dp[2] - dl) * a.scale, pv[3] * (dp[3] - dl) * a.scale);
+                    // (the score scale is applied to the finished dQ tile, 16 multiplies per lane instead of 4 per key tile; for
+                    // the power-of-two scales of 64-wide heads the result is bit-identical: rounding commutes with it)
+                    pk[half] = pack4<F16>(pv[0] * (dp[0] - dl), pv[1] * (dp[1] - dl), pv[2] * (dp[2] - dl), pv[3] * (dp[3] - dl));
                 }
             }
             const short8_t pf = join(pk[0], pk[1]);
@@ -414,8 +415,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             for (int s2 = 0; s2 + 1 < npair; ++s2) pair(s2, std::false_type{});
             if (npair > 0) pair(npair - 1, std::true_type{});
         }
-        if (BWD) store_tile<F16>(stg, o, a.dqkv + (row0 + q0) * ld + hh * HD, ld, T - q0, lane);
-        else store_tile<F16>(stg, o, a.out + (row0 + q0) * D + hh * HD, D, T - q0, lane);
+        if (BWD) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] *= a.scale;
+            store_tile<F16>(stg, o, a.dqkv + (row0 + q0) * ld + hh * HD, ld, T - q0, lane);
+        } else {
+            store_tile<F16>(stg, o, a.out + (row0 + q0) * D + hh * HD, D, T - q0, lane);
+        }
     }
 }
 
@@ -495,9 +501,11 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
                 float pv[4], dsv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pp = __builtin_amdgcn_exp2f(kok ? s_[r] * sc - lq[r] : -INFINITY);   // lse == +inf -> 0
+                    // FULL (dense, unmasked): a key beyond the sequence end needs no select - its dK / dV rows are never
+                    // stored and its K / V fragments are zeros (finite scores).  The score scale goes onto the finished dK tile.
+                    const float pp = __builtin_amdgcn_exp2f((FULL || kok) ? s_[r] * sc - lq[r] : -INFINITY);   // lse == +inf -> 0
                     pv[r] = pp;
-                    dsv[r] = pp * (dp[r] - dq[r]) * a.scale;
+                    dsv[r] = pp * (dp[r] - dq[r]);
                 }
                 pk[half] = pack4<F16>(pv[0], pv[1], pv[2], pv[3]);
                 dsk[half] = pack4<F16>(dsv[0], dsv[1], dsv[2], dsv[3]);
@@ -535,6 +543,8 @@ __global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
         {
             char* stg = a.stage_out ? smem + 2 * Tp * ROWB + 2 * Tp * sizeof(float) + w * STG_BYTES : nullptr;
             bf16_t* kdst = a.dqkv + (row0 + k0) * ld + D + hh * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dk[dt] *= a.scale;
             store_tile<F16>(stg, dk, kdst, ld, T - k0, lane);
             store_tile<F16>(stg, dv, kdst + D, ld, T - k0, lane);
         }
