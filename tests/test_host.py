@@ -87,3 +87,25 @@ def test_drop_path_rates_match_reference():
     rates = m.BACKBONE.base.drop_rates                   # vit_pytorch.py:511 linspace(0, 0.1, 12)
     assert rates[0] == 0 and abs(rates[-1] - 0.1) < 1e-7 and len(rates) == 12
     assert m.head_k == 2 and m.FREQ_INDEX.keep == 10
+
+
+def test_gemm_launch_plans_for_the_path_shapes():
+    """Host-side launch planning of the 16-bit GEMM family (no GPU involved): tile height of the forward / dgrad products and
+    split count + kernel of the weight gradients, on the shapes the bench workload runs (M = 3 * 128 * 129 token rows)."""
+    from editor_amd import ops
+    from editor_amd.functional import _splitk_for
+    m = 3 * 128 * 129
+    # 768-wide outputs: 582 full tiles = 2.27 rounds of 256 CUs -> 208-row tiles (717 tiles, still three rounds)
+    assert ops.gemm_tile_rows(m, 768) == 208
+    assert -(-m // 208) * 3 <= 3 * 256 and -(-m // 256) * 3 > 2 * 256
+    # 2304- / 3072-wide: a shorter tile would add a round (or save none): full tiles
+    assert ops.gemm_tile_rows(m, 2304) == 256 and ops.gemm_tile_rows(m, 3072) == 256
+    assert ops.EPI_TILE_ROWS(208) == 13 << 12 and ops.EPI_TILE_ROWS(256) == 0
+    # weight gradients: one round of 256x256 tiles x splits on the ping-pong kernel
+    for (n, k), sk in {(2304, 768): 9, (768, 768): 28, (3072, 768): 7, (768, 3072): 7}.items():
+        got, flags = _splitk_for(n, k, m)
+        assert (got, flags) == (sk, ops.EPI_FORCE_PP)
+        assert (n // 256) * (k // 256) * got <= 256
+    # outputs that do not tile into 256 x 256 keep the three-stage kernel and its cost model
+    got, flags = _splitk_for(768, 200, m)
+    assert flags == 0 and got >= 1
