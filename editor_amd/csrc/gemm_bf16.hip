@@ -91,6 +91,15 @@ __device__ __forceinline__ v2f_t gelu_grad2(v2f_t a)
     v2f_t e; e.x = __builtin_amdgcn_exp2f(q.x); e.y = __builtin_amdgcn_exp2f(q.y);
     return __builtin_elementwise_fma(a * 0.3989422804014327f, e, phi2(a));
 }
+// GELU lookup for bf16 pre-activations (fc1's forward epilogue, ping-pong kernel).  The epilogue evaluates gelu and gelu' on
+// values that have ALREADY been rounded to bf16 - 16 bits of input - and was VALU-bound on it (~33 instructions + 4
+// transcendentals per pair of elements, ~20 k cycles per 256x256 tile against 29 k for the K = 768 main loop).  A table over
+// the bf16 values with 2^-12 <= |x| < 16 (16 exponents x 128 mantissas x 2 signs = 4 096 entries of {gelu, gelu'} packed in 32
+// bits, 16 KiB of LDS) is filled per tile BY THE SAME FUNCTIONS (8 entries per thread), so a lookup returns exactly the bits
+// the arithmetic would; the rare chunk holding a value outside that range takes the arithmetic path.
+constexpr uint32_t kLutBase = 115u << 7, kLutSpan = 2048u, kLutBytes = 2 * kLutSpan * 4;   // bf16 exponent field 115 = 2^-12
+__device__ __forceinline__ uint32_t gelu_lut_bits(uint32_t j) { return ((j & (kLutSpan - 1)) + kLutBase) | ((j >> 11) << 15); }
+
 __device__ __forceinline__ float gelu_f(float a) { return gelu2(v2f_t{a, a}).x; }
 __device__ __forceinline__ float gelu_grad_f(float a) { return gelu_grad2(v2f_t{a, a}).x; }
 
@@ -1053,11 +1062,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
                 }
             }
         }
+        const bool gelu = g.epilogue == EDITOR_EPI_GELU;
+        uint32_t* lut = reinterpret_cast<uint32_t*>(smem + 256 * RB);          // behind the staged image
+        const bool use_lut = !F16 && gelu;
+        if (use_lut) {
+#pragma unroll 1
+            for (uint32_t j = threadIdx.x * 2; j < 2 * kLutSpan; j += 1024) {
+                const v2f_t x = H16<false>::unpack2(gelu_lut_bits(j) | (gelu_lut_bits(j + 1) << 16));
+                const v2f_t gv = gelu2(x), dv = gelu_grad2(x);
+                lut[j] = H16<false>::pack2(gv.x, dv.x);
+                lut[j + 1] = H16<false>::pack2(gv.y, dv.y);
+            }
+        }
         PP_EBAR();
         PP_STAMP(3);
         bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
         bf16_t* Ab = reinterpret_cast<bf16_t*>(g.aux);
-        const bool gelu = g.epilogue == EDITOR_EPI_GELU;
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of this thread's 8 columns (same for all its rows)
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
@@ -1066,7 +1086,31 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
             const int m = m0 + row, n = n0 + cg * 8;
             uint4 p = *reinterpret_cast<const uint4*>(smem + row * RB + cg * 16);
             if (row >= TH || m >= g.M || n >= g.N) continue;
-            if (gelu) {
+            bool looked_up = false;
+            if (use_lut) {
+                const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+                uint32_t ent[8], bad = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t lo = pw[e] & 0xFFFFu, hi = pw[e] >> 16;
+                    const uint32_t i0 = (lo & 0x7FFFu) - kLutBase, i1 = (hi & 0x7FFFu) - kLutBase;
+                    bad |= (uint32_t)(i0 >= kLutSpan) | (uint32_t)(i1 >= kLutSpan);
+                    ent[2 * e] = lut[(i0 & (kLutSpan - 1)) + ((lo >> 15) << 11)];
+                    ent[2 * e + 1] = lut[(i1 & (kLutSpan - 1)) + ((hi >> 15) << 11)];
+                }
+                if (__builtin_amdgcn_ballot_w64(bad != 0u) == 0ull) {       // (wave-uniform; ~1 chunk in 10 goes the long way)
+                    uint32_t gw[4], dw_[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        gw[e] = __builtin_amdgcn_perm(ent[2 * e + 1], ent[2 * e], 0x05040100u);     // {gelu(lo), gelu(hi)}
+                        dw_[e] = __builtin_amdgcn_perm(ent[2 * e + 1], ent[2 * e], 0x07060302u);    // {gelu'(lo), gelu'(hi)}
+                    }
+                    *reinterpret_cast<uint4*>(Ab + (long)m * g.ldaux + n) = g.aux_grad ? make_uint4(dw_[0], dw_[1], dw_[2], dw_[3]) : p;
+                    p = make_uint4(gw[0], gw[1], gw[2], gw[3]);
+                    looked_up = true;
+                }
+            }
+            if (gelu && !looked_up) {
                 uint32_t pw[4] = {p.x, p.y, p.z, p.w};
                 if (g.aux_grad) {        // the backward only needs gelu'(pre-activation): save THAT (one multiply there instead of
                     uint32_t dw_[4];     // an erfc + exponential per element in the dgrad epilogue)
@@ -1208,7 +1252,7 @@ int launch_pipe_t(GemmB16Args g, hipStream_t stream)
 template <bool F16, bool AK, bool BK_, bool CF, int F0, int F1>
 int launch_pp_t(GemmB16Args g, hipStream_t stream)
 {
-    constexpr int LDS = 256 * (256 * 2 + 16);                   // >= 2 K-tile buffers, the fp32 half-tile image and the bf16 tile image
+    constexpr int LDS = 256 * (256 * 2 + 16) + (int)kLutBytes;  // >= 2 K-tile buffers, the fp32 half-tile image, the bf16 tile image + GELU table
     auto kern = gemm_bf16_pp_kernel<F16, AK, BK_, CF, F0, F1>;
     static bool attr_done = false;
     if (!attr_done) {

@@ -70,7 +70,9 @@ def main():
             t = bench(lambda: ops.gemm(x, w, y, m, n, k, k, k, n, 0, 0, bias=bias), iters)
             rows.append(("fwd+bias", n, k, fl / t / 1e9))
             pre = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
-            t = bench(lambda: ops.gemm(x, w, y, m, n, k, k, k, n, 0, 0, bias=bias, epilogue=ops.EPI_GELU, aux=pre), iters)
+            # as the step runs it: the forward saves gelu'(pre-activation) for the backward
+            t = bench(lambda: ops.gemm(x, w, y, m, n, k, k, k, n, 0, 0, bias=bias, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD,
+                                       aux=pre), iters)
             rows.append(("fwd+gelu", n, k, fl / t / 1e9))
             res = torch.randn(m, n, device=dev, generator=g)
             yf = torch.empty(m, n, device=dev)
