@@ -474,7 +474,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmB16Args& g, float4_t (
 }
 
 // =====================================================================================================
-// Pipelined large-tile variant (the performance path).  A 128x128 tile moves 64 FLOP per byte staged into LDS and is
+// Pipelined large-tile variant (round 1's performance path; since round 2 the ping-pong kernel below takes every large
+// product - forward, dgrad and, with a one-round split, wgrad - and this one the shapes it does not).  A 128x128 tile moves 64 FLOP per byte staged into LDS and is
 // bound by L2->CU bandwidth at ~25 % of the MFMA peak (measured: 49 % of wave cycles in s_waitcnt/barrier, 0 LDS bank
 // conflicts); this kernel uses 256 x BN tiles, BN = 256 (128 FLOP/B) or 128 (85 FLOP/B, for N = 768 problems whose
 // 256-wide tiling would leave the last wave of workgroups a quarter full):

@@ -103,9 +103,9 @@ def _linear_fwd(x2d, w_act, bias, out_dtype, m_live=None):
 
 
 # Weight-gradient products run on a SIDE stream, concurrently with whatever the main stream does next (the dgrad of the
-# same layer, LayerNorm / attention backward): a dgrad into a 768-wide output is 582 tiles = 2.27 rounds of the 256 CUs
-# and a wgrad is one long round of 216-252 workgroups, so each leaves CUs idle that the other's workgroups take
-# (measured: see DESIGN.md 4.2).  Discipline: outputs are allocated on the main stream; the side stream waits for an
+# same layer, LayerNorm / attention backward): a dgrad's last round of tiles and a wgrad's single round of 243-252
+# workgroups each leave CUs idle that the other's workgroups take.  Measured: 0.6 ms per step - a 256x256
+# tile's workgroup owns its CU, so the two streams take turns on CUs rather than share them.  Discipline: outputs are allocated on the main stream; the side stream waits for an
 # event recorded after the producer of dy; the backward function joins (main waits side) before it returns.
 _SIDE = {}
 _SIDE_KEEP = []
