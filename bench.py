@@ -75,10 +75,25 @@ class _GemmProbe:
                 probe.calls.append([kind, (m, n, k, kw.get("m_live"), bool(ta)), (a, b, c, m, n, k) + args, dict(kw)])
             return probe._orig(a, b, c, m, n, k, *args, **kw)
         ops.gemm = recorded
+        # split-precision forward products ('f16x2'): algorithmic FLOPs 2 m n k (the three MFMA passes are the price of
+        # fp32-class products on the half matrix cores, not extra algorithmic work)
+        self._orig_split = ops.gemm_split
+
+        def recorded_split(a, b, c, c_lo, m, n, k, **kw):
+            if probe.recording:
+                probe.calls.append(["fwd", (m, n, k, kw.get("m_live"), False), ("split", a, b, c, c_lo, m, n, k), dict(kw)])
+            return probe._orig_split(a, b, c, c_lo, m, n, k, **kw)
+        ops.gemm_split = recorded_split
 
     def remove(self):
         from editor_amd import ops
         ops.gemm = self._orig
+        ops.gemm_split = self._orig_split
+
+    def _run(self, args, kw):
+        if args and isinstance(args[0], str):
+            return self._orig_split(*args[1:], **kw)
+        return self._orig(*args, **kw)
 
     def replay(self, reps=3):
         by_kind = {}
@@ -96,12 +111,12 @@ class _GemmProbe:
             if not calls:
                 continue
             for _, _, args, kw in calls:                   # warm
-                self._orig(*args, **kw)
+                self._run(args, kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
                 for _, _, args, kw in calls:
-                    self._orig(*args, **kw)
+                    self._run(args, kw)
             e1.record()
             torch.cuda.synchronize()
             by_kind[kind] = (sum(c[1] for c in calls), e0.elapsed_time(e1) / reps, len(calls))
@@ -239,7 +254,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (BASELINE: 128; SYNTH4L default 32)")
     ap.add_argument("--preset", default="RGBNT201")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f16x2", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--graph", action="store_true", help="time a hipGraph replay of the captured step in THIS process")

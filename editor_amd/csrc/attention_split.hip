@@ -1,0 +1,239 @@
+// Split-precision attention forward (COMPUTE_DTYPE 'f16x2'), gfx950 / CDNA4.
+// Restates Attention.forward (vit_pytorch.py:184-198) and AttentionMask.forward (:240-258) at fp32-class accuracy on the
+// HALF matrix cores: q, k, v arrive as pairs x = hi + lo of IEEE-half matrices (the qkv product's split output) and every
+// contraction is three v_mfma_f32_16x16x32_f16 into one fp32 accumulator,
+//     S   = Q_lo K_hi^T + Q_hi K_lo^T + Q_hi K_hi^T                       (lo.lo, 2^-22 relative, dropped)
+//     O   = (P_hi V_lo + P_lo V_hi + P_hi V_hi) 2^-12,   P' = 2^12 softmax(S scale) = P_hi + P_lo
+// (the probabilities are scaled by 2^12 before they are split so that the low-order half of a 1/T-sized probability stays
+// in half's normal range; the power of two is divided out of the finished fp32 tile).  The softmax itself is the
+// reference's fp32 formula exp(s - max) / sum.  Outputs: the attention output as a half pair again (operand of the proj
+// product), the row log-sum-exp for the 16-bit backward (editor_attention_bwd_f16 on the hi halves), and - for the backbone -
+// the fp32 probabilities the rollout consumes (vit_pytorch.py:638-644, SFTS.py:145-153).
+//
+// One workgroup per (sample, head) with the K and V pairs of the whole sequence in LDS (4 images; T <= 288), each wave
+// sweeping 16-query tiles; longer sequences (joint HMA block) run 64 queries per workgroup and stream the keys through LDS
+// in 128-row chunks, twice (row statistics, then P V) - the structure of attn_q_long_kernel.
+#include "common.h"
+#include "../../include/editor_hip.h"
+#include "attn_common.h"
+
+namespace {
+
+struct SplitAttnArgs {
+    const bf16_t* qkv_hi; const bf16_t* qkv_lo;
+    bf16_t* out_hi; bf16_t* out_lo; float* probs; float* lse;
+    const uint8_t* mask;
+    int T, heads; float scale;
+    int ldp;
+    const int* cu; long Mtot;
+    int cap;                              // rows per LDS image (whole form: the padded sequence; chunked form: the chunk)
+};
+
+constexpr int SCH = 128;                  // key chunk of the streamed form
+constexpr float kPScale = 4096.f;         // 2^12
+
+template <bool MULTI>
+__global__ __launch_bounds__(256) void attn_fwd_split_kernel(SplitAttnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int cap = a.cap;
+    char* khi = smem;
+    char* klo = smem + cap * ROWB;
+    char* vhi = smem + 2 * cap * ROWB;
+    char* vlo = smem + 3 * cap * ROWB;
+    const int D = a.heads * HD;
+    const int b = blockIdx.x / a.heads, hh = blockIdx.x % a.heads;
+    const long ld = 3L * D;
+    const long row0 = a.cu ? (long)a.cu[b] : (long)b * a.T;
+    const int T = a.cu ? a.cu[b + 1] - a.cu[b] : a.T;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const bf16_t* qh = a.qkv_hi + row0 * ld + hh * HD;
+    const bf16_t* ql = a.qkv_lo + row0 * ld + hh * HD;
+    const uint8_t* mk = a.mask ? a.mask + (long)b * T : nullptr;     // dense-masked form only (packed rows are all live)
+    const float sc = a.scale * kLog2e;
+    const long row_idx0 = (long)hh * a.Mtot + row0;
+    const long prow0 = ((long)b * a.heads + hh) * a.T;
+
+    // S^T tile (keys 16t .. 16t+15 of the resident images x this wave's 16 queries): lane (i, g) gets keys 16t + 4g + r
+    auto scores = [&](int t, const short8_t (&qfh)[2], const short8_t (&qfl)[2]) {
+        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const short8_t kh = frag_k(khi, t * 16, s, lane), kl = frag_k(klo, t * 16, s, lane);
+            acc = mfma16<true>(kl, qfh[s], acc);
+            acc = mfma16<true>(kh, qfl[s], acc);
+            acc = mfma16<true>(kh, qfh[s], acc);
+        }
+        return acc;
+    };
+    auto key_ok = [&](int key) { return key < T && (!mk || mk[key]); };
+
+    // sweep 1 over the resident keys [c0, c0 + 16 ntc): running max / sum of this lane's keys
+    auto sweep1 = [&](int c0, int ntc, const short8_t (&qfh)[2], const short8_t (&qfl)[2], float& m, float& l) {
+#pragma unroll 2
+        for (int t = 0; t < ntc; ++t) {
+            const float4_t acc = scores(t, qfh, qfl);
+            float sv[4], tm = -INFINITY;
+            const int key0 = c0 + 16 * t + 4 * lg;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sv[r] = key_ok(key0 + r) ? acc[r] * sc : -INFINITY;
+                tm = fmaxf(tm, sv[r]);
+            }
+            if (tm > m) { l *= __builtin_amdgcn_exp2f(m - tm); m = tm; }
+            if (m > -INFINITY)
+                l += (__builtin_amdgcn_exp2f(sv[0] - m) + __builtin_amdgcn_exp2f(sv[1] - m)) +
+                     (__builtin_amdgcn_exp2f(sv[2] - m) + __builtin_amdgcn_exp2f(sv[3] - m));
+        }
+    };
+    // sweep 2: P = exp2(s - M) / L for the resident keys; O'^T += V^T P'^T with P' = 2^12 P as a half pair
+    auto sweep2 = [&](int c0, int ntc, const short8_t (&qfh)[2], const short8_t (&qfl)[2], float Ms, float inv, float* pr,
+                      float4_t (&o)[4]) {
+        const float invs = inv * kPScale;
+#pragma unroll 1
+        for (int s2 = 0; s2 < ntc / 2; ++s2) {
+            uint2 ph[2], pl[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int t = 2 * s2 + half;
+                const float4_t acc = scores(t, qfh, qfl);
+                const int key0 = c0 + 16 * t + 4 * lg;
+                float e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(key_ok(key0 + r) ? acc[r] * sc - Ms : -INFINITY);
+                if (pr && key0 < a.ldp) *reinterpret_cast<float4*>(pr + key0) = make_float4(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv);
+                const float p0 = e[0] * invs, p1 = e[1] * invs, p2 = e[2] * invs, p3 = e[3] * invs;
+                ph[half] = pack4<true>(p0, p1, p2, p3);
+                const float2_t_ h0 = H16<true>::unpack2(ph[half].x), h1 = H16<true>::unpack2(ph[half].y);
+                pl[half] = pack4<true>(p0 - h0.x, p1 - h0.y, p2 - h1.x, p3 - h1.y);
+            }
+            const short8_t pfh = join(ph[0], ph[1]), pfl = join(pl[0], pl[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const short8_t vh = frag_t(vhi, s2, dt, lane), vl = frag_t(vlo, s2, dt, lane);
+                o[dt] = mfma16<true>(vl, pfh, o[dt]);
+                o[dt] = mfma16<true>(vh, pfl, o[dt]);
+                o[dt] = mfma16<true>(vh, pfh, o[dt]);
+            }
+        }
+    };
+    auto finish_stats = [&](float m, float l, bool qok, int q, float& Ms, float& inv) {
+        const float M = group_max(m);
+        const float L = group_sum(m > -INFINITY ? l * __builtin_amdgcn_exp2f(m - M) : 0.f);
+        const bool live = qok && L > 0.f;
+        Ms = M > -INFINITY ? M : 0.f;
+        inv = live ? 1.f / L : 0.f;
+        if (a.lse && lg == 0 && q < T) a.lse[row_idx0 + q] = live ? M + __builtin_amdgcn_logf(L) : INFINITY;
+    };
+    auto store_out = [&](int q0, float4_t (&o)[4]) {
+        if (q0 + li >= T) return;
+        const long off = (row0 + q0 + li) * D + hh * HD + 4 * lg;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const float v0 = o[dt][0] * (1.f / kPScale), v1 = o[dt][1] * (1.f / kPScale), v2 = o[dt][2] * (1.f / kPScale),
+                        v3 = o[dt][3] * (1.f / kPScale);
+            const uint2 h = pack4<true>(v0, v1, v2, v3);
+            const float2_t_ h0 = H16<true>::unpack2(h.x), h1 = H16<true>::unpack2(h.y);
+            *reinterpret_cast<uint2*>(a.out_hi + off + dt * 16) = h;
+            *reinterpret_cast<uint2*>(a.out_lo + off + dt * 16) = pack4<true>(v0 - h0.x, v1 - h0.y, v2 - h1.x, v3 - h1.y);
+        }
+    };
+
+    if constexpr (!MULTI) {
+        const int nt = ((T + 31) >> 5) << 1;                         // populated key tiles (even count), nt * 16 <= cap
+        load_image(khi, qh + D, ld, T, nt * 16);
+        load_image(klo, ql + D, ld, T, nt * 16);
+        load_image(vhi, qh + 2 * D, ld, T, nt * 16);
+        load_image(vlo, ql + 2 * D, ld, T, nt * 16);
+        images_ready();
+        for (int q0 = w * 16; q0 < T; q0 += nw * 16) {
+            const int q = q0 + li;
+            const bool qok = q < T && (!mk || mk[q]);
+            short8_t qfh[2], qfl[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { qfh[s] = frag_own(qh, ld, q0, T, s, lane); qfl[s] = frag_own(ql, ld, q0, T, s, lane); }
+            float m = -INFINITY, l = 0.f, Ms, inv;
+            sweep1(0, nt, qfh, qfl, m, l);
+            finish_stats(m, l, qok, q, Ms, inv);
+            float* pr = (a.probs && q < T) ? a.probs + (prow0 + q) * a.ldp : nullptr;
+            float4_t o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+            sweep2(0, nt, qfh, qfl, Ms, inv, pr, o);
+            store_out(q0, o);
+        }
+    } else {
+        const int qb0 = blockIdx.y * 64;
+        if (qb0 >= T) return;                                         // (whole workgroup: before any barrier)
+        const int q0 = qb0 + w * 16, q = q0 + li;
+        const bool active = q0 < T;                                   // (wave-uniform; idle waves still load and synchronise)
+        const bool qok = q < T && (!mk || mk[q]);
+        short8_t qfh[2], qfl[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { qfh[s] = frag_own(qh, ld, q0, T, s, lane); qfl[s] = frag_own(ql, ld, q0, T, s, lane); }
+        float m = -INFINITY, l = 0.f, Ms = 0.f, inv = 0.f;
+        for (int c0 = 0; c0 < T; c0 += SCH) {
+            const int len = min(SCH, T - c0), ntc = ((len + 31) >> 5) << 1;
+            __syncthreads();
+            load_image(khi, qh + D + (long)c0 * ld, ld, len, ntc * 16);
+            load_image(klo, ql + D + (long)c0 * ld, ld, len, ntc * 16);
+            images_ready();
+            if (active) sweep1(c0, ntc, qfh, qfl, m, l);
+        }
+        if (active) finish_stats(m, l, qok, q, Ms, inv);
+        float* pr = (a.probs && q < T) ? a.probs + (prow0 + q) * a.ldp : nullptr;
+        float4_t o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < T; c0 += SCH) {
+            const int len = min(SCH, T - c0), ntc = ((len + 31) >> 5) << 1;
+            __syncthreads();
+            load_image(khi, qh + D + (long)c0 * ld, ld, len, ntc * 16);
+            load_image(klo, ql + D + (long)c0 * ld, ld, len, ntc * 16);
+            load_image(vhi, qh + 2 * D + (long)c0 * ld, ld, len, ntc * 16);
+            load_image(vlo, ql + 2 * D + (long)c0 * ld, ld, len, ntc * 16);
+            images_ready();
+            if (active) sweep2(c0, ntc, qfh, qfl, Ms, inv, pr, o);
+        }
+        if (active) store_out(q0, o);
+    }
+}
+
+template <auto KERN>
+int set_lds_dev(size_t bytes)
+{
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int editor_attention_fwd_f16x2(const uint16_t* qkv_hi, const uint16_t* qkv_lo, int B, int T, int heads, int hd,
+    float scale, const uint8_t* mask, uint16_t* out_hi, uint16_t* out_lo, float* probs, int ldp, float* lse, const int* cu,
+    long Mtot, hipStream_t stream)
+{
+    if (hd != HD || T < 1 || B < 1 || !qkv_hi || !qkv_lo || !out_hi || !out_lo) return (int)hipErrorInvalidValue;
+    if (probs && (ldp < T || (ldp & 3) || (reinterpret_cast<uintptr_t>(probs) & 15) || cu)) return (int)hipErrorInvalidValue;
+    if (cu && mask) return (int)hipErrorInvalidValue;
+    if (!cu) Mtot = (long)B * T;
+    const int rows = (((T + 31) >> 5) << 1) * 16;
+    SplitAttnArgs a{qkv_hi, qkv_lo, out_hi, out_lo, probs, lse, mask, T, heads, scale, ldp, cu, Mtot, rows};
+    if (rows <= 288) {
+        const size_t lds = (size_t)4 * rows * ROWB;
+        const int tiles = (T + 15) / 16;
+        const int threads = (tiles % 3 == 0) ? 192 : 256;
+        if (int rc = set_lds_dev<attn_fwd_split_kernel<false>>(lds)) return rc;
+        hipLaunchKernelGGL(attn_fwd_split_kernel<false>, dim3(B * heads), dim3(threads), lds, stream, a);
+    } else {
+        a.cap = SCH;
+        const size_t lds = (size_t)4 * SCH * ROWB;
+        if (int rc = set_lds_dev<attn_fwd_split_kernel<true>>(lds)) return rc;
+        hipLaunchKernelGGL(attn_fwd_split_kernel<true>, dim3(B * heads, (T + 63) / 64), dim3(256), lds, stream, a);
+    }
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}

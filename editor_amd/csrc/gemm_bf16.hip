@@ -60,7 +60,36 @@ struct GemmB16Args {
     int force_pp;                            // EDITOR_EPI_FORCE_PP: the 256x256 kernel whatever the heuristic says
     int aux_grad;                            // EDITOR_EPI_AUX_GRAD: aux holds gelu'(pre-activation), not the pre-activation
     int tile_frags;                          // EDITOR_EPI_TILE_ROWS: 16-row fragments per tile of the ping-pong kernel (13; 0 = 16)
+    // split-precision forward (editor_gemm_f16x2): every operand is a PAIR of half matrices x = hi + lo of the same shape and
+    // leading dimension; the product is hi.hi + lo.hi + hi.lo in one fp32 accumulator (three passes over K)
+    const bf16_t* A_lo; const bf16_t* B_lo;
+    void* C_lo;                              // 16-bit outputs leave as a pair too (C = hi, C_lo = lo); NULL for fp32 outputs
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: remember it per device index, so a
+// second GPU in the same process (cuda:1 tensors) does not launch > 64 KiB kernels without it
+template <auto KERN>
+int ensure_lds(int bytes)
+{
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        e = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+    return 0;
+}
+
+// exact-erf GELU in fp32 (split-precision forward: the activation is evaluated on the UNROUNDED pre-activation, as
+// nn.GELU does on the reference's fp32 CPU path, vit_pytorch.py:139-145)
+__device__ __forceinline__ float gelu_exact(float a) { return 0.5f * a * (1.f + erff(a * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_exact(float a)
+{
+    return 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.3989422804014327f * __expf(-0.5f * a * a);
+}
 
 // exact-erf GELU (nn.GELU default) for bf16 outputs, two values per instruction (v_pk_fma_f32 / v_pk_mul_f32):
 // Phi(a) = 0.5 erfc(-a/sqrt2) with erfc(z) ~ (1 + a1 z + ... + a6 z^6)^-16 for z >= 0 (Abramowitz-Stegun 7.1.28,
@@ -357,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB16Args g)
 // the 16 lanes of a tile row covering 256 / 512 contiguous bytes.  Keeping the math in a rolled loop matters: the fully
 // unrolled per-fragment epilogue is ~10k straight-line instructions executed once per tile, i.e. always instruction-cache
 // cold (measured: ~5.5 us per tile even with the global stores removed).
-template <bool F16, bool C_F32, int EPI, int PBM, int PBN, int NTHREADS>
+template <bool F16, bool C_F32, int EPI, int PBM, int PBN, int NTHREADS, bool SPLIT = false>
 __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const char* lds, int m0, int n0, int split, int mlim)
 {
     constexpr int RBP = PBN * 4 + 16;
@@ -413,6 +442,13 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
             if (EPI == EDITOR_EPI_RESIDUAL) {
                 const float4 r0 = ra[it], r1 = rb[it];
                 x[0] += r0.x; x[1] += r0.y; x[2] += r0.z; x[3] += r0.w; x[4] += r1.x; x[5] += r1.y; x[6] += r1.z; x[7] += r1.w;
+            } else if (EPI == EDITOR_EPI_GELU && SPLIT) {        // aux <- gelu'(x) (half, for the 16-bit backward), C <- gelu(x) in fp32
+                uint4 p;
+                p.x = H16<F16>::pack2(gelu_grad_exact(x[0]), gelu_grad_exact(x[1])); p.y = H16<F16>::pack2(gelu_grad_exact(x[2]), gelu_grad_exact(x[3]));
+                p.z = H16<F16>::pack2(gelu_grad_exact(x[4]), gelu_grad_exact(x[5])); p.w = H16<F16>::pack2(gelu_grad_exact(x[6]), gelu_grad_exact(x[7]));
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = gelu_exact(x[e]);
             } else if (EPI == EDITOR_EPI_GELU) {                 // aux <- pre-activation (bf16), C <- gelu(rounded pre-activation)
                 uint4 p;
                 p.x = H16<F16>::pack2(x[0], x[1]); p.y = H16<F16>::pack2(x[2], x[3]); p.z = H16<F16>::pack2(x[4], x[5]); p.w = H16<F16>::pack2(x[6], x[7]);
@@ -447,6 +483,16 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
                 uint4 o;
                 o.x = H16<F16>::pack2(x[0], x[1]); o.y = H16<F16>::pack2(x[2], x[3]); o.z = H16<F16>::pack2(x[4], x[5]); o.w = H16<F16>::pack2(x[6], x[7]);
                 *reinterpret_cast<uint4*>(Cb + (long)m * g.ldc + n) = o;
+                if constexpr (SPLIT) {                           // low-order half: x - hi is exact in fp32, then rounded once
+                    const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
+                    uint32_t lw[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const v2f_t h = H16<F16>::unpack2(ow[e]);
+                        lw[e] = H16<F16>::pack2(x[2 * e] - h.x, x[2 * e + 1] - h.y);
+                    }
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C_lo) + (long)m * g.ldc + n) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+                }
             }
         }
     }
@@ -789,9 +835,13 @@ __device__ __forceinline__ void pp_unit_offsets(long ld, int r0, int R, int sub,
 // Measured: a 208-row tile takes 0.95 of a full tile's time, not 0.81 - each of the eight barrier intervals of a K-tile
 // costs ~300 cycles whatever the MFMA count of its phase (16 MFMAs = 256) - so this buys +4-7 % on the 768-wide products
 // (7 / 6 is the only short shape instantiated; 8 / 7 = 240 rows for N = 3072 measured 4-8 % SLOWER than full tiles).
-template <bool F16, bool A_KMAJOR, bool B_KMAJOR, bool C_F32, int F0 = 8, int F1 = 8>
+// SPLIT (editor_gemm_f16x2, forward products of the 'f16x2' mode): operands are pairs x = hi + lo of half matrices; the
+// K loop runs three segments over the SAME tile pipeline - lo.hi, hi.lo, then hi.hi (small terms first) - by switching the
+// LDS-DMA source per K-tile; the accumulator, the phases and the barriers are unchanged.  Dropped: lo.lo (2^-22 relative).
+template <bool F16, bool A_KMAJOR, bool B_KMAJOR, bool C_F32, int F0 = 8, int F1 = 8, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
 {
+    static_assert(!SPLIT || (F16 && A_KMAJOR && B_KMAJOR), "split precision: half operands, forward layout");
     static_assert(F0 >= 5 && F0 <= 8 && F1 >= 5 && F1 <= F0, "live fragments per wave group");
     static_assert((F0 == 8 && F1 == 8) || A_KMAJOR, "short tiles: k-major A only");
     constexpr int TH = (F0 + F1) * 16;                          // tile height
@@ -814,6 +864,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
         if (g.live_is_k) ktiles = min(ktiles, (live + BK - 1) / BK);
         else if (m0 >= live) return;
     }
+    const int nkb = ktiles;                                     // K-tiles of one operand half (SPLIT)
+    if constexpr (SPLIT) ktiles *= 3;
     const int per = (ktiles + g.splitk - 1) / g.splitk;
     const int kt0 = blockIdx.y * per, kt1 = min(ktiles, kt0 + per);
     const int nk = max(kt1 - kt0, 0);
@@ -909,12 +961,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
     // beyond the group's live fragments nobody reads them (waves 3, 6, 7 of the 7 + 6 tile) - and a wave that issues none
     // still counts right: vmcnt(6) always spans the A0 / B0 / B1 pieces issued after the A1 ones
     const bool a1_live = (wu & 3) < (wr ? F1 : F0) - 4;
+    const char* baseAlo = reinterpret_cast<const char*>(g.A_lo);
+    const char* baseBlo = reinterpret_cast<const char*>(g.B_lo);
     auto stage_a = [&](int t, int sub) {   // unit A<sub> of K-tile t
         if (sub && !a1_live) return;
-        dma2(baseA + t * kstepA, voA[sub], smem + (t & 1) * KTB + (sub ? UA1 : UA0));
+        const char* src = baseA + t * kstepA;
+        if constexpr (SPLIT)               // segments: [0,nkb) A_lo | [nkb,2nkb) A_hi | [2nkb,3nkb) A_hi
+            src = t < nkb ? baseAlo + t * kstepA : baseA + (t - (t < 2 * nkb ? nkb : 2 * nkb)) * kstepA;
+        dma2(src, voA[sub], smem + (t & 1) * KTB + (sub ? UA1 : UA0));
     };
     auto stage_b = [&](int t, int sub) {
-        dma2(baseB + t * kstepB, voB[sub], smem + (t & 1) * KTB + (sub ? UB1 : UB0));
+        const char* src = baseB + t * kstepB;
+        if constexpr (SPLIT)               //           [0,nkb) B_hi | [nkb,2nkb) B_lo | [2nkb,3nkb) B_hi
+            src = t < nkb ? baseB + t * kstepB : (t < 2 * nkb ? baseBlo + (t - nkb) * kstepB : baseB + (t - 2 * nkb) * kstepB);
+        dma2(src, voB[sub], smem + (t & 1) * KTB + (sub ? UB1 : UB0));
     };
     using c0 = std::integral_constant<int, 0>;
     using c1 = std::integral_constant<int, 1>;
@@ -993,7 +1053,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
 #define PP_EBAR() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PP_BAR(); } while (0)
     const bool staged = g.pp_staged && g.beta == 0.f && (g.splitk == 1 || g.slabs) && (g.N & 7) == 0 && (g.ldc & 7) == 0 &&
                         (g.ldaux & 7) == 0;
-    if (staged && !C_F32 && (g.epilogue == EDITOR_EPI_NONE || g.epilogue == EDITOR_EPI_GELU || g.epilogue == EDITOR_EPI_GELU_BWD)) {
+    if (!SPLIT && staged && !C_F32 && (g.epilogue == EDITOR_EPI_NONE || g.epilogue == EDITOR_EPI_GELU || g.epilogue == EDITOR_EPI_GELU_BWD)) {
         // bf16 outputs whose epilogue is per-element: scale / bias / row scale in registers, ONE pass of the whole
         // 256x256 tile through LDS as bf16 (rows padded to 528 B), then 16-byte row-contiguous stores.  GELU: the
         // staged value is the (rounded) pre-activation, which is an output anyway; the activation is computed from it
@@ -1165,6 +1225,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
             PP_EBAR();
             const int mp = m0 + (pass ? F0 * 16 : 0);                      // the pass's wave group: first row, row limit
             const int ml = min(g.M, mp + (pass ? F1 : F0) * 16);
+            if constexpr (SPLIT) {                                        // (the launcher admits NONE / RESIDUAL / GELU only)
+                switch (g.epilogue) {
+                    case EDITOR_EPI_RESIDUAL: epilogue_copy_out<F16, C_F32, EDITOR_EPI_RESIDUAL, 128, 256, 512, !C_F32>(g, smem, mp, n0, blockIdx.y, ml); break;
+                    case EDITOR_EPI_GELU:     epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU, 128, 256, 512, !C_F32>(g, smem, mp, n0, blockIdx.y, ml); break;
+                    default:                  epilogue_copy_out<F16, C_F32, EDITOR_EPI_NONE, 128, 256, 512, !C_F32>(g, smem, mp, n0, blockIdx.y, ml); break;
+                }
+            } else
             switch (g.epilogue) {
                 case EDITOR_EPI_RESIDUAL: epilogue_copy_out<F16, C_F32, EDITOR_EPI_RESIDUAL, 128, 256, 512>(g, smem, mp, n0, blockIdx.y, ml); break;
                 case EDITOR_EPI_GELU:     epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU, 128, 256, 512>(g, smem, mp, n0, blockIdx.y, ml); break;
@@ -1194,12 +1261,7 @@ template <bool F16, bool AK, bool BK_, bool CF, bool GL>
 int launch(const GemmB16Args& g, hipStream_t stream)
 {
     auto kern = gemm_bf16_kernel<F16, AK, BK_, CF, GL>;
-    static bool attr_done = false;                       // per-instantiation; idempotent
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    if (int e = ensure_lds<gemm_bf16_kernel<F16, AK, BK_, CF, GL>>(4 * TILE_BYTES)) return e;
     hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(256), 4 * TILE_BYTES, stream, g);
     EDITOR_LAUNCH_CHECK();
     return 0;
@@ -1237,12 +1299,7 @@ int launch_pipe_t(GemmB16Args g, hipStream_t stream)
 {
     constexpr int LDS = STAGES * (PBM + PBN) * BK * 2;
     auto kern = gemm_bf16_pipe_kernel<F16, AK, BK_, CF, PBM, PBN, STAGES, NWAVES>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    if (int e = ensure_lds<gemm_bf16_pipe_kernel<F16, AK, BK_, CF, PBM, PBN, STAGES, NWAVES>>(LDS)) return e;
     g.tiles_m = (g.M + PBM - 1) / PBM;
     g.tiles_n = (g.N + PBN - 1) / PBN;
     hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(NWAVES * 64), LDS, stream, g);
@@ -1250,17 +1307,12 @@ int launch_pipe_t(GemmB16Args g, hipStream_t stream)
     return 0;
 }
 
-template <bool F16, bool AK, bool BK_, bool CF, int F0, int F1>
+template <bool F16, bool AK, bool BK_, bool CF, int F0, int F1, bool SPLIT = false>
 int launch_pp_t(GemmB16Args g, hipStream_t stream)
 {
     constexpr int LDS = 256 * (256 * 2 + 16) + (int)kLutBytes;  // >= 2 K-tile buffers, the fp32 half-tile image, the bf16 tile image + GELU table
-    auto kern = gemm_bf16_pp_kernel<F16, AK, BK_, CF, F0, F1>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    auto kern = gemm_bf16_pp_kernel<F16, AK, BK_, CF, F0, F1, SPLIT>;
+    if (int e = ensure_lds<gemm_bf16_pp_kernel<F16, AK, BK_, CF, F0, F1, SPLIT>>(LDS)) return e;
     g.tiles_m = (g.M + (F0 + F1) * 16 - 1) / ((F0 + F1) * 16);
     g.tiles_n = (g.N + 255) / 256;
     // measured: the LDS-staged epilogue (full-line 16-byte stores) beats the direct one on every layout here
@@ -1378,7 +1430,7 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
                   slabs ? 0.f : beta, bias, rowscale, splitk, (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux,
                   slabs ? 1 : 0,
                   m_live, transA ? 1 : 0, 0, want_colsum ? splitk_ws : nullptr, nullptr, force_pp ? 1 : 0, aux_grad ? 1 : 0,
-                  tile_frags};
+                  tile_frags, nullptr, nullptr, nullptr};
     if (m_live && (!pipe || (splitk > 1 && !slabs))) return (int)hipErrorInvalidValue;   // live-row form: pipelined path only
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
     int rc;
@@ -1418,7 +1470,43 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
 #undef GEMM_CASE
 }
 
+// Forward product of the split-precision mode: C = alpha * (A_hi + A_lo)(B_hi + B_lo)^T (+bias) (*rowscale) (+aux residual /
+// GELU), A (M,K) and B (N,K) k-major half pairs, always on the 256x256 ping-pong kernel (any M, N; K % 64 == 0).
+int gemm_f16x2(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi, const uint16_t* B_lo, void* C, void* C_lo,
+    int c_f32, int M, int N, int K, long lda, long ldb, long ldc, float alpha, const float* bias, const float* rowscale,
+    int epilogue, void* aux, long ldaux, const int* m_live, hipStream_t stream)
+{
+    if (M <= 0 || N < 8 || K <= 0 || (K % BK) || (N & 7) || (lda & 7) || (ldb & 7) || (ldc & 7) || (ldaux & 7))
+        return (int)hipErrorInvalidValue;
+    if (!A_hi || !A_lo || !B_hi || !B_lo || !C || (!c_f32 && !C_lo) || (c_f32 && C_lo)) return (int)hipErrorInvalidValue;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(A_hi) | reinterpret_cast<uintptr_t>(A_lo) | reinterpret_cast<uintptr_t>(B_hi) |
+                         reinterpret_cast<uintptr_t>(B_lo) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(C_lo);
+    if (al & 15) return (int)hipErrorInvalidValue;
+    const int tile_frags = (epilogue >> 12) & 15;
+    if (tile_frags != 0 && tile_frags != 13) return (int)hipErrorInvalidValue;
+    const bool aux_grad = (epilogue & EDITOR_EPI_AUX_GRAD) != 0;
+    epilogue &= ~(EDITOR_EPI_FORCE_PP | EDITOR_EPI_AUX_GRAD | 0xF000);
+    if (epilogue != EDITOR_EPI_NONE && epilogue != EDITOR_EPI_RESIDUAL && epilogue != EDITOR_EPI_GELU) return (int)hipErrorInvalidValue;
+    if (epilogue != EDITOR_EPI_NONE && !aux) return (int)hipErrorInvalidValue;
+    if (epilogue == EDITOR_EPI_GELU && (c_f32 || !aux_grad)) return (int)hipErrorInvalidValue;   // aux = gelu'(x) for the backward
+    if (epilogue == EDITOR_EPI_RESIDUAL && !c_f32) return (int)hipErrorInvalidValue;
+    GemmB16Args g{(const bf16_t*)A_hi, (const bf16_t*)B_hi, C, M, N, K, lda, ldb, ldc, alpha, 0.f, bias, rowscale, 1, 0, 0,
+                  epilogue, aux, ldaux, 0, m_live, 0, 1, nullptr, nullptr, 1, 1, tile_frags,
+                  (const bf16_t*)A_lo, (const bf16_t*)B_lo, C_lo};
+    if (tile_frags == 13)
+        return c_f32 ? launch_pp_t<true, true, true, true, 7, 6, true>(g, stream) : launch_pp_t<true, true, true, false, 7, 6, true>(g, stream);
+    return c_f32 ? launch_pp_t<true, true, true, true, 8, 8, true>(g, stream) : launch_pp_t<true, true, true, false, 8, 8, true>(g, stream);
+}
+
 }  // namespace
+
+extern "C" int editor_gemm_f16x2(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi, const uint16_t* B_lo, void* C,
+    void* C_lo, int c_f32, int M, int N, int K, long lda, long ldb, long ldc, float alpha, const float* bias,
+    const float* rowscale, int epilogue, void* aux, long ldaux, const int* m_live, hipStream_t stream)
+{
+    return gemm_f16x2(A_hi, A_lo, B_hi, B_lo, C, C_lo, c_f32, M, N, K, lda, ldb, ldc, alpha, bias, rowscale, epilogue, aux, ldaux,
+                      m_live, stream);
+}
 
 extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda,
     long ldb, long ldc, int transA, int transB, float alpha, float beta, const float* bias, const float* rowscale,

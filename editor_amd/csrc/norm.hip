@@ -15,6 +15,7 @@ template <typename T> struct Vec4;
 template <> struct Vec4<float> {
     static __device__ __forceinline__ float4 ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
     static __device__ __forceinline__ void st(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+    static __device__ __forceinline__ float4 rnd(float4 v) { return v; }
 };
 template <> struct Vec4<bf16_t> {
     static __device__ __forceinline__ float4 ld(const bf16_t* p) {
@@ -25,6 +26,10 @@ template <> struct Vec4<bf16_t> {
     static __device__ __forceinline__ void st(bf16_t* p, float4 v) {
         uint2 u; u.x = pack_bf16x2(v.x, v.y); u.y = pack_bf16x2(v.z, v.w);
         *reinterpret_cast<uint2*>(p) = u;
+    }
+    static __device__ __forceinline__ float4 rnd(float4 v) {          // the values st() stores, back in fp32
+        const float2_t_ a = H16<false>::unpack2(pack_bf16x2(v.x, v.y)), b = H16<false>::unpack2(pack_bf16x2(v.z, v.w));
+        return make_float4(a.x, a.y, b.x, b.y);
     }
 };
 
@@ -38,7 +43,20 @@ template <> struct Vec4<f16_t> {
         uint2 u; u.x = pack_f16x2(v.x, v.y); u.y = pack_f16x2(v.z, v.w);
         *reinterpret_cast<uint2*>(p) = u;
     }
+    static __device__ __forceinline__ float4 rnd(float4 v) {
+        const float2_t_ a = H16<true>::unpack2(pack_f16x2(v.x, v.y)), b = H16<true>::unpack2(pack_f16x2(v.z, v.w));
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
 };
+
+// split-precision pair (COMPUTE_DTYPE 'f16x2'): hi = round(v), lo = round(v - hi) (v - hi is exact in fp32)
+template <typename T>
+__device__ __forceinline__ void st_split(T* hi, T* lo, float4 v)
+{
+    const float4 h = Vec4<T>::rnd(v);
+    Vec4<T>::st(hi, v);
+    Vec4<T>::st(lo, make_float4(v.x - h.x, v.y - h.y, v.z - h.z, v.w - h.w));
+}
 
 constexpr int kMaxV = 4;   // float4 chunks per lane: D <= 64*4*4 = 1024
 
@@ -49,7 +67,8 @@ constexpr int kMaxV = 4;   // float4 chunks per lane: D <= 64*4*4 = 1024
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, long M, int D, const uint8_t* __restrict__ rowmask, int mask_period,
-    T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, const int* __restrict__ m_live)
+    T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, const int* __restrict__ m_live,
+    T* __restrict__ y_lo = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -84,7 +103,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         o.y = ((v[i].y - mean) * rstd * g.y + bt.y) * keep;
         o.z = ((v[i].z - mean) * rstd * g.z + bt.z) * keep;
         o.w = ((v[i].w - mean) * rstd * g.w + bt.w) * keep;
-        Vec4<T>::st(yr + c0, o);
+        if (y_lo) st_split(yr + c0, y_lo + row * D + c0, o);
+        else Vec4<T>::st(yr + c0, o);
     }
     if (lane == 0) { if (mean_out) mean_out[row] = mean; if (rstd_out) rstd_out[row] = rstd; }
 }
@@ -330,7 +350,8 @@ __global__ __launch_bounds__(256) void cast_rows_colsum_kernel(const float* __re
 // == Conv2d(k=16,s=16) weight layout (768,3,16,16) flattened (vit_pytorch.py:438,455-457).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void im2col16_kernel(const float* __restrict__ img, int B, int C, int H, int W, T* __restrict__ out)
+__global__ void im2col16_kernel(const float* __restrict__ img, int B, int C, int H, int W, T* __restrict__ out,
+                                T* __restrict__ out_lo = nullptr)
 {
     const int px = W >> 4, py = H >> 4;
     const long total4 = (long)B * py * px * C * 64;                 // float4 groups
@@ -343,7 +364,20 @@ __global__ void im2col16_kernel(const float* __restrict__ img, int B, int C, int
         const int b = (int)(r / (py * px));
         const int y = (p / px) * 16 + i, x0 = (p % px) * 16 + j4 * 4;
         const float4 v = *reinterpret_cast<const float4*>(img + (((long)b * C + c) * H + y) * W + x0);
-        Vec4<T>::st(out + ((long)b * py * px + p) * (C * 256) + c * 256 + i * 16 + j4 * 4, v);
+        const long o = ((long)b * py * px + p) * (C * 256) + c * 256 + i * 16 + j4 * 4;
+        if (out_lo) st_split(out + o, out_lo + o, v);
+        else Vec4<T>::st(out + o, v);
+    }
+}
+
+// fp32 -> split-precision half pair of in * scale (scale a power of two: GEMM weights are pre-scaled so that the low-order
+// parts of |w| ~ 0.02 stay in half's normal range; the product's alpha divides it out)
+__global__ void split_f32_kernel(const float* __restrict__ in, f16_t* __restrict__ hi, f16_t* __restrict__ lo, long n4, float scale)
+{
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+        float4 v = *reinterpret_cast<const float4*>(in + e * 4);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        st_split(hi + e * 4, lo + e * 4, v);
     }
 }
 
@@ -742,6 +776,36 @@ extern "C" int editor_cast_rows_colsum(const float* in, const float* rowscale, l
     EDITOR_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((D + 63) / 64), dim3(1024), 0, stream, workspace, (int)blocks, (long)D, colsum,
                        0, colsum_scale);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_layernorm_fwd_f16x2(const float* x, const float* gamma, const float* beta, float eps, long M, int D,
+    const uint8_t* rowmask, int mask_period, uint16_t* y_hi, uint16_t* y_lo, float* mean, float* rstd, const int* m_live,
+    hipStream_t stream)
+{
+    if (D % 256 || D > 1024 || M <= 0 || !y_hi || !y_lo) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_fwd_kernel<f16_t>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream,
+                       x, gamma, beta, eps, M, D, rowmask, mask_period, (f16_t*)y_hi, mean, rstd, m_live, (f16_t*)y_lo);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_im2col16_f16x2(const float* img, int B, int C, int H, int W, uint16_t* out_hi, uint16_t* out_lo,
+                                     hipStream_t stream)
+{
+    if ((H & 15) || (W & 15) || !out_hi || !out_lo) return (int)hipErrorInvalidValue;
+    const long total4 = (long)B * (H >> 4) * (W >> 4) * C * 64;
+    hipLaunchKernelGGL(im2col16_kernel<f16_t>, dim3(grid_for(total4)), dim3(256), 0, stream, img, B, C, H, W, (f16_t*)out_hi,
+                       (f16_t*)out_lo);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_split_f32(const float* in, uint16_t* hi, uint16_t* lo, long n, float scale, hipStream_t stream)
+{
+    if (n <= 0 || (n & 3) || !hi || !lo) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(split_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, in, (f16_t*)hi, (f16_t*)lo, n / 4, scale);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

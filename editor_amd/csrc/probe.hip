@@ -38,6 +38,24 @@ __global__ void probe_mfma16_kernel(const float* __restrict__ A, const float* __
 #pragma unroll
     for (int r = 0; r < 4; ++r) D[((l >> 4) * 4 + r) * 16 + (l & 15)] = c[r];
 }
+// raw 16-bit operand lanes in, fp32 D out: v_mfma_f32_16x16x32_f16 (f16 != 0) or _bf16 - used to pin how the matrix core
+// treats SUBNORMAL half inputs (the split-precision forward keeps low-order parts there)
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+__global__ void probe_mfma16_raw_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, float* __restrict__ D, int f16)
+{
+    const int l = threadIdx.x;
+    short8_t a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        a[e] = (short)A[(l & 15) * 32 + (l >> 4) * 8 + e];
+        b[e] = (short)B[((l >> 4) * 8 + e) * 16 + (l & 15)];
+    }
+    float4_t c = {0.f, 0.f, 0.f, 0.f};
+    if (f16) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) D[((l >> 4) * 4 + r) * 16 + (l & 15)] = c[r];
+}
 }  // namespace
 
 extern "C" int editor_probe_tr16(const int* addr, uint16_t* out, hipStream_t stream)
@@ -49,6 +67,12 @@ extern "C" int editor_probe_tr16(const int* addr, uint16_t* out, hipStream_t str
 extern "C" int editor_probe_mfma16(const float* A, const float* B, float* D, hipStream_t stream)
 {
     hipLaunchKernelGGL(probe_mfma16_kernel, dim3(1), dim3(64), 0, stream, A, B, D);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int editor_probe_mfma16_raw(const uint16_t* A, const uint16_t* B, float* D, int f16, hipStream_t stream)
+{
+    hipLaunchKernelGGL(probe_mfma16_raw_kernel, dim3(1), dim3(64), 0, stream, A, B, D, f16);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

@@ -15,8 +15,14 @@ template <bool F16>
 __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict__ p_ptrs, const float* const* __restrict__ g_ptrs,
     float* const* __restrict__ m_ptrs, const int* __restrict__ chunk_tensor, const long* __restrict__ chunk_off,
     const long* __restrict__ numel, const float* __restrict__ lr, const float* __restrict__ wd, float momentum,
-    uint16_t* const* __restrict__ h_ptrs, int* __restrict__ nonfinite)
+    uint16_t* const* __restrict__ h_ptrs, int* __restrict__ nonfinite, const float* __restrict__ inv_scale_dev,
+    const int* __restrict__ skip)
 {
+    // amp.GradScaler.step semantics (engine/processor.py:94-96): when this step's gradients hold an inf / nan (flag written
+    // by grad_check_multi_kernel BEFORE this launch) nothing is updated - parameters, momentum and the 16-bit shadows keep
+    // their values; gradients that carry the (device-resident) loss scale are unscaled on the way in
+    if (skip && *skip) return;
+    const float gsc = inv_scale_dev ? *inv_scale_dev : 1.f;
     const int t = chunk_tensor[blockIdx.x];
     const long off = chunk_off[blockIdx.x];
     const long n = min((long)kChunk, numel[t] - off);
@@ -32,8 +38,9 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict
     if (vec) {
         for (long i = threadIdx.x * 4L; i + 3 < n; i += 1024) {
             float4 pv = *reinterpret_cast<float4*>(p + i);
-            const float4 gv = *reinterpret_cast<const float4*>(g + i);
+            float4 gv = *reinterpret_cast<const float4*>(g + i);
             bad |= !(isfinite(gv.x) && isfinite(gv.y) && isfinite(gv.z) && isfinite(gv.w));
+            gv.x *= gsc; gv.y *= gsc; gv.z *= gsc; gv.w *= gsc;
             float4 mv = *reinterpret_cast<float4*>(m + i);
             const float4 d = make_float4(gv.x + w * pv.x, gv.y + w * pv.y, gv.z + w * pv.z, gv.w + w * pv.w);
             mv = make_float4(momentum * mv.x + d.x, momentum * mv.y + d.y, momentum * mv.z + d.z, momentum * mv.w + d.w);
@@ -44,7 +51,7 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict
         }
         for (long i = (n & ~3L) + threadIdx.x; i < n; i += 256) {
             bad |= !isfinite(g[i]);
-            const float d = g[i] + w * p[i];
+            const float d = g[i] * gsc + w * p[i];
             const float mv = momentum * m[i] + d;
             m[i] = mv; p[i] -= l * mv;
             if (h) h[i] = H16<F16>::from_f32(p[i]);
@@ -52,13 +59,92 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict
     } else {
         for (long i = threadIdx.x; i < n; i += 256) {
             bad |= !isfinite(g[i]);
-            const float d = g[i] + w * p[i];
+            const float d = g[i] * gsc + w * p[i];
             const float mv = momentum * m[i] + d;
             m[i] = mv; p[i] -= l * mv;
             if (h) h[i] = H16<F16>::from_f32(p[i]);
         }
     }
     if (nonfinite && bad) atomicOr(nonfinite, 1);
+}
+
+// found[0] |= 1 when any gradient element of the step is inf / nan (torch._amp_foreach_non_finite_check_and_unscale_'s
+// check, engine/processor.py:94-95 via GradScaler.step): one pass over the gradients BEFORE the update, eight 16-byte loads
+// in flight per thread.  sticky (optional) accumulates across steps for FusedSGD.found_inf().
+__global__ __launch_bounds__(256) void grad_check_multi_kernel(const float* const* __restrict__ g_ptrs, const int* __restrict__ chunk_tensor,
+    const long* __restrict__ chunk_off, const long* __restrict__ numel, int* __restrict__ found, int* __restrict__ sticky)
+{
+    const int t = chunk_tensor[blockIdx.x];
+    if (!g_ptrs[t]) return;
+    const long off = chunk_off[blockIdx.x];
+    const long n = min((long)kChunk, numel[t] - off);
+    const float* __restrict__ g = g_ptrs[t] + off;
+    // |x| as integer >= 0x7f800000  <=>  inf or nan
+    uint32_t acc = 0u;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+        const long n4 = n >> 2;
+        for (long i0 = threadIdx.x; i0 < n4; i0 += 256 * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long i = i0 + j * 256;
+                v[j] = i < n4 ? *reinterpret_cast<const uint4*>(g + i * 4) : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc |= (uint32_t)((v[j].x & 0x7fffffffu) >= 0x7f800000u) | (uint32_t)((v[j].y & 0x7fffffffu) >= 0x7f800000u) |
+                       (uint32_t)((v[j].z & 0x7fffffffu) >= 0x7f800000u) | (uint32_t)((v[j].w & 0x7fffffffu) >= 0x7f800000u);
+        }
+        for (long i = (n & ~3L) + threadIdx.x; i < n; i += 256) acc |= (uint32_t)((__float_as_uint(g[i]) & 0x7fffffffu) >= 0x7f800000u);
+    } else {
+        for (long i = threadIdx.x; i < n; i += 256) acc |= (uint32_t)((__float_as_uint(g[i]) & 0x7fffffffu) >= 0x7f800000u);
+    }
+    if (__builtin_amdgcn_ballot_w64(acc != 0u) != 0ull && (threadIdx.x & 63) == 0) {
+        atomicOr(found, 1);
+        if (sticky) atomicOr(sticky, 1);
+    }
+}
+
+// amp.GradScaler.update (torch/amp/grad_scaler.py `_amp_update_scale_`) on device-resident state, one thread:
+// found -> scale *= backoff, tracker = 0; else tracker += 1 and at growth_interval scale *= growth, tracker = 0.
+// Also refreshes inv_scale = 1 / scale and clears `found` for the next step.
+__global__ void scaler_update_kernel(float* scale, float* inv_scale, int* tracker, int* found, float growth, float backoff, int interval)
+{
+    float s = scale[0];
+    if (found[0]) { s *= backoff; tracker[0] = 0; }
+    else if (++tracker[0] >= interval) { const float g = s * growth; if (isfinite(g)) s = g; tracker[0] = 0; }
+    scale[0] = s;
+    inv_scale[0] = 1.f / s;
+    found[0] = 0;
+}
+
+// split-precision pairs (COMPUTE_DTYPE 'f16x2') of many fp32 tensors in one launch: hi = half(p * scale), lo = half(p * scale - hi),
+// over the same chunk tables as sgd_multi_kernel (the forward's weight operands, refreshed after the update)
+__global__ __launch_bounds__(256) void split_multi_kernel(const float* const* __restrict__ p_ptrs, uint16_t* const* __restrict__ hi_ptrs,
+    uint16_t* const* __restrict__ lo_ptrs, const int* __restrict__ chunk_tensor, const long* __restrict__ chunk_off,
+    const long* __restrict__ numel, float scale)
+{
+    const int t = chunk_tensor[blockIdx.x];
+    if (!hi_ptrs[t]) return;
+    const long off = chunk_off[blockIdx.x];
+    const long n = min((long)kChunk, numel[t] - off);          // (shadowed tensors are >= 2-D GEMM weights: n % 4 == 0, 16-byte aligned)
+    const float* __restrict__ p = p_ptrs[t] + off;
+    uint16_t* __restrict__ hi = hi_ptrs[t] + off;
+    uint16_t* __restrict__ lo = lo_ptrs[t] + off;
+    for (long i = threadIdx.x * 4L; i + 3 < n; i += 1024) {
+        float4 v = *reinterpret_cast<const float4*>(p + i);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        uint2 h; h.x = pack_f16x2(v.x, v.y); h.y = pack_f16x2(v.z, v.w);
+        const float2_t_ a = H16<true>::unpack2(h.x), b = H16<true>::unpack2(h.y);
+        uint2 l; l.x = pack_f16x2(v.x - a.x, v.y - a.y); l.y = pack_f16x2(v.z - b.x, v.w - b.y);
+        *reinterpret_cast<uint2*>(hi + i) = h;
+        *reinterpret_cast<uint2*>(lo + i) = l;
+    }
+    for (long i = (n & ~3L) + threadIdx.x; i < n; i += 256) {
+        const float v = p[i] * scale;
+        const uint16_t h = f32_to_f16(v);
+        hi[i] = h; lo[i] = f32_to_f16(v - f16_to_f32(h));
+    }
 }
 
 // Transposed 16-bit copies of the GEMM weights for the dgrad products: dx = dy W reduces over the ROWS of the nn.Linear
@@ -140,16 +226,47 @@ __global__ void advance_state_kernel(long* state) { state[0] += 1; }
 
 extern "C" int editor_sgd_multi(float* const* p_ptrs, const float* const* g_ptrs, float* const* m_ptrs,
     const int* chunk_tensor, const long* chunk_off, const long* numel, const float* lr, const float* wd, float momentum,
-    long nchunks, uint16_t* const* h_ptrs, int shadow_dtype, int* nonfinite, hipStream_t stream)
+    long nchunks, uint16_t* const* h_ptrs, int shadow_dtype, int* nonfinite, const float* inv_scale, const int* skip,
+    hipStream_t stream)
 {
     if (nchunks < 1) return 0;
     if (h_ptrs && shadow_dtype != 1 && shadow_dtype != 2) return (int)hipErrorInvalidValue;
     if (shadow_dtype == 2)
         hipLaunchKernelGGL(sgd_multi_kernel<true>, dim3((unsigned)nchunks), dim3(256), 0, stream, p_ptrs, g_ptrs, m_ptrs,
-                           chunk_tensor, chunk_off, numel, lr, wd, momentum, h_ptrs, nonfinite);
+                           chunk_tensor, chunk_off, numel, lr, wd, momentum, h_ptrs, nonfinite, inv_scale, skip);
     else
         hipLaunchKernelGGL(sgd_multi_kernel<false>, dim3((unsigned)nchunks), dim3(256), 0, stream, p_ptrs, g_ptrs, m_ptrs,
-                           chunk_tensor, chunk_off, numel, lr, wd, momentum, h_ptrs, nonfinite);
+                           chunk_tensor, chunk_off, numel, lr, wd, momentum, h_ptrs, nonfinite, inv_scale, skip);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_grad_check_multi(const float* const* g_ptrs, const int* chunk_tensor, const long* chunk_off,
+    const long* numel, long nchunks, int* found, int* sticky, hipStream_t stream)
+{
+    if (nchunks < 1) return 0;
+    if (!found) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(grad_check_multi_kernel, dim3((unsigned)nchunks), dim3(256), 0, stream, g_ptrs, chunk_tensor, chunk_off,
+                       numel, found, sticky);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_scaler_update(float* scale, float* inv_scale, int* tracker, int* found, float growth, float backoff,
+                                    int interval, hipStream_t stream)
+{
+    if (!scale || !inv_scale || !tracker || !found || interval < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(1), 0, stream, scale, inv_scale, tracker, found, growth, backoff, interval);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_split_multi(const float* const* p_ptrs, uint16_t* const* hi_ptrs, uint16_t* const* lo_ptrs,
+    const int* chunk_tensor, const long* chunk_off, const long* numel, long nchunks, float scale, hipStream_t stream)
+{
+    if (nchunks < 1) return 0;
+    hipLaunchKernelGGL(split_multi_kernel, dim3((unsigned)nchunks), dim3(256), 0, stream, p_ptrs, hi_ptrs, lo_ptrs, chunk_tensor,
+                       chunk_off, numel, scale);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

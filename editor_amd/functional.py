@@ -74,6 +74,27 @@ def act_weight_t(w, dtype):
     return ent[2]
 
 
+F16X2 = "f16x2"      # act_dtype marker of the split-precision forward: half pairs in the forward, plain f16 in the backward
+
+
+def act_weight_split(w):
+    """fp32 master weight -> the (hi, lo) half pair of w * ops.SPLIT_WSCALE (forward operand of the 'f16x2' mode), cached like
+    act_weight (FusedSGD refreshes the pairs in its own launch)."""
+    key = (id(w), F16X2)
+    ent = _BF16_CACHE.get(key)
+    ver = w._version
+    if ent is None or ent[0]() is not w or ent[1] != ver or ent[3] != w.data_ptr() or ent[4] != _WEIGHT_EPOCH:
+        ent = (weakref.ref(w), ver, ops.split_f32(w.detach(), ops.SPLIT_WSCALE), w.data_ptr(), _WEIGHT_EPOCH)
+        _BF16_CACHE[key] = ent
+    return ent[2]
+
+
+def install_weight_pairs(triples):
+    """(parameter, hi, lo) -> entries of the operand cache for the current epoch (editor_amd.optim.FusedSGD)."""
+    for w, hi, lo in triples:
+        _BF16_CACHE[(id(w), F16X2)] = (weakref.ref(w), w._version, (hi, lo), w.data_ptr(), _WEIGHT_EPOCH)
+
+
 def act_weight(w, dtype):
     """fp32 master parameter -> GEMM operand dtype.  16-bit copies are cached per parameter OBJECT and re-cast when
     the parameter's version counter moves (optimizer step, load_state_dict).  The entry holds a weak reference so
@@ -230,6 +251,42 @@ class TransformerBlockFn(torch.autograd.Function):
         hd = d // heads
         x2d = x.reshape(m, d)
         amask = None if cu is not None else mask           # packed sequences hold only live tokens
+        if act_dtype == F16X2:
+            # split-precision forward: every product on half PAIRS (three MFMA passes, fp32-class), the exact softmax / GELU
+            # on unrounded values; what is saved for the (16-bit) backward are the hi halves - plain f16 tensors
+            act_dtype = torch.float16
+            inv_ws = 1.0 / ops.SPLIT_WSCALE
+            wq, wp, w1, w2 = (act_weight_split(w) for w in (qkvw, projw, fc1w, fc2w))
+            hidden = fc1w.shape[0]
+            h1, h1l, mean1, rstd1 = ops.layernorm_fwd_split(x2d, n1w, n1b, eps, mask, m_live)
+            qkv = torch.empty(m, 3 * d, dtype=act_dtype, device=x.device)
+            qkvl = torch.empty_like(qkv)
+            ops.gemm_split((h1, h1l), wq, qkv, qkvl, m, 3 * d, d, alpha=inv_ws, bias=qkvb, m_live=m_live)
+            del h1l
+            (ao, aol), attn_saved = ops.attention_fwd_split((qkv, qkvl), b, t, heads, hd, amask,
+                                                            None if isinstance(probs_out, list) else probs_out, cu=cu,
+                                                            scale=qk_scale)
+            del qkvl
+            x1 = torch.empty_like(x2d)
+            ops.gemm_split((ao, aol), wp, x1, None, m, d, d, alpha=inv_ws, bias=projb, rowscale=rowscale_attn,
+                           epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)
+            del aol
+            h2, h2l, mean2, rstd2 = ops.layernorm_fwd_split(x1, n2w, n2b, eps, mask, m_live)
+            a = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
+            g = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
+            gl = torch.empty_like(g)
+            ops.gemm_split((h2, h2l), w1, g, gl, m, hidden, d, alpha=inv_ws, bias=fc1b, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD,
+                           aux=a, m_live=m_live)
+            del h2l
+            x2 = torch.empty_like(x2d)
+            ops.gemm_split((g, gl), w2, x2, None, m, d, hidden, alpha=inv_ws, bias=fc2b, rowscale=rowscale_mlp,
+                           epilogue=ops.EPI_RESIDUAL, aux=x1, m_live=m_live)
+            del gl
+            ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
+                                  qkvw, projw, fc1w, fc2w, mask, attn_saved, rowscale_attn, rowscale_mlp, cu, m_live)
+            ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None,
+                        tuple(x.shape), qk_scale, sink)
+            return x2.view(x.shape)
         wq, wp, w1, w2 = (act_weight(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w))
         h1, mean1, rstd1 = ops.layernorm_fwd(x2d, n1w, n1b, eps, act_dtype, mask, 0, m_live=m_live)
         qkv = _linear_fwd(h1, wq, qkvb, act_dtype, m_live)
@@ -331,9 +388,18 @@ class PatchEmbedFn(torch.autograd.Function):
         btot = sum(i.shape[0] for i in img) if isinstance(img, (list, tuple)) else img.shape[0]
         d = conv_w.shape[0]
         kdim = conv_w[0].numel()
-        cols = ops.im2col16(img, act_dtype)
-        w = act_weight(conv_w, act_dtype).view(d, kdim)
-        patch = _linear_fwd(cols, w, conv_b, act_dtype)
+        if act_dtype == F16X2:          # split-precision forward: fp32 patch rows from the half pairs; the backward is f16
+            act_dtype = torch.float16
+            cols, cols_lo = ops.im2col16_split(img)
+            wh, wl = act_weight_split(conv_w)
+            patch = torch.empty(cols.shape[0], d, dtype=torch.float32, device=cols.device)
+            ops.gemm_split((cols, cols_lo), (wh.view(d, kdim), wl.view(d, kdim)), patch, None, cols.shape[0], d, kdim,
+                           alpha=1.0 / ops.SPLIT_WSCALE, bias=conv_b)
+            del cols_lo
+        else:
+            cols = ops.im2col16(img, act_dtype)
+            w = act_weight(conv_w, act_dtype).view(d, kdim)
+            patch = _linear_fwd(cols, w, conv_b, act_dtype)
         t = pos.shape[1]
         x = ops.embed_assemble(patch, cls.view(-1), pos.view(t, d), None if sie is None else sie.view(-1, d),
                                cam, coef, btot, t, d)

@@ -47,11 +47,11 @@ def _act_dtype(cfg):
     name = getattr(cfg.MODEL, "COMPUTE_DTYPE", "bf16")
     if name in ("f32", "fp32", "float32"):
         return torch.float32
-    if name in ("f16", "fp16", "float16", "half"):
+    if name in ("f16", "fp16", "float16", "half", "f16x2"):     # 'f16x2': f16 tensors, split-precision forward (EDITOR.split_fwd)
         return torch.float16
     if name in ("bf16", "bfloat16"):
         return torch.bfloat16
-    raise ValueError("cfg.MODEL.COMPUTE_DTYPE must be 'bf16', 'f16' or 'f32', got %r" % (name,))
+    raise ValueError("cfg.MODEL.COMPUTE_DTYPE must be 'bf16', 'f16', 'f16x2' or 'f32', got %r" % (name,))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -279,6 +279,10 @@ class EDITOR(nn.Module):
             self.AL_BN = nn.BatchNorm1d(nmod * dim)
             nn.init.normal_(self.AL_HEAD.weight, std=0.001)
         self.act_dtype = _act_dtype(cfg)
+        # 'f16x2': the forward runs every product on split-precision half pairs (hi.hi + hi.lo + lo.hi on the half matrix
+        # cores, fp32-class: token selection as the f32 parity mode, at ~2/3 of the f16 mode's speed); the backward is f16's
+        self.split_fwd = getattr(cfg.MODEL, "COMPUTE_DTYPE", "bf16") == "f16x2"
+        self.fn_dtype = fn.F16X2 if self.split_fwd else self.act_dtype       # what the autograd nodes are told
         base = self.BACKBONE.base
         if self.act_dtype != torch.float32 and (dim // base.heads != 64 or dim // self.hma_heads != 64):
             # the fused 16-bit attention kernels are written for 64-wide heads (ViT-B/L, DeiT-B); the exact-f32 parity
@@ -351,12 +355,13 @@ class EDITOR(nn.Module):
         sie = base.sie_embed if base.cam_num > 1 else None
         x = fn.PatchEmbedFn.apply(imgs, base.patch_embed.proj.weight, base.patch_embed.proj.bias, base.cls_token,
                                   base.pos_embed, sie, cam if sie is not None else None, float(base.sie_xishu),
-                                  self.act_dtype)
+                                  self.fn_dtype)
         # softmax outputs of every layer; rows padded to a multiple of 4 floats in bf16 mode (16-byte stores)
         # f32 parity mode: the (L,3B,h,T,T) softmax outputs are materialised as the reference does.  bf16 mode: every
         # block hands back its (qkv, row log-sum-exp) instead and the rollout recomputes the probabilities from them
         # (cfg.MODEL.ROLLOUT_PROBS = True keeps the materialised form: rows padded to a multiple of 4 floats).
-        recompute = self.act_dtype != torch.float32 and not self.rollout_probs
+        # (split-precision mode: the fp32 probabilities of the split attention kernel are materialised, as in f32 mode)
+        recompute = self.act_dtype != torch.float32 and not self.rollout_probs and not self.split_fwd
         ldp = t if self.act_dtype == torch.float32 else (t + 3) // 4 * 4
         probs = [] if recompute else torch.empty(base.depth, btot, base.heads, t, ldp, dtype=torch.float32,
                                                  device=dev)
@@ -373,7 +378,7 @@ class EDITOR(nn.Module):
             if scales is not None and base.drop_rates[i] > 0.0:
                 rs_a, rs_m = scales[i, 0], scales[i, 1]
             x = fn.TransformerBlockFn.apply(x, *_block_args(blk.norm1, blk.attn, blk.norm2, blk.mlp), None,
-                                            probs if recompute else probs[i], base.heads, 1e-6, self.act_dtype, rs_a, rs_m,
+                                            probs if recompute else probs[i], base.heads, 1e-6, self.fn_dtype, rs_a, rs_m,
                                             None, None, None, base.qk_scale, self._sink("backbone.%d" % i))
         x = fn.LayerNormFn.apply(x, base.norm.weight, base.norm.bias, 1e-6, None)
         return x, probs
@@ -413,7 +418,7 @@ class EDITOR(nn.Module):
             args = _block_args(getattr(fb, "norm" + tag), getattr(fb, "attn" + tag), getattr(fb, "norm" + tag + "_"),
                                getattr(fb, "mlp" + tag))
             mods.append(fn.TransformerBlockFn.apply(feats_mod[i], *args, mask, None, self.hma_heads, 1e-5,
-                                                    self.act_dtype, None, None, None, None, None, None,
+                                                    self.fn_dtype, None, None, None, None, None, None,
                                                     self._sink("hma." + tag)))
         loss_ocfr = None
         if self.training:
@@ -421,7 +426,7 @@ class EDITOR(nn.Module):
         x = torch.cat(mods, dim=1)
         mask3 = mask.repeat(1, nmod).contiguous()
         x = fn.TransformerBlockFn.apply(x, *_block_args(fb.norm1, fb.attn1, fb.norm2, fb.mlp), mask3, None,
-                                        self.hma_heads, 1e-5, self.act_dtype, None, None, None, None, None, None,
+                                        self.hma_heads, 1e-5, self.fn_dtype, None, None, None, None, None, None,
                                         self._sink("hma.joint"))
         x = fn.LayerNormFn.apply(x, fb.out_norm.weight, fb.out_norm.bias, 1e-5, mask3.view(-1))
         return x, loss_ocfr
@@ -439,7 +444,7 @@ class EDITOR(nn.Module):
             args = _block_args(getattr(fb, "norm" + tag), getattr(fb, "attn" + tag), getattr(fb, "norm" + tag + "_"),
                                getattr(fb, "mlp" + tag))
             mods.append(fn.TransformerBlockFn.apply(xa_mod[i], *args, plan.mask_a, None,
-                                                    self.hma_heads, 1e-5, self.act_dtype, None, None, plan.cu, t,
+                                                    self.hma_heads, 1e-5, self.fn_dtype, None, None, plan.cu, t,
                                                     plan.live_a, None, self._sink("hma." + tag)))
         xa = torch.cat(mods, dim=0)
         loss_ocfr = None
@@ -449,7 +454,7 @@ class EDITOR(nn.Module):
         else:
             xb = fn.GatherRowsFn.apply(xa, plan.map_b, plan.live_a, nmod, plan.mb)
         xb = fn.TransformerBlockFn.apply(xb, *_block_args(fb.norm1, fb.attn1, fb.norm2, fb.mlp), plan.mask_b, None,
-                                         self.hma_heads, 1e-5, self.act_dtype, None, None, plan.cu3, nmod * t, plan.live_b,
+                                         self.hma_heads, 1e-5, self.fn_dtype, None, None, plan.cu3, nmod * t, plan.live_b,
                                          None, self._sink("hma.joint"))
         xb = fn.LayerNormFn.apply(xb, fb.out_norm.weight, fb.out_norm.bias, 1e-5, plan.mask_b, plan.live_b)
         pooled, num = fn.PoolPackedFn.apply(xb, plan.cu, b, nmod)

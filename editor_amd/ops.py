@@ -391,6 +391,71 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
         raise TypeError(a.dtype)
 
 
+# ---------------------------------------------------------------------------------------------
+# split-precision forward (COMPUTE_DTYPE 'f16x2'): operands travel as pairs of half tensors x = hi + lo
+# ---------------------------------------------------------------------------------------------
+SPLIT_WSCALE = 256.0          # power of two folded into the weight pairs (|w| ~ 0.02: keeps the low-order halves normal); the
+                              # products' alpha divides it out
+
+
+def split_f32(x, scale=1.0):
+    """fp32 tensor -> (hi, lo) half tensors of the same shape with hi + lo = x * scale to 2^-22."""
+    x = x.contiguous()
+    hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    call("editor_split_f32", x, hi, lo, x.numel(), float(scale))
+    return hi, lo
+
+
+def layernorm_fwd_split(x2d, gamma, beta, eps, rowmask=None, m_live=None):
+    m, d = x2d.shape
+    hi = torch.empty(m, d, dtype=torch.float16, device=x2d.device)
+    lo = torch.empty(m, d, dtype=torch.float16, device=x2d.device)
+    mean = torch.empty(m, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(m, dtype=torch.float32, device=x2d.device)
+    call("editor_layernorm_fwd_f16x2", x2d, gamma, beta, float(eps), m, d, rowmask, 0, hi, lo, mean, rstd, m_live)
+    return hi, lo, mean, rstd
+
+
+def im2col16_split(img):
+    imgs = list(img) if isinstance(img, (list, tuple)) else [img]
+    b, c, h, w = imgs[0].shape
+    rows = b * (h // 16) * (w // 16)
+    hi = torch.empty(len(imgs) * rows, c * 256, dtype=torch.float16, device=imgs[0].device)
+    lo = torch.empty_like(hi)
+    for i, im in enumerate(imgs):
+        if tuple(im.shape) != (b, c, h, w):
+            raise ValueError("im2col16: modality tensors of different shapes")
+        call("editor_im2col16_f16x2", im, b, c, h, w, _ptr(hi, i * rows * c * 256), _ptr(lo, i * rows * c * 256))
+    return hi, lo
+
+
+def gemm_split(a, b, c, c_lo, m, n, k, alpha=1.0, bias=None, rowscale=None, epilogue=0, aux=None, m_live=None):
+    """c (fp32, c_lo None) or (c, c_lo) half pair = alpha * (a_hi + a_lo)(b_hi + b_lo)^T (+bias) (*rowscale) (+epilogue);
+    a = (hi, lo) (M,K), b = (hi, lo) (N,K), all contiguous."""
+    if SHORT_TILES and m >= 2048 and n >= 512 and m_live is None and not (int(epilogue) & 0xF000):
+        th = gemm_tile_rows(m, n)
+        if th != 256:
+            epilogue = int(epilogue) | EPI_TILE_ROWS(th)
+    call("editor_gemm_f16x2", a[0], a[1], b[0], b[1], c, c_lo, 1 if c.dtype == torch.float32 else 0, m, n, k, k, k, n,
+         float(alpha), bias, rowscale, int(epilogue), aux, n, m_live)
+
+
+def attention_fwd_split(qkv, b, t, heads, hd, mask=None, probs=None, cu=None, scale=None):
+    """qkv = (hi, lo) half pair (rows, 3*heads*hd) -> (out_hi, out_lo), lse."""
+    hi, lo = qkv
+    d = heads * hd
+    rows = hi.shape[0]
+    scale = float(scale or hd ** -0.5)
+    alloc = torch.zeros if cu is not None else torch.empty
+    out_hi = alloc(rows, d, dtype=torch.float16, device=hi.device)
+    out_lo = alloc(rows, d, dtype=torch.float16, device=hi.device)
+    lse = torch.empty(heads * rows, dtype=torch.float32, device=hi.device)
+    call("editor_attention_fwd_f16x2", hi, lo, b, t, heads, hd, scale, mask, out_hi, out_lo, probs,
+         0 if probs is None else probs.shape[-1], lse, cu, rows)
+    return (out_hi, out_lo), lse
+
+
 def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True, cu=None, scale=None):
     """Attention / AttentionMask core on packed qkv (rows, 3*heads*hd) -> (rows, heads*hd).
     Dense: rows = b*t.  Variable length (compacted HMA): cu (b+1 int32) = packed row range of every sequence,

@@ -19,7 +19,7 @@ from . import _lib
 
 class FusedSGD:
     def __init__(self, named_params, base_lr=1e-3, weight_decay=1e-4, bias_lr_factor=2.0, weight_decay_bias=1e-4,
-                 momentum=0.9, shadow_bf16=True, shadow_dtype=None):
+                 momentum=0.9, shadow_bf16=True, shadow_dtype=None, split_pairs=False, check_overflow=None):
         self.params = [(n, p) for n, p in named_params if p.requires_grad]
         if not self.params:
             raise ValueError("FusedSGD: no trainable parameters")
@@ -80,6 +80,20 @@ class FusedSGD:
                             dst=torch.tensor([self.shadows_t[i].data_ptr() for i in tt], dtype=torch.int64, device=dev),
                             rows=i32([self.params[i][1].shape[0] for i in tt]), cols=i32([self.params[i][1].shape[1] for i in tt]),
                             tile_t=i32(tile_t), tile_r=i32(tile_r), tile_c=i32(tile_c), n=len(tile_t))
+        # split-precision weight pairs (COMPUTE_DTYPE 'f16x2'): hi / lo halves of w * ops.SPLIT_WSCALE for the forward products,
+        # refreshed by ONE launch after the update (editor_split_multi over the same chunk tables)
+        self.pairs = None
+        if split_pairs:
+            self.pairs = [(torch.empty(p.shape, dtype=torch.float16, device=dev), torch.empty(p.shape, dtype=torch.float16, device=dev))
+                          if p.dim() >= 2 else None for _, p in self.params]
+            self.hi_ptrs = torch.tensor([0 if pr is None else pr[0].data_ptr() for pr in self.pairs], dtype=torch.int64, device=dev)
+            self.lo_ptrs = torch.tensor([0 if pr is None else pr[1].data_ptr() for pr in self.pairs], dtype=torch.int64, device=dev)
+        # overflow protocol of amp.GradScaler.step (engine/processor.py:94-96): one pass over the gradients sets `_found`
+        # BEFORE the update, and the update kernel does nothing when it is set - parameters, momentum and shadows keep their
+        # values.  Default: on in f16 modes (half gradients can overflow), off for bf16 / fp32 (fp32 exponent range).
+        self.check_overflow = (shadow_dtype == torch.float16) if check_overflow is None else bool(check_overflow)
+        self._found = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.grad_scaler = None              # DeviceGradScaler.step() attaches itself: gradients then carry its loss scale
         self.p_ptrs = torch.tensor([p.data_ptr() for _, p in self.params], dtype=torch.int64, device=dev)
         self.m_ptrs = torch.tensor([b.data_ptr() for b in self.bufs], dtype=torch.int64, device=dev)
         # gradient tensors are new every step: their addresses go to the device through double-buffered pinned staging
@@ -128,8 +142,9 @@ class FusedSGD:
 
     def found_inf(self, reset=True):
         """True if any step since the last reset saw an inf / nan gradient (synchronises: call it every N steps, as the
-        reference's GradScaler bookkeeping does once per step, engine/processor.py:95-96).  The update is NOT skipped:
-        lower cfg.MODEL.GRAD_SCALE and restart from the last checkpoint."""
+        reference's GradScaler bookkeeping does once per step, engine/processor.py:95-96).  Such a step was SKIPPED on the
+        device (check_overflow): nothing was written.  With the static in-backward scale (cfg.MODEL.GRAD_SCALE) halve it
+        on a hit; a DeviceGradScaler backs its own scale off without the host."""
         bad = bool(self._nonfinite.item())
         if reset:
             self._nonfinite.zero_()
@@ -199,10 +214,23 @@ class FusedSGD:
         dev_tab.copy_(host, non_blocking=True)
         # momentum buffers start at zero, so mu*0 + g' == g' reproduces torch's first-step `buf = clone(g')` exactly
         # without a "first step" flag (a flag passed by value would be baked into a captured graph)
+        sc = self.grad_scaler
+        check = self.check_overflow or sc is not None
         with torch.cuda.device(self.device):
+            if check:
+                found = sc._found if sc is not None else self._found
+                if sc is None:
+                    self._found.zero_()              # (the scaler's update kernel clears its own flag)
+                _lib.call("editor_grad_check_multi", dev_tab, self.chunk_t, self.chunk_o, self.numel, self.nchunks, found,
+                          self._nonfinite)
             _lib.call("editor_sgd_multi", self.p_ptrs, dev_tab, self.m_ptrs, self.chunk_t, self.chunk_o, self.numel,
                       self.lr, self.wd, float(self.momentum), self.nchunks, self.h_ptrs,
-                      2 if self.shadow_dtype == torch.float16 else 1, self._nonfinite)
+                      2 if self.shadow_dtype == torch.float16 else 1, None if check else self._nonfinite,
+                      sc._inv_scale if sc is not None else None, found if check else None)
+            if self.pairs is not None:
+                from . import ops
+                _lib.call("editor_split_multi", self.p_ptrs, self.hi_ptrs, self.lo_ptrs, self.chunk_t, self.chunk_o, self.numel,
+                          self.nchunks, float(ops.SPLIT_WSCALE))
         if not capturing:
             self._ev[k] = torch.cuda.Event()
             self._ev[k].record()
@@ -220,3 +248,62 @@ class FusedSGD:
                                              if h is not None and p.grad is not None)
             functional.install_weight_copies(((p, h) for (_, p), h in zip(self.params, self.shadows_t)
                                               if h is not None and p.grad is not None), transposed=True)
+        if self.pairs is not None:
+            functional.install_weight_pairs((p, pr[0], pr[1]) for (_, p), pr in zip(self.params, self.pairs) if pr is not None)
+
+
+class DeviceGradScaler:
+    """torch.cuda.amp.GradScaler (engine/processor.py:60,94-96) with its whole state on the device, so that a step using it
+    can be captured into a hipGraph and replayed: no `.item()`, no host branch.
+
+        scaler = DeviceGradScaler(device)            # init_scale 2**15, growth 2, backoff 0.5, growth_interval 2000
+        scaler.scale(loss).backward()                # loss * scale (a device scalar): gradients come out scaled
+        scaler.step(optimizer)                       # FusedSGD: overflow check -> unscale + update, or nothing
+        scaler.update()                              # overflow: scale *= backoff; else every growth_interval steps *= growth
+
+    Use it with cfg.MODEL.GRAD_SCALE = 1 (the static in-backward scale of editor_amd.functional off): the loss scale then
+    rides through the backward exactly as the reference's does."""
+
+    def __init__(self, device, init_scale=2.0 ** 15, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self.device = torch.device(device)
+        self._scale = torch.full((1,), float(init_scale), dtype=torch.float32, device=self.device)
+        self._inv_scale = torch.full((1,), 1.0 / float(init_scale), dtype=torch.float32, device=self.device)
+        self._tracker = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._found = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self.enabled = enabled
+
+    def scale(self, loss):
+        return loss * self._scale.to(loss.dtype).view(()) if self.enabled else loss
+
+    def step(self, optimizer):
+        if not self.enabled:
+            return optimizer.step()
+        if not isinstance(optimizer, FusedSGD):
+            raise TypeError("DeviceGradScaler drives editor_amd.optim.FusedSGD (its update kernel unscales and skips on the device)")
+        optimizer.grad_scaler = self
+        try:
+            optimizer.step()
+        finally:
+            optimizer.grad_scaler = None
+
+    def update(self):
+        if self.enabled:
+            with torch.cuda.device(self.device):
+                _lib.call("editor_scaler_update", self._scale, self._inv_scale, self._tracker, self._found, self.growth_factor,
+                          self.backoff_factor, self.growth_interval)
+
+    def get_scale(self):
+        """Host copy of the scale (synchronises; logging only)."""
+        return float(self._scale.item())
+
+    def state_dict(self):
+        return {"scale": self.get_scale(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(self._tracker.item())}
+
+    def load_state_dict(self, sd):
+        self._scale.fill_(float(sd["scale"]))
+        self._inv_scale.fill_(1.0 / float(sd["scale"]))
+        self._tracker.fill_(int(sd.get("_growth_tracker", 0)))
+        self.growth_factor, self.backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
+        self.growth_interval = int(sd["growth_interval"])

@@ -42,7 +42,7 @@ def make_optimizer(cfg, model, center_criterion=None):
                                   "configs/*/EDITOR.yml OPTIMIZER_NAME: 'SGD'); got %r" % (name,))
     opt = FusedSGD(model.named_parameters(), base_lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY,
                    bias_lr_factor=s.BIAS_LR_FACTOR, weight_decay_bias=s.WEIGHT_DECAY_BIAS, momentum=s.MOMENTUM,
-                   shadow_dtype=_shadow_dtype(model))
+                   shadow_dtype=_shadow_dtype(model), split_pairs=bool(getattr(getattr(model, "module", model), "split_fwd", False)))
     for g, (n, lr, wd) in zip(opt.param_groups, param_group_table(cfg, [g["name"] for g in opt.param_groups])):
         g["lr"], g["weight_decay"] = lr, wd
     opt.sync_param_groups()

@@ -19,6 +19,9 @@ typedef struct ihipStream_t* editor_stream_t;
 int editor_probe_tr16(const int* addr, uint16_t* out, editor_stream_t stream);
 /* lane -> element maps of v_mfma_f32_16x16x32_bf16: D (16x16) = A (16x32) B (32x16), operands given as fp32 */
 int editor_probe_mfma16(const float* A, const float* B, float* D, editor_stream_t stream);
+/* D (16x16 fp32) = A (16x32) B (32x16) with the operands given as RAW 16-bit patterns (f16 != 0: IEEE half, else bf16):
+ * pins the matrix core's treatment of subnormal half operands (tests/test_gpu_kernels.py) */
+int editor_probe_mfma16_raw(const uint16_t* A, const uint16_t* B, float* D, int f16, editor_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

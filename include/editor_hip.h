@@ -125,6 +125,15 @@ int editor_cast_rows_colsum(const float* in, const float* rowscale, long M, int 
                             editor_stream_t stream);
 int editor_cast_bf16_to_f32(const uint16_t* in, float* out, long n, editor_stream_t stream);
 
+/* split-precision producers (COMPUTE_DTYPE 'f16x2'): the same kernels writing x as the half pair hi = half(x),
+ * lo = half(x - hi).  editor_split_f32: a flat fp32 tensor times a power-of-two scale (n % 4 == 0). */
+int editor_layernorm_fwd_f16x2(const float* x, const float* gamma, const float* beta, float eps, long M, int D,
+                               const uint8_t* rowmask, int mask_period, uint16_t* y_hi, uint16_t* y_lo, float* mean,
+                               float* rstd, const int* m_live, editor_stream_t stream);
+int editor_im2col16_f16x2(const float* img, int B, int C, int H, int W, uint16_t* out_hi, uint16_t* out_lo,
+                          editor_stream_t stream);
+int editor_split_f32(const float* in, uint16_t* hi, uint16_t* lo, long n, float scale, editor_stream_t stream);
+
 /* PatchEmbed_overlap with stride == patch == 16 (vit_pytorch.py:449-458): im2col rows (b*N+p), cols (c,i,j). */
 int editor_im2col16(const float* img, int B, int C, int H, int W, void* out, int out_bf16, editor_stream_t stream);
 /* cls token + pos_embed + SIE_COE * sie_embed[cam] (vit_pytorch.py:627-637).  Btot samples may hold several
@@ -169,6 +178,22 @@ int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, i
                      float* splitk_ws /* splitk*M*N floats or NULL (then split-K uses fp32 atomics) */,
                      const int* m_live /* see below */, editor_stream_t stream);
 
+/* Split-precision forward product (COMPUTE_DTYPE 'f16x2'; replaces the fp32 F.linear of vit_pytorch.py:139-145,184-198 at
+ * fp32-class accuracy on the half matrix cores): every operand is a PAIR of half matrices x = hi + lo of the same shape
+ * and leading dimension (A (M,K), B (N,K) = nn.Linear layout, both k-major);
+ *     C = alpha * (A_hi B_hi^T + A_lo B_hi^T + A_hi B_lo^T) (+bias) (*rowscale)   [lo.lo, 2^-22 relative, is dropped]
+ * accumulated in ONE fp32 accumulator over three passes of the K loop.  c_f32 != 0: C fp32 (C_lo NULL; epilogue NONE or
+ * RESIDUAL with aux = fp32 residual); c_f32 == 0: the result leaves as a pair again, C = half(v), C_lo = half(v - C)
+ * (epilogue NONE, or GELU | AUX_GRAD: v = exact-erf gelu of the UNROUNDED pre-activation x, aux = half(gelu'(x)) for the
+ * 16-bit backward).  K % 64 == 0, N % 8 == 0, lda / ldb / ldc / ldaux multiples of 8; m_live as below.
+ * EDITOR_EPI_TILE_ROWS(208) selects the short tiles.  Half keeps SUBNORMAL low-order parts (pinned by
+ * tests/test_gpu_select.py::test_probe_mfma_f16_keeps_subnormal_operands); weights are handed over pre-scaled by a
+ * power of two (editor_split_f32 / editor_split_multi) with alpha carrying its inverse. */
+int editor_gemm_f16x2(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi, const uint16_t* B_lo, void* C,
+                      void* C_lo, int c_f32, int M, int N, int K, long lda, long ldb, long ldc, float alpha,
+                      const float* bias, const float* rowscale, int epilogue, void* aux, long ldaux, const int* m_live,
+                      editor_stream_t stream);
+
 /* the same contraction on IEEE-half operands (v_mfma_f32_16x16x32_f16): C half or fp32 */
 int editor_gemm_f16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda, long ldb,
                     long ldc, int transA, int transB, float alpha, float beta, const float* bias,
@@ -210,6 +235,16 @@ int editor_attention_fwd_bf16(const uint16_t* qkv, int B, int T, int heads, int 
 int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, int B,
                               int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv,
                               float* workspace, const int* cu, long Mtot, editor_stream_t stream);
+/* Split-precision attention forward (COMPUTE_DTYPE 'f16x2'): q, k, v as half pairs qkv = qkv_hi + qkv_lo (both (rows,
+ * 3*heads*64), the split output of the qkv product); every contraction is three half MFMAs into one fp32 accumulator
+ * (S = Q_lo K_hi + Q_hi K_lo + Q_hi K_hi; O likewise on the 2^12-scaled probability pair), the softmax is the reference's
+ * fp32 exp(s - max) / sum (vit_pytorch.py:184-198,240-258).  out_hi / out_lo: the output as a half pair (operand of the proj
+ * product); probs (optional, dense form only): fp32 softmax rows for the rollout (:638-644); lse: for
+ * editor_attention_bwd_f16, which runs on the hi halves.  Any T (<= 288 tokens: whole sequence in LDS; longer: 128-key
+ * chunks); mask / cu / Mtot as editor_attention_fwd_bf16. */
+int editor_attention_fwd_f16x2(const uint16_t* qkv_hi, const uint16_t* qkv_lo, int B, int T, int heads, int hd, float scale,
+                               const uint8_t* mask, uint16_t* out_hi, uint16_t* out_lo, float* probs, int ldp, float* lse,
+                               const int* cu, long Mtot, editor_stream_t stream);
 int editor_attention_fwd_f16(const uint16_t* qkv, int B, int T, int heads, int hd, float scale, const uint8_t* mask,
                              uint16_t* out, float* probs, int ldp, float* lse, const int* cu, long Mtot,
                              editor_stream_t stream);
@@ -320,7 +355,23 @@ int editor_sgd_multi(float* const* p_ptrs, const float* const* g_ptrs, float* co
                      const long* chunk_off, const long* numel, const float* lr, const float* wd, float momentum,
                      long nchunks, uint16_t* const* h_ptrs, int shadow_dtype,
                      int* nonfinite /* device flag, OR-ed with 1 when a gradient element is inf / nan; may be NULL */,
+                     const float* inv_scale /* device scalar multiplied into every gradient (1 / loss scale); NULL = 1 */,
+                     const int* skip /* device flag: nonzero -> the whole update is skipped (GradScaler.step); NULL = never */,
                      editor_stream_t stream);
+/* amp.GradScaler's overflow check (engine/processor.py:94-96 -> torch/amp/grad_scaler.py): found[0] |= 1 (and sticky[0] |= 1,
+ * optional) when any gradient element of the tensors in the chunk tables is inf / nan.  Run BEFORE editor_sgd_multi with
+ * skip = found. */
+int editor_grad_check_multi(const float* const* g_ptrs, const int* chunk_tensor, const long* chunk_off, const long* numel,
+                            long nchunks, int* found, int* sticky, editor_stream_t stream);
+/* amp.GradScaler.update on device-resident state (hipGraph-replay safe): found -> scale *= backoff, tracker = 0; else
+ * tracker += 1 and every `interval` clean steps scale *= growth.  Refreshes inv_scale = 1 / scale and clears found. */
+int editor_scaler_update(float* scale, float* inv_scale, int* tracker, int* found, float growth, float backoff,
+                         int interval, editor_stream_t stream);
+/* split-precision weight operands of COMPUTE_DTYPE 'f16x2' for a table of fp32 tensors in one launch (same chunk tables as
+ * editor_sgd_multi): hi[t] = half(p[t] * scale), lo[t] = half(p[t] * scale - hi[t]); hi_ptrs[t] == NULL skips tensor t. */
+int editor_split_multi(const float* const* p_ptrs, uint16_t* const* hi_ptrs, uint16_t* const* lo_ptrs,
+                       const int* chunk_tensor, const long* chunk_off, const long* numel, long nchunks, float scale,
+                       editor_stream_t stream);
 /* dst[t] (cols x rows) = transpose of src[t] (rows x cols), 16-bit elements, for a table of tensors in ONE launch: the
  * k-major copies W^T of the nn.Linear weights that the dgrad products read (both dims multiples of 64).  Tables are
  * device arrays; tile i is the 64x64 tile (tile_r[i], tile_c[i]) of tensor tile_tensor[i]. */

@@ -121,3 +121,28 @@ def test_rollout_recomputed_from_qk_matches_materialised(t):
     k = 2
     same = (got.topk(k, dim=-1).indices.sort(-1).values == ref.topk(k, dim=-1).indices.sort(-1).values).all(-1)
     assert same.float().mean().item() > 0.98                      # selections agree except on near-ties
+
+
+@pytest.mark.gpu
+def test_probe_mfma_f16_keeps_subnormal_operands():
+    """The split-precision forward (COMPUTE_DTYPE 'f16x2') keeps low-order parts of its operands in IEEE half, where small
+    ones are SUBNORMAL (|x| < 2^-14): pins that v_mfma_f32_16x16x32_f16 multiplies them exactly instead of flushing."""
+    from editor_amd import _lib
+    a = torch.zeros(16, 32, dtype=torch.float16)
+    b = torch.zeros(32, 16, dtype=torch.float16)
+    a[:, 0] = 2.0 ** -20                    # subnormal half (min normal 2^-14, min subnormal 2^-24)
+    a[:, 1] = 2.0 ** -24
+    a[:, 2] = 3 * 2.0 ** -24
+    b[0, :] = 1024.0
+    b[1, :] = 2.0 ** 14
+    b[2, :] = 2.0 ** -24                    # subnormal x subnormal: 3 * 2^-48, representable in the fp32 accumulator
+    exp = (a.double() @ b.double()).float()
+    assert exp[0, 0] > 0
+    d = torch.zeros(16, 16, device="cuda")
+    ag, bg = a.view(torch.int16).cuda(), b.view(torch.int16).cuda()
+    rc = _lib.probe_lib().editor_probe_mfma16_raw(ctypes.c_void_p(ag.data_ptr()), ctypes.c_void_p(bg.data_ptr()),
+                                                  ctypes.c_void_p(d.data_ptr()), 1,
+                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    print("mfma f16 subnormal probe:", d[0, 0].item(), "expected", exp[0, 0].item())
+    assert torch.equal(d.cpu(), exp), "the matrix core flushes subnormal half operands"
