@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py - tri-modal images/sec, forward+backward+optimizer step, of the EDITOR hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|f16|f32] [--preset RGBNT201|RGBNT100|MSVR310|SYNTH4L]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|f16|f16x2|f32] [--preset RGBNT201|RGBNT100|MSVR310|SYNTH4L]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,17 +10,23 @@ Workload (BASELINE.json configs[1]): RGBNT201 cfg, 3 modalities, ViT-B/16, 256x1
 weights of the real architecture.  A "step" is what engine/processor.py:70-107 does per batch:
 zero_grad -> forward -> loss (pairs + aux) -> backward (+ gradient all-reduce, overlapped) -> SGD step.
 
-`value` (the headline): inputs resident in HBM, K steps between two synchronisations (the contract of this file).
-`with_h2d_sync`: the same step fed the way the reference's loop feeds it (processor.py:73-78,107): pinned double-buffered
-host batches copied to the device every step and a device synchronisation per iteration (N = 1 only).
+`value` (the headline) is the reference's own throughput definition (engine/processor.py:107,114-118): B / mean
+seconds per iteration of a loop that hands every step its batch from pinned host memory (processor.py:73-78; the copy of
+batch i+1 is pipelined under step i, as a prefetching loader does) and synchronises the device every iteration; K iterations
+between a barrier + synchronize on both sides, MAX over ranks.  `replay_only`: the bare step beside it (inputs resident,
+one synchronisation at the end; N = 1 only).
 
 One JSON line on rank 0.
   roofline      the dominant kernel family (16-bit MFMA GEMM): algorithmic FLOPs of every launch of one step / their
                 HIP-event durations (replayed back to back after the timed region), against the 2.5 PFLOP/s dense peak;
                 `traffic` = HBM bytes per step of those launches from the committed PMC profile of the same command
-                (profiles/r02_pmc_traffic.json, tools/pmc_traffic.sh), null when absent;
+                (profiles/r03_pmc_traffic.json, tools/pmc_traffic.sh), null when absent; `step_frac` = SURVEY.md 8(d)'s
+                algorithmic FLOPs of the WHOLE step / ms_per_step / peak;
                 `hbm_kernels` = the memory-bound select / gather / normalisation kernels timed live with HIP events
                 against the 8 TB/s HBM peak (algorithmic bytes).
+  modes         every compute mode beside the benchmarked one - bf16, f16, f16x2 (split-precision forward), f32 (exact-f32
+                parity mode): images/sec of the same timed loop (child process each) AND its accuracy against the oracle
+                (cls4t relative error, token-selection agreement), so the speed is never read without the parity it buys.
   cpu_baseline  the oracle (CPU restatement pinned to the reference) timed on this host's cores: the same step at B=128
                 (1 warm-up + 3 timed iterations: forward, the reference's loss, backward, SGD) and config 1 (`c1`: B=32,
                 RGB only, backbone forward).  N = 1 only.
@@ -179,6 +185,79 @@ def hbm_kernels(model, img, b, act_dtype):
     return out
 
 
+def mode_accuracy(preset, dtypes, batch=16, seed=31):
+    """Accuracy of every compute mode beside its speed: eval forward of `batch` tri-modal samples against the oracle
+    (oracle/editor_ref.py, pinned to the reference by tests/golden) - selection agreement free-running, `cls4t` relative
+    error with the oracle's selection teacher-forced (the protocol of tests/test_gpu_fullsize.py; north_star: indices
+    bit-identical, features within 1e-3)."""
+    import contextlib
+    import io
+    from oracle import editor_ref as oracle
+    from editor_amd import config, synth
+    from editor_amd.modeling import make_model
+    torch.set_num_threads(_usable_cores())
+    cfg, c, cams = config.preset(preset, drop_path=0.0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m0 = make_model(cfg, c, cams)
+    synth.fill_state_dict_(m0.state_dict(), seed)
+    sd = {k: v.clone() for k, v in m0.state_dict().items()}
+    h, w = cfg.INPUT.SIZE_TRAIN
+    img, label, cam, view = synth.make_batch(seed + 1, batch, h, w, cams, instances=2)
+    with torch.no_grad():
+        ref, aux = oracle.editor_forward(sd, img, cam, training=False, al=cfg.MODEL.AL, return_aux=True)
+    gimg = {k: v.cuda() for k, v in img.items()}
+    res = {}
+    for dt in dtypes:
+        cfg_d, c, cams = config.preset(preset, compute_dtype=dt, drop_path=0.0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = make_model(cfg_d, c, cams)
+        m.load_state_dict(sd)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            m(gimg, cam_label=cam.cuda(), view_label=view.cuda())
+            got = m.last_aux
+            rows = [(got["attn_masks"][i].cpu().bool() == aux["attn_masks"][i]).all(dim=1).float().mean().item() for i in range(3)]
+            same = torch.equal(got["index"].cpu().bool(), aux["index"])
+            m.teacher_index = aux["index"]
+            out = m(gimg, cam_label=cam.cuda(), view_label=view.cuda())
+        err = ((out.cpu().double() - ref.double()).norm() / ref.double().norm()).item()
+        res[dt] = {"cls4t_rel_err": float("%.3g" % err), "selection_rows_identical": round(min(rows), 4),
+                   "index_bit_identical": bool(same)}
+        del m
+        torch.cuda.empty_cache()
+    return res, batch
+
+
+def modes_block(args, cfg, cams, own_value):
+    """{mode: img/s (the same timed loop, in a child process per mode) + accuracy vs the oracle}."""
+    import subprocess
+    modes = ["bf16", "f16", "f16x2", "f32"]
+    acc, nb = mode_accuracy(args.preset, modes)
+    out = {"accuracy_sample": f"eval forward, B={nb}, {args.preset}, vs the oracle on the host cores; cls4t with the oracle's "
+                              "selection teacher-forced, selection free-running (rows = (sample, modality) attention masks)"}
+    for dt in modes:
+        entry = dict(acc[dt])
+        if dt == args.dtype:
+            entry["value"] = own_value
+        else:
+            steps, warm = (3, 1) if dt == "f32" else (args.steps, args.warmup)
+            cmd = [sys.executable, os.path.abspath(__file__), "--dtype", dt, "--preset", args.preset, "--batch", str(args.batch),
+                   "--steps", str(steps), "--warmup", str(warm), "--graph", "--no-cpu-baseline", "--no-replay", "--no-modes"]
+            if args.no_h2d:
+                cmd.append("--no-h2d")
+            try:
+                cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+                j = json.loads(lines[-1])
+                entry["value"] = j["value"]
+                entry["ms_per_step"] = j["ms_per_step"]
+            except Exception as e:                       # a mode that fails to run is reported, not hidden
+                entry["value"] = None
+                entry["error"] = type(e).__name__
+        out[dt] = entry
+    return out
+
+
 def _usable_cores():
     """Cores this process may really use: affinity mask, capped by the cgroup CPU quota (a container that
     reports 256 logical CPUs but is throttled to a few thrashes when handed 256 threads)."""
@@ -260,7 +339,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="time a hipGraph replay of the captured step in THIS process")
     ap.add_argument("--no-graph", action="store_true", help="time the eager step (no hipGraph attempt)")
     ap.add_argument("--no-replay", action="store_true", help="skip the GEMM replay / kernel micro-timings (clean rocprof totals)")
-    ap.add_argument("--no-h2d", action="store_true", help="skip the second timed variant (H2D copy + per-step sync)")
+    ap.add_argument("--no-h2d", action="store_true", help="time the bare step instead of the reference loop's feeding (no H2D, no per-step sync)")
+    ap.add_argument("--no-modes", action="store_true", help="skip the per-mode block (speed + accuracy of bf16 / f16 / f16x2 / f32)")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 32 if args.preset == "SYNTH4L" else 128
@@ -393,59 +473,72 @@ def main():
         if okf.item() < 0.5 and graph is not None:
             graph = None
             probe.calls = []
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if graph is not None:
-            graph.replay()
-            loss = static_loss
-        else:
-            probe.recording = rank == 0 and i == args.steps - 1
-            loss = step()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # ---- timed region (SURVEY.md 8(d) = the reference's own log line, engine/processor.py:107,114-118): every iteration
+    # receives its batch from pinned host memory (:73-78: the image tensors and labels go to the device every iteration) and
+    # ends with a device synchronisation; throughput = B / mean seconds per iteration.  The copy is pipelined the way a
+    # prefetching loader does it: batch i+1 travels host -> device staging on a copy stream while step i runs, and a
+    # device-to-device copy moves it into the step's (static, graph-captured) input tensors.  K copies of 151 MB and K
+    # synchronisations are inside the timed region.  --no-h2d times the bare step (inputs resident, one sync at the end).
+    feed = not args.no_h2d
+    if feed:
+        pins = [{k: v.clone().pin_memory() for k, v in img_h.items()} for _ in range(2)]
+        lab_pin = [t_.cpu().clone().pin_memory() for t_ in (label, cam, view)]
+        stage = [({k: torch.empty_like(v) for k, v in img.items()}, [torch.empty_like(t_) for t_ in (label, cam, view)])
+                 for _ in range(2)]
+        copy_s = torch.cuda.Stream()
+
+        def prefetch(i):                                  # host -> staging[i & 1] on the copy stream
+            with torch.cuda.stream(copy_s):
+                for k in img:
+                    stage[i & 1][0][k].copy_(pins[i & 1][k], non_blocking=True)
+                for dst, src in zip(stage[i & 1][1], lab_pin):
+                    dst.copy_(src, non_blocking=True)
+
+        def take(i):                                      # staging[i & 1] -> the step's inputs, on the main stream
+            torch.cuda.current_stream().wait_stream(copy_s)
+            for k in img:
+                img[k].copy_(stage[i & 1][0][k], non_blocking=True)
+            for dst, src in zip((label, cam, view), stage[i & 1][1]):
+                dst.copy_(src, non_blocking=True)
+
+    def timed_loop(feeding):
+        if feeding:
+            prefetch(0)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss_ = None
+        for i in range(args.steps):
+            if feeding:
+                take(i)
+                prefetch(i + 1)                           # next batch under this step (staging[(i+1)&1] was consumed at i-1)
+            if graph is not None:
+                graph.replay()
+                loss_ = static_loss
+            else:
+                probe.recording = rank == 0 and i == args.steps - 1 and not probe.calls
+                loss_ = step()
+                probe.recording = False
+            if feeding:
+                torch.cuda.synchronize()                  # engine/processor.py:107
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el_ = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(el_, op=dist.ReduceOp.MAX)
+        return float(el_.item()), loss_
+
+    elapsed, loss = timed_loop(feed)
+    replay_only = None
+    if feed and world == 1 and not force_ddp:            # the bare step beside it (inputs resident, no per-iteration sync)
+        el2, _ = timed_loop(False)
+        replay_only = {"value": round(b * args.steps / el2, 2), "ms_per_step": round(1e3 * el2 / args.steps, 3),
+                       "what": "same K steps with the inputs resident in HBM and one synchronisation at the end"}
     probe.recording = False
     probe.remove()
     lossv = float(loss.detach())
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-
-    # ---- second timed variant: the reference loop's feeding (processor.py:73-78: H2D copy of the image tensors and labels
-    # every iteration; :107: a device synchronisation per iteration) - pinned double-buffered host batches, copy on a side
-    # stream into the (static) device inputs, the step, a sync.  Throughput = B / mean seconds per iteration (:114-118).
-    h2d = None
-    if world == 1 and not args.no_h2d and not force_ddp:
-        pins = [{k: v.clone().pin_memory() for k, v in img_h.items()} for _ in range(2)]
-        lab_pin = [t_.cpu().clone().pin_memory() for t_ in (label, cam, view)]
-        copy_s = torch.cuda.Stream()
-        times = []
-        for i in range(args.steps + 1):
-            t1 = time.perf_counter()
-            copy_s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(copy_s):
-                for k in img:
-                    img[k].copy_(pins[i & 1][k], non_blocking=True)
-                for dst, src in zip((label, cam, view), lab_pin):
-                    dst.copy_(src, non_blocking=True)
-            torch.cuda.current_stream().wait_stream(copy_s)
-            if graph is not None:
-                graph.replay()
-            else:
-                step()
-            torch.cuda.synchronize()
-            if i:                                                    # first iteration untimed
-                times.append(time.perf_counter() - t1)
-        mean_t = sum(times) / len(times)
-        h2d = {"value": round(b / mean_t, 2), "ms_per_step": round(1e3 * mean_t, 3),
-               "h2d_mb_per_step": round(sum(v.numel() * 4 for v in img_h.values()) / 1e6, 1),
-               "what": "pinned double-buffered H2D of the image tensors + labels every step, device sync per iteration "
-                       "(engine/processor.py:73-78,107); images/sec = B / mean s per iteration (:114-118)"}
 
     if rank == 0:
         kinds = {} if args.no_replay else probe.replay()
@@ -456,7 +549,9 @@ def main():
         ms_step = 1e3 * elapsed / args.steps
         arch = cfg.MODEL.TRANSFORMER_TYPE.replace("_patch16_224", "").replace("vit_", "ViT-").replace("base", "B").replace("large", "L")
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(tpath) and args.preset == "RGBNT201" and b == 128 and args.dtype == "bf16":
             try:
                 traffic = json.load(open(tpath))
@@ -467,12 +562,19 @@ def main():
                 "traffic": None if traffic is None else traffic.get("gemm_hbm_bytes_per_step"),
                 "traffic_note": None if traffic is None else traffic.get("note"),
                 "kernel": "16-bit GEMM family: gemm_bf16_pp_kernel (256x256x64 ping-pong; fwd, dgrad, and wgrad as one round of "
-                          "split-K workgroups + slab reduction), v_mfma_f32_16x16x32_" + ("f16" if args.dtype == "f16" else "bf16"),
+                          "split-K workgroups + slab reduction), v_mfma_f32_16x16x32_" + ("bf16" if args.dtype == "bf16" else "f16") +
+                          ("; forward products as split-precision half pairs (3 MFMA passes per algorithmic FLOP)" if args.dtype == "f16x2" else ""),
                 "launches_per_step": launches, "gemm_ms_per_step": round(ms, 3),
                 "alg_tflop_per_step": round(flops / 1e12, 2),
                 "alg_bytes_per_step": None if traffic is None else traffic.get("gemm_alg_bytes_per_step"),
                 "by_kind": {k: {"tflops": round(f / (m_ * 1e-3) / 1e12, 1), "ms_per_step": round(m_, 3), "launches": n}
                             for k, (f, m_, n) in kinds.items()}}
+        # whole-step view: SURVEY.md 8(d)'s algorithmic FLOPs of one step (240.5 GF per tri-modal 256x128 ViT-B image fwd+bwd,
+        # scaled by tokens / width for the other presets through the measured GEMM list when available) over the step time
+        alg_step = {"RGBNT201": 240.5e9, "RGBNT100": 240.5e9, "MSVR310": 368e9}.get(args.preset)
+        if alg_step is not None:
+            roof["step_alg_tflop"] = round(alg_step * b / 1e12, 2)
+            roof["step_frac"] = round(alg_step * b / (ms_step * 1e-3) / 1e12 / PEAK_TFLOPS, 4)
         if args.dtype == "f32":
             roof.update(bound="mfma (exact-f32 parity mode: v_mfma_f32_16x16x4_f32; not the performance path)",
                         achieved=None, frac=None, peak=PEAK_F32_TFLOPS)
@@ -481,6 +583,9 @@ def main():
         out = {
             "metric": "tri-modal images/sec fwd+bwd @ B=128 ViT-B",
             "value": round(world * b * args.steps / elapsed, 2),
+            "value_definition": ("B / mean seconds per iteration of the reference's loop (engine/processor.py:73-78,107,114-118): "
+                                 "H2D of the batch every iteration (pipelined) + the step + a device sync per iteration")
+            if feed else "bare step: inputs resident, one synchronisation after K steps",
             "unit": "tri-modal images/sec" if nmod == 3 else f"{nmod}-modal images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3),
@@ -494,8 +599,10 @@ def main():
                        "grad_buckets": None if buckets is None else buckets.describe()},
             "roofline": roof,
         }
-        if h2d is not None:
-            out["with_h2d_sync"] = h2d
+        if replay_only is not None:
+            out["replay_only"] = replay_only
+        if world == 1 and not args.no_modes and not force_ddp and args.preset in ("RGBNT201", "RGBNT100", "MSVR310"):
+            out["modes"] = modes_block(args, cfg, cams, out["value"])
         if world == 1 and not args.no_cpu_baseline and not force_ddp:
             out["cpu_baseline"] = cpu_baseline(model, cfg, cams, b, args.cpu_iters)
     if use_dist:
