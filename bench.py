@@ -414,6 +414,8 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
+        if buckets is not None:
+            buckets.broadcast_buffers(model)       # DDP's per-forward broadcast_buffers (train_net.py:63-64: the default)
         out = model(img, label=label, cam_label=cam, view_label=view, img_path=None, writer=writer, epoch=1)
         loss = losses.loss_pairs(out, label)
         loss.backward()

@@ -164,8 +164,9 @@ class BlockSink:
     """Where one transformer block's backward (editor_amd.functional.TransformerBlockFn) writes its 12 parameter
     gradients: views of a flat bucket, in forward-argument order (None for absent biases)."""
 
-    def __init__(self, owner, seg, views):
+    def __init__(self, owner, seg, views, params=None):
         self.owner, self.seg, self.views = owner, seg, views
+        self.params = params if params is not None else [None] * len(views)
 
     def ln_pair(self, i):
         """(2, D) view over the adjacent [weight | bias] gradient slots of a LayerNorm (slots i, i + 1)."""
@@ -176,6 +177,12 @@ class BlockSink:
         return torch.as_strided(w, (2, w.numel()), (w.numel(), 1))
 
     def done(self):
+        # The backward WROTE the slots (it hands autograd None for these parameters): make sure every parameter's .grad
+        # still IS its slot - nn.Module.zero_grad() / `p.grad = None` by foreign code would otherwise leave .grad None and
+        # the optimizer would silently skip 99 % of the weights.
+        for p, v in zip(self.params, self.views):
+            if p is not None and (p.grad is None or p.grad.data_ptr() != v.data_ptr()):
+                p.grad = v
         self.owner.segment_done(self.seg)
 
 
@@ -235,16 +242,24 @@ class GradBuckets:
                     p.grad = v                       # the parameter's gradient IS the bucket slot, permanently
                     p._grad_sink = v                 # (FusedSGD.zero_grad restores it instead of dropping it)
                     views.append(v)
-                self.sinks[si] = BlockSink(self, si, views)
+                self.sinks[si] = BlockSink(self, si, views, list(segments[si][1]))
                 self.seg_bucket[si] = bi
             self.buckets.append(dict(flat=flat, segs=segs, pending=len(segs), work=None))
-        self._tail = None                 # (flat, views, params) built at the first finish()
+        self._tail = None                 # (flat, views, params, key) of the tail parameters that carry a gradient
         self._inflight = []
+        self._written = set()             # segments whose slots were written since the last finish()
 
     def sink(self, seg_index):
         return self.sinks[seg_index]
 
     def segment_done(self, si):
+        # The slots are OVERWRITTEN by a backward, not accumulated into: a second backward before finish() / the optimizer
+        # step (gradient accumulation, two forwards per step) would silently keep only the last micro-batch.
+        if si in self._written:
+            raise RuntimeError("GradBuckets: segment %r was written twice before finish() - gradient accumulation is not "
+                               "supported with in-place gradient buckets (call finish() + optimizer.step() per backward)"
+                               % (self.segments[si][0],))
+        self._written.add(si)
         b = self.buckets[self.seg_bucket[si]]
         b["pending"] -= 1
         if b["pending"] == 0:
@@ -260,20 +275,30 @@ class GradBuckets:
     @torch.no_grad()
     def finish(self):
         """After loss.backward(): exchange the tail parameters and wait for every bucket (stream-level wait on RCCL)."""
+        self._written.clear()
         if not self.active:
             return
-        if self._tail is None:
-            live = [p for p in self.tail_params if p.grad is not None]
-            flat = torch.zeros(sum(p.numel() for p in live), dtype=torch.float32, device=live[0].device)
+        # tail = the small parameters that carry a gradient THIS step (never-used ones - BACKBONE.base.fc, the head cfg.MODEL.AL
+        # does not select - have none).  The set is re-checked every step outside a capture, so a parameter that starts
+        # receiving gradients later is exchanged too; inside a captured graph the set is fixed by construction.
+        capturing = self.tail_params and self.tail_params[0].is_cuda and torch.cuda.is_current_stream_capturing()
+        live = [p for p in self.tail_params if p.grad is not None]
+        key = tuple(id(p) for p in live)
+        if self._tail is None or (not capturing and self._tail[3] != key):
+            if capturing and self._tail is None:
+                raise RuntimeError("GradBuckets.finish(): run one eager step before capturing (the tail bucket is built there)")
+            dev = live[0].device if live else self.buckets[0]["flat"].device
+            flat = torch.zeros(sum(p.numel() for p in live), dtype=torch.float32, device=dev)
             views, off = [], 0
             for p in live:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-            self._tail = (flat, views, live)
-        flat, views, live = self._tail
-        torch._foreach_copy_(views, [p.grad for p in live])
-        tail = dict(flat=flat, work=None)
-        self._launch(tail)
+            self._tail = (flat, views, live, key)
+        flat, views, live, _ = self._tail
+        if live:
+            torch._foreach_copy_(views, [p.grad for p in live])
+            tail = dict(flat=flat, work=None)
+            self._launch(tail)
         inv = 1.0 / self.world
         for b in self._inflight:
             b["work"].wait()
@@ -281,13 +306,41 @@ class GradBuckets:
                 b["flat"].mul_(inv)
             b["work"] = None
         self._inflight = []
-        torch._foreach_copy_([p.grad for p in live], views)
+        if live:
+            torch._foreach_copy_([p.grad for p in live], views)
 
+    def _broadcast_coalesced(self, tensors, src):
+        """One broadcast per dtype of a flat copy (the ~440 parameters + buffers are a handful of collectives, not 440)."""
+        by_dtype = {}
+        for t in tensors:
+            by_dtype.setdefault(t.dtype, []).append(t)
+        for dt, ts in by_dtype.items():
+            flat = torch.cat([t.detach().reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src, group=self.group)
+            off = 0
+            for t in ts:
+                t.data.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+
+    @torch.no_grad()
     def broadcast_parameters(self, module, src=0):
+        """Initial sync of parameters and buffers from rank `src` (what DDP's constructor does), coalesced; the 16-bit operand
+        copies cached by an earlier forward are invalidated (the version counters do not move under `.data` writes)."""
         if not self.active:
             return
-        for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src, group=self.group)
+        self._broadcast_coalesced(list(module.parameters()) + list(module.buffers()), src)
+        from . import functional
+        functional.invalidate_weight_cache()
+
+    @torch.no_grad()
+    def broadcast_buffers(self, module, src=0):
+        """DDP's per-forward `broadcast_buffers=True` (the reference constructs DDP with the default, train_net.py:63-64):
+        BatchNorm running statistics follow rank `src`.  One small coalesced collective per dtype; capturable."""
+        if not self.active:
+            return
+        bufs = [b for b in module.buffers() if b.numel()]
+        if bufs:
+            self._broadcast_coalesced(bufs, src)
 
     def describe(self):
         return {"buckets": len(self.buckets) + 1, "bucket_mib": [round(b["flat"].numel() * 4 / 2 ** 20, 1) for b in self.buckets],

@@ -166,3 +166,116 @@ def test_grad_buckets_real_parameter_list_world2():
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker_buckets, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world))
+
+
+def _worker_contract(rank, world, port, ret):
+    """The sink contract: a cleared .grad is re-attached by BlockSink.done(); a second backward before
+    finish() is refused; a tail parameter that starts receiving gradients later joins the exchange; coalesced parameter /
+    buffer broadcasts."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from editor_amd.ddp import GradBuckets
+    torch.manual_seed(rank)                                  # ranks start DIFFERENT: the broadcast must equalise them
+    blk = [nn.Parameter(torch.randn(8, 8)) for _ in range(12)]
+    tail_a, tail_b = nn.Parameter(torch.randn(5)), nn.Parameter(torch.randn(7))
+    mod = nn.Module()
+    for i, p in enumerate(blk + [tail_a, tail_b]):
+        mod.register_parameter("p%d" % i, p)
+    mod.register_buffer("running", torch.full((4,), float(rank)))
+    gb = GradBuckets([("blk", blk)], [tail_a, tail_b])
+    ok = gb.active
+    gb.broadcast_parameters(mod)
+    ref = [p.detach().clone() for p in mod.parameters()]
+    for t in ref:
+        dist.broadcast(t, src=0)
+    ok &= all(torch.equal(p.detach(), r) for p, r in zip(mod.parameters(), ref)) and float(mod.running.sum()) == 0.0
+    mod.running.fill_(float(rank + 3))
+    gb.broadcast_buffers(mod)
+    ok &= float(mod.running[0]) == 3.0
+    sink = gb.sink(0)
+    # step 1: foreign code dropped the gradients; the backward writes the slots and done() re-attaches them
+    for p in blk:
+        p.grad = None
+    for j, v in enumerate(sink.views):
+        v.fill_(float(rank + j))
+    sink.done()
+    ok &= all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(blk, sink.views))
+    try:
+        sink.done()                                          # second backward before finish(): refused, not silently lost
+        ok = False
+    except RuntimeError:
+        pass
+    tail_a.grad = torch.full((5,), float(rank))
+    gb.finish()
+    ok &= bool((blk[3].grad == (0 + 3 + 1 + 3) / 2).all()) and bool((tail_a.grad == 0.5).all()) and tail_b.grad is None
+    # step 2: tail_b receives a gradient for the first time -> it is exchanged too
+    for j, v in enumerate(sink.views):
+        v.fill_(1.0)
+    sink.done()
+    tail_a.grad = torch.full((5,), float(rank))
+    tail_b.grad = torch.full((7,), float(2 * rank))
+    gb.finish()
+    ok &= bool((tail_b.grad == 1.0).all()) and bool((tail_a.grad == 0.5).all())
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_grad_buckets_contract_world2():
+    world = 2
+    port = _free_port()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker_contract, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world))
+
+
+def _worker_strong(rank, world, port, ret):
+    """The secondary (strong-scaling) series of SURVEY.md 7 "DDP batch semantics": GLOBAL batch 128 split by
+    RandomIdentitySampler_DDP into whole identities per rank (P_local = 4 identities x 16 instances at world 2), each rank's
+    mean-reduced loss gradient averaged by GradBuckets.finish() == the gradient of the global-batch mean loss."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from editor_amd.data import RandomIdentitySampler_DDP
+    from editor_amd.ddp import GradBuckets
+    data = [("img%d" % i, i // 20, 0, 0) for i in range(20 * 24)]         # 24 identities x 20 images
+    np.random.seed(5)
+    sam = RandomIdentitySampler_DDP(data, 128, 16, seed=77)
+    mine = list(iter(sam))[:128 // world]                                 # this rank's share of the first global batch
+    pids = [data[i][1] for i in mine]
+    ok = len(mine) == 64 and len(set(pids)) == 4 and all(pids.count(p) == 16 for p in set(pids))    # whole identities
+    allidx = [None] * world
+    dist.all_gather_object(allidx, mine)
+    ok &= len(set(sum(allidx, []))) == 128 or len(sum(allidx, [])) == 128
+    # a linear model on per-sample features: rank-local mean loss, in-place slots, averaged exchange
+    torch.manual_seed(0)
+    w = [nn.Parameter(torch.randn(6, 6)) for _ in range(12)]
+    t = nn.Parameter(torch.randn(6))
+    gb = GradBuckets([("blk", w)], [t])
+    feats = torch.randn(20 * 24, 6, generator=torch.Generator().manual_seed(1))
+
+    def loss_of(idx):
+        x = feats[idx]
+        y = x
+        for p in w:
+            y = torch.tanh(y @ p)
+        return (y.sum(dim=1) + (x * t).sum(dim=1)).pow(2).mean()
+
+    gl = torch.autograd.grad(loss_of(sum(allidx, [])), w + [t])           # global-batch gradient (what 1 GPU would compute)
+    grads = torch.autograd.grad(loss_of(mine), w + [t])
+    sink = gb.sink(0)
+    for v, g in zip(sink.views, grads[:12]):
+        v.copy_(g)
+    sink.done()
+    t.grad = grads[12].clone()
+    gb.finish()
+    ok &= all(torch.allclose(p.grad, g, atol=1e-6, rtol=1e-5) for p, g in zip(w + [t], gl))
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_series_world2():
+    world = 2
+    port = _free_port()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker_strong, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world))

@@ -159,3 +159,91 @@ def test_fused_sgd_f16_shadows():
     # without an optimizer in the loop the cache builds the transpose itself
     q = torch.randn(128, 256).cuda().requires_grad_(True)
     assert torch.equal(fnc.act_weight_t(q, torch.bfloat16), q.detach().bfloat16().t())
+
+
+def _params(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    names = ["a.weight", "a.bias", "b.weight"]
+    ps = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.1).cuda()) for s in ((64, 128), (64,), (300, 64))]
+    return names, ps
+
+
+def test_fused_sgd_skips_the_step_on_overflow():
+    """GradScaler.step semantics (engine/processor.py:94-96): a step whose gradients hold an inf / nan writes
+    NOTHING - parameters, momentum buffers and 16-bit shadows keep their bits - and is reported; the next clean step applies."""
+    from editor_amd.optim import FusedSGD
+    names, ps = _params()
+    opt = FusedSGD(list(zip(names, ps)), base_lr=1e-2, momentum=0.9, shadow_dtype=torch.float16)
+    assert opt.check_overflow
+    g = torch.Generator().manual_seed(1)
+    for p in ps:
+        p.grad = torch.randn(p.shape, generator=g).cuda()
+    opt.step()                                               # a clean step: momentum buffers and shadows now hold values
+    before = [(p.detach().clone(), b.clone(), None if h is None else h.clone()) for p, b, h in zip(ps, opt.bufs, opt.shadows)]
+    assert not opt.found_inf()
+    for p in ps:
+        p.grad = torch.randn(p.shape, generator=g).cuda()
+    ps[2].grad[17, 3] = float("inf")
+    opt.step()
+    for p, b, h, (p0, b0, h0) in zip(ps, opt.bufs, opt.shadows, before):
+        assert torch.equal(p.detach(), p0) and torch.equal(b, b0) and (h is None or torch.equal(h, h0))
+    assert opt.found_inf() and not opt.found_inf()           # reported once, then reset
+    ps[2].grad[17, 3] = 0.5
+    opt.step()
+    assert not torch.equal(ps[0].detach(), before[0][0]) and not opt.found_inf()
+    # bf16 / fp32 modes do not pay for the check pass
+    assert not FusedSGD(list(zip(names, ps)), base_lr=1e-2).check_overflow
+
+
+def test_device_grad_scaler_matches_torch_sgd_and_backs_off():
+    """DeviceGradScaler: scale(loss).backward() -> step (unscale + update on the device) -> update(); an injected overflow
+    leaves the weights unchanged and halves the scale; growth after `growth_interval` clean steps; the whole sequence
+    replays from a hipGraph."""
+    from editor_amd.optim import DeviceGradScaler, FusedSGD
+    names, ps = _params(3)
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = FusedSGD(list(zip(names, ps)), base_lr=1e-2, momentum=0.9, weight_decay=0.0, weight_decay_bias=0.0, bias_lr_factor=1.0,
+                   shadow_dtype=torch.float16)
+    topt = torch.optim.SGD(ref, lr=1e-2, momentum=0.9)
+    sc = DeviceGradScaler("cuda", init_scale=2.0 ** 10, growth_interval=3)
+    x = torch.randn(32, 128, generator=torch.Generator().manual_seed(9)).cuda()
+
+    def loss_of(params, poison=0.0):
+        y = torch.tanh(x @ params[0].t() + params[1]) @ params[2].t()
+        return y.pow(2).mean() * (1.0 + poison)
+
+    for step in range(3):
+        opt.zero_grad(); topt.zero_grad()
+        sc.scale(loss_of(ps)).backward()
+        assert abs(float(ps[0].grad.abs().max()) / 2.0 ** 10) > 0          # gradients carry the scale
+        sc.step(opt); sc.update()
+        loss_of(ref).backward(); topt.step()
+        for p, r in zip(ps, ref):
+            assert torch.allclose(p.detach(), r.detach(), atol=1e-6, rtol=1e-5)
+    assert sc.get_scale() == 2.0 ** 11                                     # three clean steps: grown once
+    keep = [p.detach().clone() for p in ps]
+    opt.zero_grad()
+    sc.scale(loss_of(ps, poison=float("inf"))).backward()                 # overflow in the backward
+    sc.step(opt); sc.update()
+    assert all(torch.equal(p.detach(), k) for p, k in zip(ps, keep)) and sc.get_scale() == 2.0 ** 10
+    # captured: the same three calls replay with the device-resident scale
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            opt.zero_grad()
+            sc.scale(loss_of(ps)).backward()
+            sc.step(opt); sc.update()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    opt.zero_grad()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        sc.scale(loss_of(ps)).backward()
+        sc.step(opt); sc.update()
+    s0 = sc.get_scale()
+    w0 = ps[0].detach().clone()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert not torch.equal(ps[0].detach(), w0) and sc.get_scale() >= s0
