@@ -66,8 +66,9 @@ def test_gemm_f16x2_vs_float64(m, n, k):
     torch.nn.functional.gelu(x).sum().backward()
     e4 = rel_err(aux.double().cpu(), x.grad)
     print("gemm_f16x2 %dx%dx%d: residual %.2e pair %.2e gelu %.2e gelu' %.2e | torch fp32 matmul %.2e" % (m, n, k, e1, e2, e3, e4, f32_err))
-    # fp32-class: no worse than 1.5x torch's own fp32 CPU matmul on the same inputs (its error grows with sqrt(K) as well)
-    assert max(e1, e2, e3) < max(3e-7, 1.5 * f32_err) and e4 < 6e-4
+    # fp32-class: within 2x torch's own fp32 CPU matmul on the same inputs (its error grows with sqrt(K) as well; a pair
+    # OUTPUT adds its own 2^-23 representation error on top of the product's)
+    assert max(e1, e2, e3) < max(3e-7, 2.0 * f32_err) and e4 < 6e-4
 
 
 def test_gemm_f16x2_live_rows():
