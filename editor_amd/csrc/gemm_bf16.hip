@@ -10,11 +10,16 @@
 // k-major operands are fed to the matrix core with ds_read_b128; operands whose reduction index is the row
 // index are staged untransposed and read with the CDNA4 LDS transpose load ds_read_b64_tr_b16.
 //
-// Tiling: 128x128x64 per workgroup, 4 wavefronts (2x2), each 64x64 = 4x4 MFMA tiles; LDS double buffered
-// (64 KiB -> 2 workgroups/CU), register-staged global->LDS with XOR-swizzled images; XCD-aware tile order
-// (consecutive n-tiles of one A row-panel stay on one XCD's L2); optional split-K with fp32 atomics.
-// The MFMA is issued with its operands swapped (D^T tile) so each lane owns 4 CONSECUTIVE output columns:
-// 8/16-byte epilogue stores and float4 bias loads.
+// Three tilings, one MFMA / LDS-image vocabulary (the MFMA is issued with its operands swapped - a D^T tile - so each lane
+// owns 4 CONSECUTIVE output columns):
+//   gemm_bf16_pp_kernel    256x256x64 "ping-pong", 8 waves as two groups one barrier apart, LDS-DMA staging, counted vmcnt:
+//                          THE path's kernel - every forward, dgrad and (one round of split-K workgroups) wgrad product of
+//                          the transformer blocks, 208-row short tiles for the 768-wide outputs, and the split-precision
+//                          (hi.hi + hi.lo + lo.hi) forward of the 'f16x2' mode
+//   gemm_bf16_pipe_kernel  256x128x64, three LDS-DMA stages: shapes the ping-pong kernel does not take
+//   gemm_bf16_kernel       128x128x64, 4 waves, register- or DMA-staged: small / ragged problems (K % 64 != 0, N < 128)
+// XCD-aware tile order (consecutive n-tiles of one A row-panel stay on one XCD's L2); split-K through per-split slabs and a
+// fixed-order reduction (deterministic), fp32 atomics only on the generic kernel.
 #include "common.h"
 #include "../../include/editor_hip.h"
 #include <stdlib.h>

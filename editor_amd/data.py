@@ -269,3 +269,73 @@ class DeviceTrainTransform:
         call("editor_augment_u8", images_u8.contiguous(), params, b, h, w, int(self.padding), self.mean, self.std, noise,
              int(seed) & 0xFFFFFFFFFFFFFFFF, out)
         return out
+
+
+class DeviceJpegDecoder:
+    """`Image.open(path).convert('RGB')` + the 256-wide crops of data/datasets/bases.py:9-41 for a BATCH of baseline JPEG
+    files: the host Huffman-decodes each file into quantised DCT coefficients (a thread pool; the C entry point releases
+    the GIL), ONE device call per geometry does dequantisation + IDCT + chroma upsampling + YCbCr -> RGB + the crop split
+    (editor_jpeg_reconstruct).  Pixels are bit-identical to Pillow's (tests/golden/f14_decode.npz).
+
+        dec = DeviceJpegDecoder(crop_w=256)
+        crops = dec([open(p, "rb").read() for p in paths], device)     # uint8 (ncrop, B, H, 256, 3): RGB, NI, TI
+        x = DeviceResize(cfg.INPUT.SIZE_TRAIN)(crops[0])               # ... the rest of the transform on the device
+
+    Progressive / arithmetic-coded files raise (EDITOR_JPEG_UNSUPPORTED): there is no silent host fallback."""
+
+    def __init__(self, crop_w=256, threads=8):
+        from concurrent.futures import ThreadPoolExecutor
+        from . import _lib
+        self.crop_w = int(crop_w)
+        self._cd = _lib.lib().cdll
+        self._pool = ThreadPoolExecutor(max_workers=max(1, int(threads)))
+
+    def parse(self, data):
+        """-> info (16 int32): W, H, ncomp, hmax, vmax, mcus_x, mcus_y, ycc_transform, blocks_per_image, ..."""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        info = np.zeros(16, dtype=np.int32)
+        rc = self._cd.editor_jpeg_parse(ctypes.c_void_p(buf.ctypes.data), len(data), ctypes.c_void_p(info.ctypes.data))
+        if rc:
+            raise ValueError("JPEG %s (editor_jpeg_parse rc %d)" % ("uses a coding mode the device decoder does not cover "
+                             "(progressive / arithmetic / 4 components)" if rc == 9002 else "is corrupt", rc))
+        return info
+
+    def _entropy(self, data, coef_ptr, blocks, qt_ptr, info):
+        buf = np.frombuffer(data, dtype=np.uint8)
+        rc = self._cd.editor_jpeg_entropy_decode(ctypes.c_void_p(buf.ctypes.data), len(data), ctypes.c_void_p(coef_ptr),
+                                                 ctypes.c_long(blocks), ctypes.c_void_p(qt_ptr), ctypes.c_void_p(info.ctypes.data))
+        if rc:
+            raise ValueError("JPEG entropy decode failed (rc %d)" % rc)
+
+    def __call__(self, files, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("DeviceJpegDecoder reconstructs on the GPU (no CPU fallback)")
+        infos = [self.parse(f) for f in files]
+        w, h = int(infos[0][0]), int(infos[0][1])
+        cw = self.crop_w if self.crop_w > 0 else w
+        ncrop = w // cw
+        if ncrop < 1 or any(int(i[0]) != w or int(i[1]) != h for i in infos):
+            raise ValueError("DeviceJpegDecoder: the files of a batch must share one image size >= the crop width")
+        b = len(files)
+        out = torch.empty(ncrop, b, h, cw, 3, dtype=torch.uint8, device=device)
+        groups = {}
+        for i, inf in enumerate(infos):                      # one launch per coefficient geometry (sampling factors)
+            groups.setdefault(tuple(int(v) for v in inf[:9]), []).append(i)
+        for key, idx in groups.items():
+            blocks = key[8]
+            n = len(idx)
+            coef = torch.empty(n, blocks, 64, dtype=torch.int16).pin_memory()
+            qt = torch.empty(n, 3, 64, dtype=torch.int16).pin_memory()           # (uint16 bit patterns)
+            ginfo = [np.zeros(16, dtype=np.int32) for _ in idx]
+            list(self._pool.map(lambda a: self._entropy(files[a[1]], coef[a[0]].data_ptr(), blocks, qt[a[0]].data_ptr(), ginfo[a[0]]),
+                                enumerate(idx)))
+            pb = ctypes.c_long(0)
+            self._cd.editor_jpeg_planes_bytes(ctypes.c_void_p(ginfo[0].ctypes.data), ctypes.byref(pb))
+            coef_d, qt_d = coef.to(device, non_blocking=True), qt.to(device, non_blocking=True)
+            planes = torch.empty(n * pb.value, dtype=torch.uint8, device=device)
+            dst = out if n == b else torch.empty(ncrop, n, h, cw, 3, dtype=torch.uint8, device=device)
+            call("editor_jpeg_reconstruct", coef_d, qt_d, ctypes.c_void_p(ginfo[0].ctypes.data), n, planes, cw, dst)
+            if n != b:
+                out[:, torch.tensor(idx, device=device)] = dst
+        return out

@@ -10,8 +10,9 @@ CPU tensor raises.
 MI355X-first differences in HOW (not WHAT) it computes:
   * the shared backbone runs ONCE on the three modalities stacked on the batch axis (3B samples), so every
     GEMM sees M = 3*B*T rows and the shared weights stream from HBM once;
-  * attention probabilities are written once per layer into one (L,3B,h,T,T) buffer and consumed by a
-    row-vector rollout kernel (no 129x129 matmul chain);
+  * the attention rollout is a row-vector recurrence (no 129x129 matmul chain): the 16-bit modes recompute each layer's
+    probabilities from its saved q / k and row log-sum-exps (no probability tensor at all), the f32 parity mode and the
+    split-precision 'f16x2' mode read the (L,3B,h,T,T) softmax buffer their attention kernels materialise;
   * top-k tie order of torch's CPU kernel is reproduced on device (libstdc++ heap/introselect).
 """
 import math
@@ -382,12 +383,6 @@ class EDITOR(nn.Module):
                                             None, None, None, base.qk_scale, self._sink("backbone.%d" % i))
         x = fn.LayerNormFn.apply(x, base.norm.weight, base.norm.bias, 1e-6, None)
         return x, probs
-
-    @staticmethod
-    def _drop_rows(b, t, p, device):
-        keep = 1.0 - p
-        r = torch.floor(keep + torch.rand(b, device=device)) / keep
-        return r.repeat_interleave(t).contiguous()
 
     def _select(self, probs, mask_fre, b):
         """Part_Attention x3 + union with the frequency mask (SFTS.py:145-164,183-187) -> (B,N) uint8."""

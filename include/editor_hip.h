@@ -333,6 +333,30 @@ int editor_augment_u8(const uint8_t* in, const int* params, int B, int H, int W,
                       const float* stdv, const float* noise, unsigned long long seed, float* out,
                       editor_stream_t stream);
 
+/* ---- baseline-JPEG decode (data/datasets/bases.py:9-41 `Image.open(path).convert('RGB')` + the 256-wide
+ * crops of the stitched tri-modal image) -------------------------------------------------------------------------------
+ * Split: the HOST parses the markers and Huffman-decodes the scan(s) into quantised DCT coefficient blocks (the only
+ * inherently serial part); the DEVICE does dequantisation + inverse DCT + chroma upsampling + YCbCr -> RGB + the crop
+ * split for a whole batch per call.  Integer for integer libjpeg's default decompression path (jidctint.c islow,
+ * jdsample.c fancy upsampling, jdcolor.c) - the pixels equal Pillow's bit for bit (tests/golden/f14_decode.npz).
+ * Supported: 8-bit baseline / extended-sequential Huffman, 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, restart intervals,
+ * interleaved or per-component scans.  Anything else -> EDITOR_JPEG_UNSUPPORTED (no silent fallback).
+ * info (16 ints, host): {W, H, ncomp, hmax, vmax, mcus_x, mcus_y, ycc_transform, blocks_per_image, tq0, tq1, tq2, ...}. */
+#define EDITOR_JPEG_CORRUPT 9001
+#define EDITOR_JPEG_UNSUPPORTED 9002
+/* HOST: headers only (geometry of the coefficient buffer) */
+int editor_jpeg_parse(const uint8_t* data, long n, int* info);
+/* HOST: coef (host, coef_blocks x 64 int16, natural order; component planes one after another, block grids padded to whole
+ * MCUs) and qt (host, 3 x 64 uint16, natural order, per component) of one image */
+int editor_jpeg_entropy_decode(const uint8_t* data, long n, int16_t* coef, long coef_blocks, uint16_t* qt, int* info);
+/* HOST: bytes of the per-image sample-plane scratch editor_jpeg_reconstruct needs */
+int editor_jpeg_planes_bytes(const int* info, long* bytes);
+/* DEVICE: B images of ONE geometry (info, host pointer): coef (B x blocks_per_image x 64) and qt (B x 3 x 64) in device
+ * memory -> out uint8 (ncrop, B, H, crop_w, 3), ncrop = W / crop_w (crop_w <= 0: one crop of the full width); planes:
+ * B x planes_bytes scratch. */
+int editor_jpeg_reconstruct(const int16_t* coef, const uint16_t* qt, const int* info, int B, uint8_t* planes, int crop_w,
+                            uint8_t* out, editor_stream_t stream);
+
 /* T.Resize(size, interpolation) of decoded uint8 images (make_dataloader.py:246,256; torchvision 0.14.1 ->
  * PIL.Image.resize = Pillow ImagingResample, 8-bit path): horizontal pass then vertical pass with 22-bit fixed-point taps.
  * in (B,Hin,Win,3) -> out (B,Hout,Wout,3); bounds: (n_out,2) int32 {window start, tap count}; k: (n_out, ksize) int32
