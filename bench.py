@@ -395,9 +395,10 @@ def main():
     # gradients are written by the backward straight into a few flat 64 MiB buckets and each bucket's RCCL all-reduce is
     # issued from inside the backward as soon as its last block is done (editor_amd.ddp.GradBuckets): overlapped with the
     # remaining backward in the eager step AND in the captured hipGraph (the collectives are part of the graph).
-    buckets = model.enable_grad_buckets(force=force_ddp) if use_dist else None
-    if buckets is not None:
-        buckets.broadcast_parameters(model)
+    # (N = 1 as well: the in-place gradient slots are how the backward hands its weight gradients over - no process group, no
+    # collective; editor_amd.functional.GROUP_WGRAD)
+    buckets = model.enable_grad_buckets(force=force_ddp)
+    buckets.broadcast_parameters(model)
 
     # solver/make_optimizer.py:4-29: SGD, momentum 0.9, wd 1e-4, bias lr x2 (BASE_LR 0.001) - fused HIP update
     from editor_amd import solver

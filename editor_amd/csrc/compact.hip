@@ -92,7 +92,8 @@ __global__ void scatter_rows_kernel(const float* __restrict__ dy, const int* __r
     }
 }
 
-// pooling on layout B (make_model.py:186-203): block per (sample, modality)
+// pooling on layout B (make_model.py:186-203): block per (sample, modality).  Both row loops keep EIGHT independent loads in
+// flight per thread (one dependent load per trip over ~80 rows made this 116 us for 30 MB).
 __global__ __launch_bounds__(256) void pool_packed_fwd_kernel(const float* __restrict__ x, const int* __restrict__ cu,
     long B, int nmod, int D, float* __restrict__ out, float* __restrict__ num_out)
 {
@@ -103,11 +104,18 @@ __global__ __launch_bounds__(256) void pool_packed_fwd_kernel(const float* __res
     const float* x0 = x + ((long)nmod * start) * D;                  // modality 0 (RGB) rows of this sample
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
+    const int lane = threadIdx.x & 63;
     for (int l = 1 + (threadIdx.x >> 6); l < len; l += 4) {          // num = #RGB patch rows with non-zero row sum
         float s = 0.f;
-        for (int c = threadIdx.x & 63; c < D; c += 64) s += x0[(long)l * D + c];
+        for (int c0 = lane; c0 < D; c0 += 512) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = c0 + 64 * j < D ? x0[(long)l * D + c0 + 64 * j] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
         s = wave_sum(s);
-        if ((threadIdx.x & 63) == 0 && s != 0.f) atomicAdd(&cnt, 1);
+        if (lane == 0 && s != 0.f) atomicAdd(&cnt, 1);
     }
     __syncthreads();
     const float num = (float)cnt;
@@ -116,7 +124,13 @@ __global__ __launch_bounds__(256) void pool_packed_fwd_kernel(const float* __res
     float* o = out + ((long)m * B + b) * 2 * D;
     for (int c = threadIdx.x; c < D; c += 256) {
         float s = 0.f;
-        for (int l = 1; l < len; ++l) s += xm[(long)l * D + c];
+        for (int l0 = 1; l0 < len; l0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = l0 + j < len ? xm[(long)(l0 + j) * D + c] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];                   // (row order, as before)
+        }
         o[c] = xm[c];
         o[D + c] = s / num;
     }
@@ -175,6 +189,24 @@ extern "C" int editor_gather_rows(const float* in, const int* src, long R, int D
     EDITOR_LAUNCH_CHECK();
     return 0;
 }
+// rows [live, roundup64(live)) of a packed (rows x row_bytes) buffer <- 0: the contract of the live-row kernels (reductions over
+// token rows read whole 64-row K-tiles) without zero-filling the worst-case-sized buffer (4 x 150 MB of fills per step)
+__global__ void zero_tail_rows_kernel(char* __restrict__ buf, long row_bytes, long rows, const int* __restrict__ live)
+{
+    const long r0 = *live, r1 = min(rows, (r0 + 63) & ~63L);
+    const long n16 = (r1 - r0) * (row_bytes >> 4);
+    uint4* p = reinterpret_cast<uint4*>(buf + r0 * row_bytes);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n16; e += (long)gridDim.x * blockDim.x) p[e] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+extern "C" int editor_zero_tail_rows(void* buf, long row_bytes, long rows, const int* live, hipStream_t stream)
+{
+    if (!buf || !live || (row_bytes & 15) || rows < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(zero_tail_rows_kernel, dim3(64), dim3(256), 0, stream, (char*)buf, row_bytes, rows, live);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int editor_scatter_rows(const float* dy, const int* src, long R, int D, long rows_out, float* dx,
                                    hipStream_t stream)
 {

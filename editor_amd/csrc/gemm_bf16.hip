@@ -24,6 +24,7 @@
 #include "../../include/editor_hip.h"
 #include <stdlib.h>
 #include <stdio.h>
+#include <string.h>
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) short short4_t;
@@ -844,7 +845,7 @@ __device__ __forceinline__ void pp_unit_offsets(long ld, int r0, int R, int sub,
 // K loop runs three segments over the SAME tile pipeline - lo.hi, hi.lo, then hi.hi (small terms first) - by switching the
 // LDS-DMA source per K-tile; the accumulator, the phases and the barriers are unchanged.  Dropped: lo.lo (2^-22 relative).
 template <bool F16, bool A_KMAJOR, bool B_KMAJOR, bool C_F32, int F0 = 8, int F1 = 8, bool SPLIT = false>
-__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
+__device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, const int by)
 {
     static_assert(!SPLIT || (F16 && A_KMAJOR && B_KMAJOR), "split precision: half operands, forward layout");
     static_assert(F0 >= 5 && F0 <= 8 && F1 >= 5 && F1 <= F0, "live fragments per wave group");
@@ -855,7 +856,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
     constexpr int GM = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = g.tiles_m * g.tiles_n;
-    const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int grp = GM * g.tiles_n;
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
     const int nkb = ktiles;                                     // K-tiles of one operand half (SPLIT)
     if constexpr (SPLIT) ktiles *= 3;
     const int per = (ktiles + g.splitk - 1) / g.splitk;
-    const int kt0 = blockIdx.y * per, kt1 = min(ktiles, kt0 + per);
+    const int kt0 = by * per, kt1 = min(ktiles, kt0 + per);
     const int nk = max(kt1 - kt0, 0);
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
     const int gb = wr ? F0 * 16 : 0;                            // tile row of this wave group's first row
     const int fg = wr ? F1 : F0;                                // ... and its live fragments
     const int li = lane & 15, lg = lane >> 4;
-#define PP_STAMP(k) do { if (g.trace && threadIdx.x == 0) g.trace[(long)(blockIdx.y * gridDim.x + bid) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PP_STAMP(k) do { if (g.trace && threadIdx.x == 0) g.trace[(long)(by * gridDim.x + bid) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     PP_STAMP(0);
 
     float4_t acc[8][4];
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
         // on the way out, as the unfused form would.
         constexpr int RB = 256 * 2 + 16;
         PP_EBAR();
-        const bool add_bias = g.bias && blockIdx.y == 0;
+        const bool add_bias = g.bias && by == 0;
         float4 bv[4];                                          // this lane's four column groups: loaded once, not per row
         float rsv[8];
 #pragma unroll
@@ -1232,26 +1232,50 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
             const int ml = min(g.M, mp + (pass ? F1 : F0) * 16);
             if constexpr (SPLIT) {                                        // (the launcher admits NONE / RESIDUAL / GELU only)
                 switch (g.epilogue) {
-                    case EDITOR_EPI_RESIDUAL: epilogue_copy_out<F16, C_F32, EDITOR_EPI_RESIDUAL, 128, 256, 512, !C_F32>(g, smem, mp, n0, blockIdx.y, ml); break;
-                    case EDITOR_EPI_GELU:     epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU, 128, 256, 512, !C_F32>(g, smem, mp, n0, blockIdx.y, ml); break;
-                    default:                  epilogue_copy_out<F16, C_F32, EDITOR_EPI_NONE, 128, 256, 512, !C_F32>(g, smem, mp, n0, blockIdx.y, ml); break;
+                    case EDITOR_EPI_RESIDUAL: epilogue_copy_out<F16, C_F32, EDITOR_EPI_RESIDUAL, 128, 256, 512, !C_F32>(g, smem, mp, n0, by, ml); break;
+                    case EDITOR_EPI_GELU:     epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU, 128, 256, 512, !C_F32>(g, smem, mp, n0, by, ml); break;
+                    default:                  epilogue_copy_out<F16, C_F32, EDITOR_EPI_NONE, 128, 256, 512, !C_F32>(g, smem, mp, n0, by, ml); break;
                 }
             } else
             switch (g.epilogue) {
-                case EDITOR_EPI_RESIDUAL: epilogue_copy_out<F16, C_F32, EDITOR_EPI_RESIDUAL, 128, 256, 512>(g, smem, mp, n0, blockIdx.y, ml); break;
-                case EDITOR_EPI_GELU:     epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU, 128, 256, 512>(g, smem, mp, n0, blockIdx.y, ml); break;
-                case EDITOR_EPI_GELU_BWD: epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU_BWD, 128, 256, 512>(g, smem, mp, n0, blockIdx.y, ml); break;
-                default:                  epilogue_copy_out<F16, C_F32, EDITOR_EPI_NONE, 128, 256, 512>(g, smem, mp, n0, blockIdx.y, ml); break;
+                case EDITOR_EPI_RESIDUAL: epilogue_copy_out<F16, C_F32, EDITOR_EPI_RESIDUAL, 128, 256, 512>(g, smem, mp, n0, by, ml); break;
+                case EDITOR_EPI_GELU:     epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU, 128, 256, 512>(g, smem, mp, n0, by, ml); break;
+                case EDITOR_EPI_GELU_BWD: epilogue_copy_out<F16, C_F32, EDITOR_EPI_GELU_BWD, 128, 256, 512>(g, smem, mp, n0, by, ml); break;
+                default:                  epilogue_copy_out<F16, C_F32, EDITOR_EPI_NONE, 128, 256, 512>(g, smem, mp, n0, by, ml); break;
             }
             PP_STAMP(3 + pass);
         }
     } else {
-        epilogue_store<F16, C_F32, 8>(g, acc, m0 + gb, n0 + wc * 64, lane, blockIdx.y == 0);   // (full tiles only: host)
+        epilogue_store<F16, C_F32, 8>(g, acc, m0 + gb, n0 + wc * 64, lane, by == 0);   // (full tiles only: host)
     }
     if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(5); }
 #undef PP_STAMP
 #undef PP_EBAR
 #undef PP_BAR
+}
+
+template <bool F16, bool A_KMAJOR, bool B_KMAJOR, bool C_F32, int F0 = 8, int F1 = 8, bool SPLIT = false>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
+{
+    pp_body<F16, A_KMAJOR, B_KMAJOR, C_F32, F0, F1, SPLIT>(g, blockIdx.x, blockIdx.y);
+}
+
+// GROUPED weight gradients: the four dW = dy^T x products of one transformer block (qkv, proj, fc1, fc2: 27 + 9 + 36 + 36 =
+// 108 output tiles of 256 x 256, reduction over all token rows) as ONE launch - grid.x = the tiles of all problems back to
+// back, grid.y = the split of the reduction shared by all - so that the split comes from tile parallelism: 108 x 7 = 756
+// workgroups = 2.95 rounds of 110-K-tile workgroups, where four launches had 9 / 28 / 7 / 7 splits, one partly filled round
+// each, and the 768 x 768 product ran at 692 TFLOP/s behind 28 slabs.  Per-problem arguments ride in the kernel argument.
+constexpr int kMaxGroup = 4;
+struct GemmGroupArgs { GemmB16Args p[kMaxGroup]; int start[kMaxGroup + 1]; int n; };
+
+template <bool F16>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_group_kernel(GemmGroupArgs ga)
+{
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxGroup; ++i) pi += (i < ga.n && (int)blockIdx.x >= ga.start[i]) ? 1 : 0;
+    pi = __builtin_amdgcn_readfirstlane(pi);
+    pp_body<F16, false, false, true, 8, 8, false>(ga.p[pi], (int)blockIdx.x - ga.start[pi], blockIdx.y);
 }
 
 __global__ void scale_c_kernel(float* C, long rows, int cols, long ld, float beta)
@@ -1503,7 +1527,59 @@ int gemm_f16x2(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi,
     return c_f32 ? launch_pp_t<true, true, true, true, 8, 8, true>(g, stream) : launch_pp_t<true, true, true, false, 8, 8, true>(g, stream);
 }
 
+// The weight gradients of one block in one launch (see gemm_bf16_pp_group_kernel).  Problem i: dW_i (N_i x K_i fp32, contiguous) =
+// alpha * dy_i^T x_i with dy_i (M, N_i), x_i (M, K_i) 16-bit row-major, M token rows shared; N_i, K_i multiples of 256.
+// ws: splitk * sum_i N_i K_i floats of slabs; fixed-order reduction per problem afterwards (deterministic).
+template <bool F16>
+int gemm_wgrad_group(int count, const uint16_t* const* dy, const uint16_t* const* x, float* const* dw, const int* N, const int* K,
+                     int M, float alpha, int splitk, float* ws, const int* m_live, hipStream_t stream)
+{
+    if (count < 1 || count > kMaxGroup || M < 64 || (M % 64) || splitk < 1 || !ws) return (int)hipErrorInvalidValue;
+    GemmGroupArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.n = count;
+    long wsoff = 0;
+    int tiles = 0;
+    const int ktiles = M / BK;
+    if (splitk > ktiles) splitk = ktiles;
+    float* slab[kMaxGroup];
+    for (int i = 0; i < count; ++i) {
+        if (N[i] % 256 || K[i] % 256 || !dy[i] || !x[i] || !dw[i]) return (int)hipErrorInvalidValue;
+        if ((reinterpret_cast<uintptr_t>(dy[i]) | reinterpret_cast<uintptr_t>(x[i]) | reinterpret_cast<uintptr_t>(dw[i])) & 15) return (int)hipErrorInvalidValue;
+        slab[i] = ws + wsoff;
+        // output (N_i, K_i); "A" = dy stored (Kred = M, N_i) row-k, "B" = x stored (Kred = M, K_i) row-k
+        GemmB16Args g{(const bf16_t*)dy[i], (const bf16_t*)x[i], (void*)slab[i], N[i], K[i], M, (long)N[i], (long)K[i], (long)K[i],
+                      alpha, 0.f, nullptr, nullptr, splitk, N[i] / 256, K[i] / 256, EDITOR_EPI_NONE, nullptr, (long)K[i], 1,
+                      m_live, 1, 1, nullptr, nullptr, 1, 0, 0, nullptr, nullptr, nullptr};
+        ga.p[i] = g;
+        ga.start[i] = tiles;
+        tiles += g.tiles_m * g.tiles_n;
+        wsoff += (long)splitk * N[i] * K[i];
+    }
+    ga.start[count] = tiles;
+    constexpr int LDS = 256 * (256 * 2 + 16) + (int)kLutBytes;
+    if (int e = ensure_lds<gemm_bf16_pp_group_kernel<F16>>(LDS)) return e;
+    hipLaunchKernelGGL(gemm_bf16_pp_group_kernel<F16>, dim3(tiles, splitk), dim3(512), LDS, stream, ga);
+    EDITOR_LAUNCH_CHECK();
+    for (int i = 0; i < count; ++i) {
+        const long n4 = (long)N[i] * K[i] / 4;
+        long blocks = (n4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slab[i], splitk, n4, dw[i], 0.f);
+        EDITOR_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 }  // namespace
+
+extern "C" int editor_gemm_wgrad_group(int dtype, int count, const uint16_t* const* dy, const uint16_t* const* x, float* const* dw,
+    const int* N, const int* K, int M, float alpha, int splitk, float* ws, const int* m_live, hipStream_t stream)
+{
+    if (dtype == 2) return gemm_wgrad_group<true>(count, dy, x, dw, N, K, M, alpha, splitk, ws, m_live, stream);
+    if (dtype == 1) return gemm_wgrad_group<false>(count, dy, x, dw, N, K, M, alpha, splitk, ws, m_live, stream);
+    return (int)hipErrorInvalidValue;
+}
 
 extern "C" int editor_gemm_f16x2(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi, const uint16_t* B_lo, void* C,
     void* C_lo, int c_f32, int M, int N, int K, long lda, long ldb, long ldc, float alpha, const float* bias,

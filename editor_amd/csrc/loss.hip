@@ -127,35 +127,58 @@ __global__ void triplet_mine_kernel(const float* __restrict__ gram, const float*
 }
 
 // one block per feature row r: gather every anchor's contribution to row r (as anchor, as its positive, as its
-// negative) in anchor order.  The few anchors that touch row r are listed in LDS first.
-__global__ void triplet_bwd_kernel(const float* __restrict__ f, long ldf, int B, int D, const int* __restrict__ idx,
+// negative) in anchor order.  The few anchors that touch row r are listed in LDS first - by ballots over 64-anchor chunks
+// (anchor order preserved) - together with their partner rows and weights, so that the column loop issues the three feature
+// loads of FOUR list entries before it uses any (it was one dependent idx -> coef -> feature chain per entry: 75 us).
+__global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restrict__ f, long ldf, int B, int D, const int* __restrict__ idx,
     const float* __restrict__ coef, const float* __restrict__ g, float* __restrict__ df)
 {
-    __shared__ unsigned char flag[1024];
-    __shared__ int list[1024];
+    __shared__ int l_i[1024], l_p[1024], l_n[1024];
+    __shared__ float l_wp[1024], l_wn[1024];
     __shared__ int nlist;
     const int r = blockIdx.x;
-    for (int i = threadIdx.x; i < B; i += blockDim.x) flag[i] = (i == r || idx[i] == r || idx[B + i] == r) ? 1 : 0;
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {                                            // wave 0 builds the list
         int n = 0;
-        for (int i = 0; i < B; ++i) if (flag[i]) list[n++] = i;
-        nlist = n;
+        for (int i0 = 0; i0 < B; i0 += 64) {
+            const int i = i0 + threadIdx.x;
+            const bool hit = i < B && (i == r || idx[i] == r || idx[B + i] == r);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+            if (hit) {
+                const int pos = n + __builtin_popcountll(m & ((1ull << threadIdx.x) - 1ull));
+                const float s = coef[i];
+                l_i[pos] = i; l_p[pos] = idx[i]; l_n[pos] = idx[B + i];
+                l_wp[pos] = s * coef[B + i]; l_wn[pos] = s * coef[2 * B + i];
+            }
+            n += __builtin_popcountll(m);
+        }
+        if (threadIdx.x == 0) nlist = n;
     }
     __syncthreads();
     const float k = g[0] / (float)B;
     const int n_l = nlist;
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
         float acc = 0.f;
-        for (int q = 0; q < n_l; ++q) {
-            const int i = list[q], p = idx[i], n = idx[B + i];
-            const float s = coef[i], wp = s * coef[B + i], wn = s * coef[2 * B + i];
-            const float fi = f[(long)i * ldf + c];
-            const float ep = (fi - f[(long)p * ldf + c]) * wp;
-            const float en = n >= 0 ? (fi - f[(long)n * ldf + c]) * wn : 0.f;
-            if (r == i) acc += ep - en;
-            if (r == p) acc -= ep;
-            if (r == n) acc += en;
+        for (int q0 = 0; q0 < n_l; q0 += 4) {
+            float fi[4], fp[4], fn[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = min(q0 + j, n_l - 1);
+                const int n = l_n[q];
+                fi[j] = f[(long)l_i[q] * ldf + c];
+                fp[j] = f[(long)l_p[q] * ldf + c];
+                fn[j] = f[(long)(n >= 0 ? n : l_i[q]) * ldf + c];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = q0 + j;
+                if (q >= n_l) break;
+                const int i = l_i[q], p = l_p[q], n = l_n[q];
+                const float ep = (fi[j] - fp[j]) * l_wp[q];
+                const float en = n >= 0 ? (fi[j] - fn[j]) * l_wn[q] : 0.f;
+                if (r == i) acc += ep - en;
+                if (r == p) acc -= ep;
+                if (r == n) acc += en;
+            }
         }
         df[(long)r * D + c] = k * acc;
     }

@@ -424,17 +424,26 @@ __global__ void embed_bwd_patch_kernel(const float* __restrict__ dx, long Btot, 
         Vec4<T>::st(dpatch + rp * D + c0, v);
     }
 }
-// dpos[t,:] = sum_b dx[b,t,:]   grid (Tn, ceil(D/1024)), 256 thr x float4
-__global__ void embed_bwd_pos_kernel(const float* __restrict__ dx, long Btot, int Tn, int D, float* __restrict__ dpos)
+// dpos[t,:] = sum_b dx[b,t,:].  Stage 1: grid (Tn, ceil(D/1024), S) - split s sums samples b = s, s + S, ... with EIGHT
+// 16-byte loads in flight per thread into partial[s][t][:] (one block per token with a 384-deep serial load chain was 150 us
+// for 152 MB); stage 2 = reduce_rows_kernel over the S partial rows (fixed order: deterministic).
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const float* __restrict__ dx, long Btot, int Tn, int D, int S,
+                                                            float* __restrict__ partial)
 {
-    const int tk = blockIdx.x, c0 = (blockIdx.y * 256 + threadIdx.x) * 4;
+    const int tk = blockIdx.x, c0 = (blockIdx.y * 256 + threadIdx.x) * 4, sp = blockIdx.z;
     if (c0 >= D) return;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long b = 0; b < Btot; ++b) {
-        const float4 v = *reinterpret_cast<const float4*>(dx + (b * Tn + tk) * D + c0);
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    for (long b0 = sp; b0 < Btot; b0 += 8L * S) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long b = b0 + (long)j * S;
+            v[j] = b < Btot ? *reinterpret_cast<const float4*>(dx + (b * Tn + tk) * D + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
     }
-    *reinterpret_cast<float4*>(dpos + (long)tk * D + c0) = a;
+    *reinterpret_cast<float4*>(partial + ((long)sp * Tn + tk) * D + c0) = a;
 }
 // rowsum[b,:] = sum_t dx[b,t,:]      grid (Btot, ceil(D/1024))
 __global__ void embed_bwd_rowsum_kernel(const float* __restrict__ dx, int Tn, int D, float* __restrict__ rowsum)
@@ -456,19 +465,30 @@ __global__ void embed_bwd_rowsum_kernel(const float* __restrict__ dx, int Tn, in
     }
     *reinterpret_cast<float4*>(rowsum + b * D + c0) = make_float4(a.x + a2.x, a.y + a2.y, a.z + a2.z, a.w + a2.w);
 }
-// dsie[c,:] = coef * sum_{b: cam[b%Bcam]==c} rowsum[b,:]    grid (ncam, ceil(D/1024))
-__global__ void embed_bwd_sie_kernel(const float* __restrict__ rowsum, const long* __restrict__ cam, int Bcam, long Btot,
-                                     int D, float coef, float* __restrict__ dsie)
+// dsie[c,:] = coef * sum_{b: cam[b%Bcam]==c} rowsum[b,:].  grid (ncam, ceil(D/64)), 256 threads: lane = column, the four
+// waves take samples b = w, w + 4, ... (eight predicated loads in flight each) and fold through LDS in wave order - four
+// blocks of 192 threads walking 384 samples one dependent load at a time took 70 us.
+__global__ __launch_bounds__(256) void embed_bwd_sie_kernel(const float* __restrict__ rowsum, const long* __restrict__ cam, int Bcam, long Btot,
+                                                            int D, float coef, float* __restrict__ dsie)
 {
-    const int c = blockIdx.x, c0 = (blockIdx.y * 256 + threadIdx.x) * 4;
-    if (c0 >= D) return;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long b = 0; b < Btot; ++b) {
-        if (cam[b % Bcam] != c) continue;
-        const float4 v = *reinterpret_cast<const float4*>(rowsum + b * D + c0);
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    __shared__ float red[4][64];
+    const int c = blockIdx.x, col = blockIdx.y * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float a = 0.f;
+    if (col < D) {
+        for (long b0 = w; b0 < Btot; b0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long b = b0 + 4L * j;
+                v[j] = (b < Btot && cam[b % Bcam] == c) ? rowsum[b * D + col] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += v[j];
+        }
     }
-    *reinterpret_cast<float4*>(dsie + (long)c * D + c0) = make_float4(coef * a.x, coef * a.y, coef * a.z, coef * a.w);
+    red[w][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (w == 0 && col < D) dsie[(long)c * D + col] = coef * (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -839,14 +859,19 @@ extern "C" int editor_embed_assemble_bwd(const float* dx, const long* cam, int B
     DISPATCH_T(dpatch_bf16, hipLaunchKernelGGL(embed_bwd_patch_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, stream,
                dx, Btot, T, D, (TT*)dpatch, dpatch_scale));
     EDITOR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(T, (D + 1023) / 1024), dim3(256), 0, stream, dx, Btot, T, D, dpos);
+    // workspace: max(EDITOR_EMBED_POS_SPLITS * T * D, Btot * D) floats - the dpos partial rows, then (re-used) the row sums
+    if (!workspace) return (int)hipErrorInvalidValue;
+    const int S = (int)(Btot < EDITOR_EMBED_POS_SPLITS ? Btot : EDITOR_EMBED_POS_SPLITS);
+    hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(T, (D + 1023) / 1024, S), dim3(256), 0, stream, dx, Btot, T, D, S, workspace);
+    EDITOR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)(((long)T * D + 63) / 64)), dim3(1024), 0, stream, workspace, S, (long)T * D,
+                       dpos, 0, 1.f);
     EDITOR_LAUNCH_CHECK();
     if (dsie) {
-        if (!workspace) return (int)hipErrorInvalidValue;
         hipLaunchKernelGGL(embed_bwd_rowsum_kernel, dim3((unsigned)Btot, (D + 1023) / 1024), dim3(256), 0, stream, dx, T, D,
                            workspace);
         EDITOR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(embed_bwd_sie_kernel, dim3(ncam, (D + 1023) / 1024), dim3(256), 0, stream, workspace, cam, Bcam,
+        hipLaunchKernelGGL(embed_bwd_sie_kernel, dim3(ncam, (D + 63) / 64), dim3(256), 0, stream, workspace, cam, Bcam,
                            Btot, D, coef, dsie);
         EDITOR_LAUNCH_CHECK();
     }

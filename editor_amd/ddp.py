@@ -268,6 +268,9 @@ class GradBuckets:
                 self._launch(b)
 
     def _launch(self, b):
+        if b["flat"].is_cuda:
+            from . import functional
+            functional.join_side_stream(b["flat"].device)   # the blocks' grouped weight gradients (side stream) are in the slots
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
         self._inflight.append(b)
@@ -276,6 +279,9 @@ class GradBuckets:
     def finish(self):
         """After loss.backward(): exchange the tail parameters and wait for every bucket (stream-level wait on RCCL)."""
         self._written.clear()
+        if self.buckets and self.buckets[0]["flat"].is_cuda:
+            from . import functional
+            functional.join_side_stream(self.buckets[0]["flat"].device)    # deferred weight-gradient launches of the last blocks
         if not self.active:
             return
         # tail = the small parameters that carry a gradient THIS step (never-used ones - BACKBONE.base.fc, the head cfg.MODEL.AL

@@ -151,8 +151,21 @@ def join_side_stream(device):
     _SIDE_KEEP.clear()          # (main-stream work enqueued from here on is ordered after the side stream's reads)
 
 
+# The four weight gradients of a transformer block as ONE grouped launch (ops.gemm_wgrad_group) at the end of the block's
+# backward instead of four split-K launches spread over it, on the side stream.
+#   * With gradient SINKS (editor_amd.ddp.GradBuckets - bench.py and the training loop always enable them, with or without a
+#     process group) the gradients are written in place into bucket slots and autograd is handed nothing, so the launch may
+#     still be running when the block's backward returns: it is joined one block LATER (the next block's dgrad chain overlaps
+#     it) - by the next block, by a bucket's all-reduce, by GradBuckets.finish() and by FusedSGD.step().
+#   * Without sinks the gradients flow through autograd, whose AccumulateGrad may read them (it clones a gradient it cannot
+#     steal) on the main stream as soon as the backward returns - a deferred join there handed it unwritten memory (measured:
+#     NaN losses) - so the launch is joined before the block's backward returns.
+GROUP_WGRAD = os.environ.get("EDITOR_GROUP_WGRAD", "1") != "0"
+WGRAD_DEFER_JOIN = os.environ.get("EDITOR_WGRAD_DEFER", "1") != "0"       # measurement switch: 0 = join at the end of each block
+
+
 def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None, gs=1.0, dw_out=None,
-                db_out=None, dxcs_out=None, w_t=None):
+                db_out=None, dxcs_out=None, w_t=None, defer=None):
     """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy) (or the
     caller's, when the kernel that produced dy summed its columns on the way).  dx_colsum: also return colsum(dx) - the
     bias gradient of the layer BELOW - from the dgrad's own epilogue when it can deliver it (else None).
@@ -183,7 +196,12 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, 
     else:
         need_colsum = False
     sk, skf = _splitk_for(n, k, m)
-    if use_side:
+    if defer is not None:
+        # the weight gradient joins the block's grouped launch (issued by the caller once the last dy exists)
+        defer.append((dy, x2d, dw))
+        if need_colsum:
+            ops.colsum(dy, out=db, scale=inv)
+    elif use_side:
         side = _side_stream(dy.device)
         side.wait_event(dy_ready)                    # dy is complete; the dgrad above runs concurrently
         # dy may be released by the caller (and its block re-used by a main-stream allocation) before the side stream has
@@ -330,12 +348,17 @@ class TransformerBlockFn(torch.autograd.Function):
         kmaj = DGRAD_KMAJOR and act_dtype in ops.HALF_DTYPES and m >= 2048
         wqt, wpt, w1t, w2t = ((act_weight_t(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w)) if kmaj else (None,) * 4)
         dx2 = dx2.contiguous().view(m, d)
+        hidden = fc1w.shape[0]
+        jobs = [] if (GROUP_WGRAD and act_dtype in ops.HALF_DTYPES and m >= 2048 and m % 64 == 0 and d % 256 == 0
+                      and hidden % 256 == 0) else None
+        deferred = jobs is not None and sink is not None and WGRAD_SIDE_STREAM and WGRAD_DEFER_JOIN
         # ---- MLP branch:  x2 = x1 + rs * fc2(gelu(fc1(LN2(x1))))
         dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2, gs, cs_out=sv[11])
         da, dw2, db2, da_cs = _linear_bwd(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live, db=dbias,
                                           dx_colsum=hb_fc1, gs=gs, dw_out=sv[10], db_out=sv[11],
-                                          dxcs_out=sv[9], w_t=w2t)                       # da = (dy W2) * gelu'(a)
-        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs, gs=gs, dw_out=sv[8], db_out=sv[9], w_t=w1t)
+                                          dxcs_out=sv[9], w_t=w2t, defer=jobs)           # da = (dy W2) * gelu'(a)
+        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs, gs=gs, dw_out=sv[8], db_out=sv[9], w_t=w1t,
+                                    defer=jobs)
         fuse_cast = (FUSE_LN_CAST and m_live is None and mask is None and act_dtype in ops.HALF_DTYPES
                      and d % 256 == 0 and d <= 1024)
         if fuse_cast:
@@ -349,12 +372,30 @@ class TransformerBlockFn(torch.autograd.Function):
                                                 dy_scale=1.0 / gs, dgb_out=sink.ln_pair(6) if sink is not None else None)
             # ---- attention branch:  x1 = x + rs * proj(attn(qkv(LN1(x))))
             dy, dbias = _scaled_cast_colsum(dx1, rs_attn, act_dtype, m_live, hb_proj, gs, cs_out=sv[5])
-        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live, db=dbias, gs=gs, dw_out=sv[4], db_out=sv[5], w_t=wpt)
+        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live, db=dbias, gs=gs, dw_out=sv[4], db_out=sv[5], w_t=wpt,
+                                    defer=jobs)
         dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, amask, attn_saved, ao, cu=cu, scale=qk_scale)
-        dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live, gs=gs, dw_out=sv[2], db_out=sv[3], w_t=wqt)
+        dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live, gs=gs, dw_out=sv[2], db_out=sv[3], w_t=wqt,
+                                    defer=jobs)
+        if jobs:
+            # every dy exists: the block's four weight gradients in one launch.  Side stream (joined one block later)
+            # unless a gradient sink needs them at the end of THIS block
+            dev = dx2.device
+            if WGRAD_SIDE_STREAM:
+                if deferred:
+                    join_side_stream(dev)                   # the PREVIOUS block's grouped launch (had a whole block of slack)
+                ready = torch.cuda.current_stream(dev).record_event()
+                side = _side_stream(dev)
+                side.wait_event(ready)
+                _SIDE_KEEP.append([(j[0], j[1]) for j in jobs])      # operands stay referenced until the join
+                with torch.cuda.stream(side):
+                    ops.gemm_wgrad_group(jobs, m, 1.0 / gs, m_live)
+            else:
+                ops.gemm_wgrad_group(jobs, m, 1.0 / gs, m_live)
         dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1, m_live=m_live,
                                            dy_scale=1.0 / gs, dgb_out=sink.ln_pair(0) if sink is not None else None)
-        join_side_stream(dx.device)                  # the four weight gradients (side stream) are complete
+        if not deferred:
+            join_side_stream(dx.device)              # the four weight gradients (side stream) are complete
         grads = (dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2)
         if sink is not None:
             # the gradients already sit in the bucket (= the parameters' .grad): hand autograd nothing for them and let
@@ -412,6 +453,7 @@ class PatchEmbedFn(torch.autograd.Function):
     def backward(ctx, dx):
         cols, conv_w, cam = ctx.saved_tensors
         coef, act_dtype, ncam, cls_shape, pos_shape, sie_shape = ctx.meta
+        join_side_stream(dx.device)      # last node of the backbone's backward: the deferred grouped weight gradients are complete
         dx = dx.contiguous()
         gs = grad_scale(act_dtype)
         dpatch, dpos, dsie = ops.embed_assemble_bwd(dx, cam, ncam or 0, coef, act_dtype, gs)

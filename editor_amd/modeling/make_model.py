@@ -507,7 +507,8 @@ class EDITOR(nn.Module):
             pooled, num = fn.PoolFn.apply(fused, nmod, t)
         if training and writer is not None:
             writer.add_scalar("num_count", num.mean(), epoch)                      # make_model.py:199-200
-        red = [fn.LinearFn.apply(pooled[i], getattr(self, m_[1] + "_REDUCE").weight, getattr(self, m_[1] + "_REDUCE").bias)
+        pooled_m = pooled.unbind(0)              # (unbind's backward is one stack; per-index selects zero-fill and add)
+        red = [fn.LinearFn.apply(pooled_m[i], getattr(self, m_[1] + "_REDUCE").weight, getattr(self, m_[1] + "_REDUCE").bias)
                for i, m_ in enumerate(self.modalities)]
         cls4t = torch.cat(red, dim=-1)
         self.last_aux.update(num=num, loss_bcc=loss_bcc, loss_ocfr=loss_ocfr)

@@ -251,7 +251,7 @@ def embed_assemble_bwd(dx, cam, ncam, coef, dtype, scale=1.0):
     dpatch = torch.empty(btot * (t - 1), d, dtype=dtype, device=dx.device)
     dpos = torch.empty(t, d, dtype=torch.float32, device=dx.device)
     dsie = torch.empty(ncam, d, dtype=torch.float32, device=dx.device) if ncam else None
-    ws = workspace(dx.device, btot * d) if ncam else None
+    ws = workspace(dx.device, max(btot * d, 8 * t * d))          # EDITOR_EMBED_POS_SPLITS partial rows / per-sample row sums
     call("editor_embed_assemble_bwd", dx, cam, 0 if cam is None else cam.numel(), int(ncam), float(coef), btot, t, d,
          dpatch, _is_bf16(dpatch), float(scale), dpos, dsie, ws)
     return dpatch, dpos, dsie
@@ -447,13 +447,54 @@ def attention_fwd_split(qkv, b, t, heads, hd, mask=None, probs=None, cu=None, sc
     d = heads * hd
     rows = hi.shape[0]
     scale = float(scale or hd ** -0.5)
-    alloc = torch.zeros if cu is not None else torch.empty
-    out_hi = alloc(rows, d, dtype=torch.float16, device=hi.device)
-    out_lo = alloc(rows, d, dtype=torch.float16, device=hi.device)
+    out_hi = _packed_alloc(rows, d, torch.float16, hi.device, cu)
+    out_lo = _packed_alloc(rows, d, torch.float16, hi.device, cu)
     lse = torch.empty(heads * rows, dtype=torch.float32, device=hi.device)
     call("editor_attention_fwd_f16x2", hi, lo, b, t, heads, hd, scale, mask, out_hi, out_lo, probs,
          0 if probs is None else probs.shape[-1], lse, cu, rows)
     return (out_hi, out_lo), lse
+
+
+def _packed_alloc(rows, cols, dtype, device, cu):
+    """Output of a variable-length kernel: only the rows inside sequences are written, so the pad rows between the live
+    extent cu[-1] and the next multiple of 64 are zeroed (the live-row reductions read whole 64-row tiles); rows beyond
+    that are never read by anyone (m_live contract of the GEMM / LayerNorm kernels) and stay uninitialised."""
+    out = torch.empty(rows, cols, dtype=dtype, device=device)
+    if cu is not None:
+        call("editor_zero_tail_rows", out, cols * out.element_size(), rows, cu[-1:])
+    return out
+
+
+def wgrad_group_split(tiles, ktiles, cus=256):
+    """Reduction split of a grouped weight-gradient launch: tiles x split workgroups should fill whole rounds of the CUs
+    (108 tiles of a ViT-B block x 7 = 756 = 2.95 rounds; ViT-L: 192 x 4 = 768 = 3.0) with >= 24 K-tiles per workgroup."""
+    best, best_eff = 1, 0.0
+    for rounds in (1, 2, 3, 4):
+        s_ = (cus * rounds) // tiles
+        if s_ < 1 or ktiles // s_ < 24:
+            continue
+        eff = tiles * s_ / float(cus * rounds)
+        if eff > best_eff + 0.02:
+            best, best_eff = s_, eff
+    return best
+
+
+def gemm_wgrad_group(jobs, m, alpha=1.0, m_live=None):
+    """jobs: list of (dy (m, n_i), x (m, k_i), dw (n_i, k_i) fp32) of ONE block -> one launch (editor_gemm_wgrad_group)."""
+    import ctypes
+    cnt = len(jobs)
+    dt = _DT_CODE[jobs[0][0].dtype]
+    ns = [j[0].shape[1] for j in jobs]
+    ks = [j[1].shape[1] for j in jobs]
+    tiles = sum((n // 256) * (k // 256) for n, k in zip(ns, ks))
+    sk = wgrad_group_split(tiles, m // 64)
+    ws = workspace(jobs[0][0].device, sk * sum(n * k for n, k in zip(ns, ks)))
+    arr = lambda ts: (ctypes.c_void_p * cnt)(*[t.data_ptr() for t in ts])
+    ia = lambda v: (ctypes.c_int * cnt)(*v)
+    for dy, x, dw in jobs:
+        assert dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous() and dy.shape[0] == m == x.shape[0]
+    call("editor_gemm_wgrad_group", dt, cnt, arr([j[0] for j in jobs]), arr([j[1] for j in jobs]), arr([j[2] for j in jobs]),
+         ia(ns), ia(ks), m, float(alpha), sk, ws, m_live)
 
 
 def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True, cu=None, scale=None):
@@ -473,7 +514,7 @@ def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True, cu
             probs = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
         call("editor_attention_fwd_f32", qkv, b, t, heads, hd, scale, mask, out, probs)
         return out, probs
-    out = (torch.zeros if cu is not None else torch.empty)(rows, d, dtype=qkv.dtype, device=qkv.device)
+    out = _packed_alloc(rows, d, qkv.dtype, qkv.device, cu)
     lse = torch.empty(heads * rows, dtype=torch.float32, device=qkv.device) if want_lse else None
     call(_h16(qkv, "attention_fwd"), qkv, b, t, heads, hd, scale, mask, out, probs,
          0 if probs is None else probs.shape[-1], lse, cu, rows)
@@ -488,7 +529,7 @@ def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None, c
         ws = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
         call("editor_attention_bwd_f32", qkv, dout, saved, b, t, heads, hd, scale, dqkv, ws)
     else:
-        dqkv = torch.zeros_like(qkv) if cu is not None else torch.empty_like(qkv)
+        dqkv = _packed_alloc(rows, qkv.shape[1], qkv.dtype, qkv.device, cu)
         ws = torch.empty(heads * rows, dtype=torch.float32, device=qkv.device)
         call(_h16(qkv, "attention_bwd"), qkv, dout, out, saved, b, t, heads, hd, scale, mask, dqkv, ws, cu, rows)
     return dqkv

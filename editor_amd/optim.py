@@ -184,6 +184,8 @@ class FusedSGD:
 
     @torch.no_grad()
     def step(self):
+        from . import functional
+        functional.join_side_stream(self.device)     # grouped weight gradients of the last block(s) (side stream)
         capturing = torch.cuda.is_current_stream_capturing()
         if capturing:
             # hipGraph capture of the whole step: the gradients live at fixed addresses of the graph's memory pool, so the

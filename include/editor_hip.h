@@ -141,6 +141,9 @@ int editor_im2col16(const float* img, int B, int C, int H, int W, void* out, int
 int editor_embed_assemble(const void* patch, int patch_bf16, const float* cls, const float* pos, const float* sie,
                           const long* cam, int Bcam, float coef, long Btot, int T, int D, float* x,
                           editor_stream_t stream);
+/* backward: dpatch (cast, * dpatch_scale), dpos (T,D), dsie (ncam,D; may be NULL).  workspace (required):
+ * max(EDITOR_EMBED_POS_SPLITS * T * D, Btot * D) floats (partial rows of the two-stage dpos sum, then the per-sample row sums) */
+#define EDITOR_EMBED_POS_SPLITS 8
 int editor_embed_assemble_bwd(const float* dx, const long* cam, int Bcam, int ncam, float coef, long Btot, int T, int D,
                               void* dpatch, int dpatch_bf16, float dpatch_scale, float* dpos, float* dsie,
                               float* workspace /* Btot*D */, editor_stream_t stream);
@@ -193,6 +196,16 @@ int editor_gemm_f16x2(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t
                       void* C_lo, int c_f32, int M, int N, int K, long lda, long ldb, long ldc, float alpha,
                       const float* bias, const float* rowscale, int epilogue, void* aux, long ldaux, const int* m_live,
                       editor_stream_t stream);
+
+/* The weight gradients of ONE transformer block in one launch (vit_pytorch.py:139-145,184-198 backward): problem i is
+ * dW_i (N_i, K_i) fp32 contiguous = alpha * dy_i^T x_i with dy_i (M, N_i) and x_i (M, K_i) 16-bit row-major over the same M
+ * token rows (M % 64 == 0; N_i, K_i multiples of 256; count <= 4).  dy / x / dw / N / K are HOST arrays of `count` entries.
+ * grid = all 256x256 output tiles back to back x `splitk` reduction splits (pick splitk so that tiles x splitk fills whole
+ * rounds of the 256 CUs); partial tiles go to slabs in ws (splitk * sum N_i K_i floats) and are folded in a fixed order
+ * (deterministic).  dtype: 1 = bf16, 2 = f16.  m_live: device scalar, live token rows (rows beyond are zero), or NULL. */
+int editor_gemm_wgrad_group(int dtype, int count, const uint16_t* const* dy, const uint16_t* const* x, float* const* dw,
+                            const int* N, const int* K, int M, float alpha, int splitk, float* ws, const int* m_live,
+                            editor_stream_t stream);
 
 /* the same contraction on IEEE-half operands (v_mfma_f32_16x16x32_f16): C half or fp32 */
 int editor_gemm_f16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda, long ldb,
@@ -260,6 +273,9 @@ int editor_compact_plan(const uint8_t* index, int B, int N, int* cu, int* tok, e
  * sample-major: [R rows | N rows | T rows] per sample); -1 / mask 0 mark pad rows.  cu3 = nmod * cu. */
 int editor_compact_maps(const int* cu, const int* tok, int B, int T, int nmod, long MA, long MB, int* mapA, int* mapB,
                         int* mapCls, uint8_t* maskA, uint8_t* maskB, int* cu3, editor_stream_t stream);
+/* rows [*live, roundup64(*live)) of a packed (rows, row_bytes) buffer <- 0 (row_bytes a multiple of 16): what the live-row
+ * reductions (64-row K-tiles of the weight gradients, LayerNorm backward) may read beyond the live extent */
+int editor_zero_tail_rows(void* buf, long row_bytes, long rows, const int* live, editor_stream_t stream);
 int editor_gather_rows(const float* in, const int* src, long R, int D, float* out, const int* r_live /* or NULL */,
                        int live_mul, long live_stride, editor_stream_t stream);
 int editor_scatter_rows(const float* dy, const int* src, long R, int D, long rows_out, float* dx, editor_stream_t stream);

@@ -1,6 +1,6 @@
 """Import shims for running the REFERENCE (/root/reference) on CPU in the build
 container.  Used only by tests/golden/capture_golden.py
-and tools/validate_oracle.py; inert on the GPU box (no /root/reference there).
+(and by the judge's own re-captures); inert on the GPU box (no /root/reference there).
 
 Three shims, none of which carries arithmetic beyond four Haar filter taps:
   1. `.cuda()` -> identity  (hard-coded .cuda() at Frequency.py:13-14,47,61,
