@@ -53,10 +53,19 @@ __device__ __forceinline__ Quad gather_level(float v, int lane, int bx, int by) 
     return haar_fwd(x00, x01, x10, x11);
 }
 
+// NMOD / NC > 0: compile-time modality / channel counts (the path's 3 x 3 and the 4-modal extension): all NMOD * NC * 2
+// row loads of a lane (8 bytes each: its 2 x 2 pixels) are REQUESTED UP FRONT - the butterflies of one (channel, modality)
+// plane are ~80 dependent shuffles / FMAs, and with the loads inside the runtime loops at most two were in flight per lane
+// while it waited (3.3 TB/s on 151 MB -> 3.9).  Measured and dropped: staging 16-row x 64-pixel strips of every plane through
+// LDS with one 16-byte load per thread and plane (full cache lines): 54 us against 39 - 39 KiB of LDS per block leaves a
+// quarter of the waves resident, and the kernel is bound by its shuffle chains, not by request granularity.
+// NMOD == 0: the generic runtime-count form.
+template <int NMOD, int NC>
 __global__ __launch_bounds__(256) void freq_counts_kernel(
     const float* __restrict__ m0, const float* __restrict__ m1, const float* __restrict__ m2, const float* __restrict__ m3,
-    int nmod, int B, int C, int H, int W, int32_t* __restrict__ counts)
+    int nmod_rt, int B, int C_rt, int H, int W, int32_t* __restrict__ counts)
 {
+    const int nmod = NMOD > 0 ? NMOD : nmod_rt, C = NMOD > 0 ? NC : C_rt;
     const int lane = threadIdx.x & 63;
     const int tiles_x = W >> 4, tiles_y = H >> 4, ntile = tiles_x * tiles_y;
     const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -68,16 +77,35 @@ __global__ __launch_bounds__(256) void freq_counts_kernel(
     const float* mods[4] = {m0, m1, m2, m3};
     const float fnm = (float)nmod;
 
+    constexpr int NPRE = NMOD > 0 ? NMOD * NC : 1;
+    float2 pre0[NPRE], pre1[NPRE];
+    if constexpr (NMOD > 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int m = 0; m < NMOD; ++m) {
+                const float* base = mods[m] + (((long)b * NC + c) * H + y0) * W + x0;
+                pre0[c * NMOD + m] = *reinterpret_cast<const float2*>(base);
+                pre1[c * NMOD + m] = *reinterpret_cast<const float2*>(base + W);
+            }
+    }
+
     float sum[4] = {0.f, 0.f, 0.f, 0.f};                 // channel sums of the reconstruction
-    for (int c = 0; c < C; ++c) {
+    auto channel = [&](int c) {
         Quad acc[4];                                      // modality-summed coefficients per level
 #pragma unroll
         for (int l = 0; l < 4; ++l) acc[l] = Quad{0.f, 0.f, 0.f, 0.f};
         float ll4 = 0.f;
-        for (int m = 0; m < nmod; ++m) {
-            const float* base = mods[m] + (((long)b * C + c) * H + y0) * W + x0;
-            const float2 r0 = *reinterpret_cast<const float2*>(base);
-            const float2 r1 = *reinterpret_cast<const float2*>(base + W);
+#pragma unroll
+        for (int m = 0; m < (NMOD > 0 ? NMOD : 4); ++m) {
+            if (m >= nmod) break;
+            float2 r0, r1;
+            if constexpr (NMOD > 0) { r0 = pre0[c * NMOD + m]; r1 = pre1[c * NMOD + m]; }
+            else {
+                const float* base = mods[m] + (((long)b * C + c) * H + y0) * W + x0;
+                r0 = *reinterpret_cast<const float2*>(base);
+                r1 = *reinterpret_cast<const float2*>(base + W);
+            }
             Quad q1 = haar_fwd(r0.x, r0.y, r1.x, r1.y);
             Quad q2 = gather_level(q1.ll, lane, 1, 8);
             Quad q3 = gather_level(q2.ll, lane, 2, 16);
@@ -103,12 +131,33 @@ __global__ __launch_bounds__(256) void freq_counts_kernel(
         sum[1] += haar_inv(acc[0], 0, 1);
         sum[2] += haar_inv(acc[0], 1, 0);
         sum[3] += haar_inv(acc[0], 1, 1);
+    };
+    if constexpr (NMOD > 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) channel(c);
+    } else {
+        for (int c = 0; c < C; ++c) channel(c);
     }
     // sign(mean over channels) == sign(sum); torch.mean then .gt(0) (Frequency.py:44,54)
     const float cdiv = (float)C;
     int cnt = ((sum[0] / cdiv) > 0.f) + ((sum[1] / cdiv) > 0.f) + ((sum[2] / cdiv) > 0.f) + ((sum[3] / cdiv) > 0.f);
     cnt = wave_sum_i(cnt);
     if (lane == 0) counts[tile] = cnt;
+}
+
+static int freq_counts_launch(const float* m0, const float* m1, const float* m2, const float* m3, int nmod, int B, int C, int H, int W,
+                              int32_t* counts, hipStream_t stream)
+{
+    const long tiles = (long)B * (H >> 4) * (W >> 4);
+    const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+    if (nmod == 3 && C == 3)
+        hipLaunchKernelGGL((freq_counts_kernel<3, 3>), grid, block, 0, stream, m0, m1, m2, m3, nmod, B, C, H, W, counts);
+    else if (nmod == 4 && C == 3)
+        hipLaunchKernelGGL((freq_counts_kernel<4, 3>), grid, block, 0, stream, m0, m1, m2, m3, nmod, B, C, H, W, counts);
+    else
+        hipLaunchKernelGGL((freq_counts_kernel<0, 0>), grid, block, 0, stream, m0, m1, m2, m3, nmod, B, C, H, W, counts);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -307,11 +356,7 @@ extern "C" int editor_freq_counts_f32(const float* rgb, const float* nir, const 
 {
     if ((H & 15) || (W & 15) || B <= 0 || C <= 0) return (int)hipErrorInvalidValue;
     const int nmod = tir ? 3 : 2;
-    const long tiles = (long)B * (H >> 4) * (W >> 4);
-    hipLaunchKernelGGL(freq_counts_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream,
-                       rgb, nir, tir, nullptr, nmod, B, C, H, W, counts);
-    EDITOR_LAUNCH_CHECK();
-    return 0;
+    return freq_counts_launch(rgb, nir, tir, nullptr, nmod, B, C, H, W, counts, stream);
 }
 
 extern "C" int editor_freq_counts_nmod_f32(const float* m0, const float* m1, const float* m2, const float* m3, int nmod,
@@ -319,11 +364,7 @@ extern "C" int editor_freq_counts_nmod_f32(const float* m0, const float* m1, con
 {
     if ((H & 15) || (W & 15) || B <= 0 || C <= 0 || nmod < 2 || nmod > 4 || !m0 || !m1 || (nmod > 2 && !m2) || (nmod > 3 && !m3))
         return (int)hipErrorInvalidValue;
-    const long tiles = (long)B * (H >> 4) * (W >> 4);
-    hipLaunchKernelGGL(freq_counts_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream,
-                       m0, m1, m2, m3, nmod, B, C, H, W, counts);
-    EDITOR_LAUNCH_CHECK();
-    return 0;
+    return freq_counts_launch(m0, m1, m2, m3, nmod, B, C, H, W, counts, stream);
 }
 
 template <typename V>

@@ -261,8 +261,9 @@ def sfts_apply(feat, index, want_loss):
     nmod, b, t, d = feat.shape
     out = torch.empty_like(feat)
     loss = torch.empty(1, dtype=torch.float32, device=feat.device) if want_loss else None
-    ws = workspace(feat.device, 4096)
-    call("editor_sfts_apply", feat, index, nmod, b, t, d, out, loss, ws, 4096)
+    nblk = (b * t + 7) // 8                      # one partial BCC sum per block of 8 token rows (csrc/norm.hip SFTS_ROWS)
+    ws = workspace(feat.device, nblk)
+    call("editor_sfts_apply", feat, index, nmod, b, t, d, out, loss, ws, nblk)
     return out, loss
 
 
