@@ -90,14 +90,27 @@ class _GemmProbe:
                 probe.calls.append(["fwd", (m, n, k, kw.get("m_live"), False), ("split", a, b, c, c_lo, m, n, k), dict(kw)])
             return probe._orig_split(a, b, c, c_lo, m, n, k, **kw)
         ops.gemm_split = recorded_split
+        # the four weight gradients of a block as one grouped launch (editor_gemm_wgrad_group)
+        self._orig_group = ops.gemm_wgrad_group
+
+        def recorded_group(jobs, m, alpha=1.0, m_live=None):
+            if probe.recording:
+                nk = sum(j[0].shape[1] * j[1].shape[1] for j in jobs)
+                # (m, n, k) of the probe's FLOP formula 2 m n k with the token rows as the reduction: n * k -> sum_i N_i K_i
+                probe.calls.append(["wgrad", (nk, 1, m, m_live, True), ("group", list(jobs), m, alpha, m_live), {}])
+            return probe._orig_group(jobs, m, alpha, m_live)
+        ops.gemm_wgrad_group = recorded_group
 
     def remove(self):
         from editor_amd import ops
         ops.gemm = self._orig
         ops.gemm_split = self._orig_split
+        ops.gemm_wgrad_group = self._orig_group
 
     def _run(self, args, kw):
         if args and isinstance(args[0], str):
+            if args[0] == "group":
+                return self._orig_group(*args[1:], **kw)
             return self._orig_split(*args[1:], **kw)
         return self._orig(*args, **kw)
 
@@ -340,6 +353,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="time the eager step (no hipGraph attempt)")
     ap.add_argument("--no-replay", action="store_true", help="skip the GEMM replay / kernel micro-timings (clean rocprof totals)")
     ap.add_argument("--no-h2d", action="store_true", help="time the bare step instead of the reference loop's feeding (no H2D, no per-step sync)")
+    ap.add_argument("--act-light", action="store_true", help="activation-light blocks (cfg.MODEL.ACT_LIGHT): 24 B instead of 36 B "
+                    "saved per token-row-element (config 5 at B = 64 per GPU)")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-mode block (speed + accuracy of bf16 / f16 / f16x2 / f32)")
     args = ap.parse_args()
     if args.batch is None:
@@ -383,7 +398,7 @@ def main():
     from editor_amd import config, losses, synth
     from editor_amd.modeling import make_model
 
-    cfg, num_class, cams = config.preset(args.preset, compute_dtype=args.dtype, drop_path=0.1)
+    cfg, num_class, cams = config.preset(args.preset, compute_dtype=args.dtype, drop_path=0.1, act_light=args.act_light)
     torch.manual_seed(1111)                                       # SOLVER.SEED (config/defaults.py:138)
     import contextlib
     import io
@@ -450,12 +465,17 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 step()                                            # allocator / lazy-attribute warm-up on the capture stream
-                probe.recording = rank == 0                       # the GEMM launch list of one (eager) step
+                probe.recording = rank == 0 and not args.no_replay   # the GEMM launch list of one (eager) step: it keeps that
+                                                                  # step's operands alive for the replay (--no-replay: config 5 at B = 64)
                 step()
                 probe.recording = False
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             opt.zero_grad(set_to_none=True)
+            # the eager warm-up steps leave their activations CACHED in the allocator's ordinary pool; the capture allocates
+            # the same set again from the graph's private pool - hand the cached blocks back first, or large configurations
+            # (config 5 at B = 64: ~120 GB of saved activations) need twice their memory
+            torch.cuda.empty_cache()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 static_loss = step()
@@ -520,7 +540,7 @@ def main():
                 graph.replay()
                 loss_ = static_loss
             else:
-                probe.recording = rank == 0 and i == args.steps - 1 and not probe.calls
+                probe.recording = rank == 0 and i == args.steps - 1 and not probe.calls and not args.no_replay
                 loss_ = step()
                 probe.recording = False
             if feeding:
@@ -595,7 +615,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.preset} {nmod}-modal {arch}/16 {h}x{w}, batch {b}/GPU, fwd+bwd+SGD step, "
-                                   f"drop_path 0.1, SFTS+HMA HIP kernels",
+                                   f"drop_path 0.1, SFTS+HMA HIP kernels" + (", activation-light blocks" if args.act_light else ""),
                        "global_batch": world * b, "parallelism": f"dp{world}", "loss": round(lossv, 4),
                        "launch": ("hipGraph replay" + (" incl. RCCL bucket all-reduces (overlapped with backward)" if use_dist else ""))
                        if graph is not None else ("eager" + (", RCCL bucket all-reduces overlapped with backward" if use_dist else "")),

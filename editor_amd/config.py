@@ -36,6 +36,7 @@ def make_cfg(size_train=(256, 128), al=1, transformer_type="vit_base_patch16_224
     # extension knobs of this build (absent from the reference cfg => defaults)
     model.COMPUTE_DTYPE = extra.pop("compute_dtype", "bf16")   # 'bf16' | 'f32'
     model.HMA_COMPACT = extra.pop("hma_compact", True)
+    model.ACT_LIGHT = extra.pop("act_light", False)              # blocks save 24 B instead of 36 B per token-row-element
     model.ROLLOUT_PROBS = extra.pop("rollout_probs", False)      # bf16 mode: keep the materialised (L,3B,h,T,T) probabilities
     for k, v in extra.items():
         setattr(model, k.upper(), v)

@@ -74,6 +74,12 @@ def act_weight_t(w, dtype):
     return ent[2]
 
 
+# Activation-light blocks (cfg.MODEL.ACT_LIGHT; BASELINE config 5 at B = 64 per GPU does not fit otherwise): a block saves
+# 24 instead of 36 bytes per token-row-element - not the LayerNorm outputs h1 / h2 (recomputed in the backward from the saved
+# residual rows and statistics: one LayerNorm pass each) and not the GELU output g (recomputed from the saved pre-activation,
+# which then also feeds gelu' in the fc2 dgrad epilogue instead of a saved gelu').  Same forward bits; 16-bit modes only.
+ACT_LIGHT = False
+
 F16X2 = "f16x2"      # act_dtype marker of the split-precision forward: half pairs in the forward, plain f16 in the backward
 
 
@@ -165,7 +171,7 @@ WGRAD_DEFER_JOIN = os.environ.get("EDITOR_WGRAD_DEFER", "1") != "0"       # meas
 
 
 def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None, gs=1.0, dw_out=None,
-                db_out=None, dxcs_out=None, w_t=None, defer=None):
+                db_out=None, dxcs_out=None, w_t=None, defer=None, aux_is_grad=True):
     """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy) (or the
     caller's, when the kernel that produced dy summed its columns on the way).  dx_colsum: also return colsum(dx) - the
     bias gradient of the layer BELOW - from the dgrad's own epilogue when it can deliver it (else None).
@@ -186,7 +192,7 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, 
     if gelu_pre is None:
         ops.gemm(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, m_live=m_live, colsum=dxcs, colsum_scale=inv, tag="dgrad")
     else:
-        ag = ops.EPI_AUX_GRAD if dy.dtype in ops.HALF_DTYPES else 0      # 16-bit: gelu_pre holds gelu'(pre-activation)
+        ag = ops.EPI_AUX_GRAD if (dy.dtype in ops.HALF_DTYPES and aux_is_grad) else 0   # 16-bit: gelu_pre holds gelu'(pre-activation)
         ops.gemm(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, epilogue=ops.EPI_GELU_BWD | ag, aux=gelu_pre, m_live=m_live,
                  colsum=dxcs, colsum_scale=inv, tag="dgrad")
     dw = dw_out if dw_out is not None else torch.empty(n, k, dtype=torch.float32, device=dy.device)
@@ -302,6 +308,7 @@ class TransformerBlockFn(torch.autograd.Function):
             del gl
             ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
                                   qkvw, projw, fc1w, fc2w, mask, attn_saved, rowscale_attn, rowscale_mlp, cu, m_live)
+            ctx.light = None
             ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None,
                         tuple(x.shape), qk_scale, sink)
             return x2.view(x.shape)
@@ -322,13 +329,17 @@ class TransformerBlockFn(torch.autograd.Function):
         g = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
         # 16-bit modes: `a` receives gelu'(pre-activation) - all the backward needs of it (one multiply in the fc2 dgrad
         # epilogue instead of an erfc + exponential per element); the f32 parity kernels keep the pre-activation
-        ag = ops.EPI_AUX_GRAD if act_dtype in ops.HALF_DTYPES else 0
+        light = ACT_LIGHT and act_dtype in ops.HALF_DTYPES
+        ag = ops.EPI_AUX_GRAD if (act_dtype in ops.HALF_DTYPES and not light) else 0     # light: `a` keeps the pre-activation
         ops.gemm(h2, w1, g, m, hidden, d, d, d, hidden, 0, 0, bias=fc1b, epilogue=ops.EPI_GELU | ag, aux=a, m_live=m_live)
         x2 = torch.empty_like(x2d)
         ops.gemm(g, w2, x2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b, rowscale=rowscale_mlp,
                  epilogue=ops.EPI_RESIDUAL, aux=x1, m_live=m_live)
+        if light:
+            h1 = h2 = g = None                      # recomputed by the backward (n1b / n2b / eps ride along)
         ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
                               qkvw, projw, fc1w, fc2w, mask, attn_saved, rowscale_attn, rowscale_mlp, cu, m_live)
+        ctx.light = (n1b, n2b, float(eps)) if light else None
         ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None,
                     tuple(x.shape), qk_scale, sink)
         return x2.view(x.shape)
@@ -348,6 +359,11 @@ class TransformerBlockFn(torch.autograd.Function):
         kmaj = DGRAD_KMAJOR and act_dtype in ops.HALF_DTYPES and m >= 2048
         wqt, wpt, w1t, w2t = ((act_weight_t(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w)) if kmaj else (None,) * 4)
         dx2 = dx2.contiguous().view(m, d)
+        light = ctx.light
+        if light is not None:
+            # activation-light block: the GELU output for the fc2 weight gradient from the saved pre-activation (the fc2 dgrad
+            # epilogue evaluates gelu' from it as well); the LayerNorm outputs right before their weight gradients need them
+            g = ops.gelu_fwd(a)
         hidden = fc1w.shape[0]
         jobs = [] if (GROUP_WGRAD and act_dtype in ops.HALF_DTYPES and m >= 2048 and m % 64 == 0 and d % 256 == 0
                       and hidden % 256 == 0) else None
@@ -356,7 +372,9 @@ class TransformerBlockFn(torch.autograd.Function):
         dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2, gs, cs_out=sv[11])
         da, dw2, db2, da_cs = _linear_bwd(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live, db=dbias,
                                           dx_colsum=hb_fc1, gs=gs, dw_out=sv[10], db_out=sv[11],
-                                          dxcs_out=sv[9], w_t=w2t, defer=jobs)           # da = (dy W2) * gelu'(a)
+                                          dxcs_out=sv[9], w_t=w2t, defer=jobs, aux_is_grad=light is None)   # da = (dy W2) * gelu'(a)
+        if light is not None:
+            h2 = ops.layernorm_fwd(x1, n2w, light[1], light[2], act_dtype, mask, 0, want_stats=False, m_live=m_live)[0]
         dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs, gs=gs, dw_out=sv[8], db_out=sv[9], w_t=w1t,
                                     defer=jobs)
         fuse_cast = (FUSE_LN_CAST and m_live is None and mask is None and act_dtype in ops.HALF_DTYPES
@@ -375,6 +393,8 @@ class TransformerBlockFn(torch.autograd.Function):
         dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live, db=dbias, gs=gs, dw_out=sv[4], db_out=sv[5], w_t=wpt,
                                     defer=jobs)
         dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, amask, attn_saved, ao, cu=cu, scale=qk_scale)
+        if light is not None:
+            h1 = ops.layernorm_fwd(x2d, n1w, light[0], light[2], act_dtype, mask, 0, want_stats=False, m_live=m_live)[0]
         dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live, gs=gs, dw_out=sv[2], db_out=sv[3], w_t=wqt,
                                     defer=jobs)
         if jobs:

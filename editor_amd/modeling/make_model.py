@@ -294,6 +294,7 @@ class EDITOR(nn.Module):
                                                                    dim // base.heads, dim // self.hma_heads))
         if hasattr(cfg.MODEL, "GRAD_SCALE"):
             fn.set_f16_grad_scale(cfg.MODEL.GRAD_SCALE)
+        fn.ACT_LIGHT = bool(getattr(cfg.MODEL, "ACT_LIGHT", False))      # 24 instead of 36 saved bytes per token-row-element
         self.hma_compact = bool(getattr(cfg.MODEL, "HMA_COMPACT", True))
         self.rollout_probs = bool(getattr(cfg.MODEL, "ROLLOUT_PROBS", False))
         self.teacher_index = None            # optional (B,N) bool: force the SFTS selection (bf16 protocol)

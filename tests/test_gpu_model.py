@@ -325,3 +325,30 @@ def test_hipgraph_replay_matches_eager_training():
               "FUSE_block.attn1.qkv.weight", "BACKBONE.base.cls_token", "FUSE_BN.running_mean",
               "FUSE_block.memory_cls.RGB_centers"):
         assert torch.equal(sd1[k], sd2[k]), k
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_activation_light_blocks_match_default(dtype):
+    """cfg.MODEL.ACT_LIGHT (24 instead of 36 saved bytes per token-row-element: LayerNorm outputs and the GELU output are
+    recomputed in the backward): the forward is bit-identical, the gradients agree to 16-bit rounding (gelu' is then evaluated
+    from the saved pre-activation instead of read back rounded)."""
+    from editor_amd import functional as fn
+    outs, grads = [], []
+    try:
+        for light in (False, True):
+            torch.manual_seed(5)
+            m, cfg, c, cams = _model("RGBNT201", 41, dtype, drop_path=0.0, act_light=light)
+            assert fn.ACT_LIGHT == light
+            m.train()
+            img, label, cam, view = _cuda_batch(*synth.make_batch(42, 16, 256, 128, cams, instances=4))
+            out = m(img, label=label, cam_label=cam, view_label=view, writer=_Writer(), epoch=1)
+            total = out[-1] + sum((o * synth.uniform(5, "proj/%d" % i, tuple(o.shape)).cuda()).mean() for i, o in enumerate(out[:-1]))
+            total.backward()
+            outs.append([o.detach().clone() for o in out])
+            grads.append({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    finally:
+        fn.ACT_LIGHT = False
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    worst = max(rel_err(grads[1][k].cpu(), grads[0][k].cpu()) for k in grads[0] if grads[0][k].abs().max() > 0)
+    print(dtype, "activation-light vs default: worst gradient rel err", worst)
+    assert worst < (2e-2 if dtype == "bf16" else 3e-3)
