@@ -430,7 +430,7 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
-        if buckets is not None:
+        if buckets is not None and os.environ.get("EDITOR_BCAST_BUFFERS", "1") != "0":
             buckets.broadcast_buffers(model)       # DDP's per-forward broadcast_buffers (train_net.py:63-64: the default)
         out = model(img, label=label, cam_label=cam, view_label=view, img_path=None, writer=writer, epoch=1)
         loss = losses.loss_pairs(out, label)

@@ -268,12 +268,30 @@ class GradBuckets:
                 self._launch(b)
 
     def _launch(self, b):
-        if b["flat"].is_cuda:
-            from . import functional
-            functional.join_side_stream(b["flat"].device)   # the blocks' grouped weight gradients (side stream) are in the slots
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
+        if b["flat"].is_cuda:
+            # The bucket's slots are written on TWO streams: LayerNorm / bias gradients on the main stream, the blocks' grouped
+            # weight gradients on the side stream (editor_amd.functional).  The collective is issued from a third stream that
+            # waits for both - the main stream itself never waits for the side stream here (joining it at every bucket
+            # boundary stalled the backward by ~0.35 ms per bucket: 49.3 instead of 45.9 ms per step with a 1-rank group)
+            from . import functional
+            dev = b["flat"].device
+            comm = self._comm_stream(dev)
+            comm.wait_stream(torch.cuda.current_stream(dev))
+            side = functional._SIDE.get(dev.index)
+            if side is not None:
+                comm.wait_stream(side)
+            with torch.cuda.stream(comm):
+                b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
+        else:
+            b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
         self._inflight.append(b)
+
+    def _comm_stream(self, dev):
+        st = getattr(self, "_comm", None)
+        if st is None:
+            st = self._comm = torch.cuda.Stream(device=dev)
+        return st
 
     @torch.no_grad()
     def finish(self):
@@ -306,6 +324,8 @@ class GradBuckets:
             tail = dict(flat=flat, work=None)
             self._launch(tail)
         inv = 1.0 / self.world
+        if getattr(self, "_comm", None) is not None:
+            torch.cuda.current_stream(self._comm.device).wait_stream(self._comm)     # (re-joins the issuing stream: capture)
         for b in self._inflight:
             b["work"].wait()
             if not self._avg:
