@@ -157,6 +157,19 @@ def test_config5_4modal_vitl_eval_vs_oracle(oracle):
         print("config5", dtype, "cls4t rel err (teacher-forced):", e2)
         assert e2 < tol
         del m2
+    # split-precision forward: FREE-RUNNING - 513-token sequences take the chunked split attention kernel, the joint HMA
+    # block up to 2052 tokens; selection identical to the oracle's, features 1e-4
+    m3, _, _ = _large_model("f16x2", nmod=4)
+    m3.load_state_dict(sd)
+    m3 = m3.cuda().eval()
+    with torch.no_grad():
+        out3 = m3(gimg, cam_label=cam.cuda(), view_label=view.cuda())
+    for i in range(4):
+        assert torch.equal(m3.last_aux["attn_masks"][i].cpu().bool(), aux["attn_masks"][i]), i
+    assert torch.equal(m3.last_aux["index"].cpu().bool(), aux["index"])
+    e3 = rel_err(out3.cpu(), ref)
+    print("config5 f16x2 cls4t rel err (free-running, selection identical):", e3)
+    assert e3 < 1e-4
 
 
 def test_config5_4modal_vitl_train_step_vs_oracle(oracle):

@@ -258,6 +258,29 @@ def test_eval_16bit_384x128_config4(dtype):
     assert err < TOL[dtype]["eval_cls4t"]
 
 
+@pytest.mark.parametrize("tag,preset,h,w", [("vitb_256x128", "RGBNT201", 256, 128), ("vitb_384x128", "MSVR310", 384, 128)])
+def test_eval_f16x2_selection_and_features_match_reference_goldens(tag, preset, h, w):
+    """The split-precision forward against the REFERENCE's own outputs (goldens captured from /root/reference), free-running:
+    frequency mask, the three per-modality attention masks and the union index bit for bit, fused features to 1e-4 -
+    configs 2 / 3 geometry (T = 129) and config 4 geometry (T = 193, joint HMA block of up to 579 tokens: the chunked
+    split attention kernel)."""
+    g = load_golden("f3_eval_" + tag)
+    seed, batch = int(g["seed"]), int(g["batch"])
+    m, cfg, c, cams = _model(preset, seed, "f16x2", drop_path=0.0)
+    m.eval()
+    img, label, cam, view = _cuda_batch(*synth.make_batch(seed + 1, batch, h, w, cams))
+    with torch.no_grad():
+        cls4t = m(img, cam_label=cam, view_label=view)
+    aux = m.last_aux
+    assert torch.equal(aux["mask_fre"].cpu().bool(), t(g["mask_fre"]))
+    for i, n in enumerate(("rgb", "nir", "tir")):
+        assert torch.equal(aux["attn_masks"][i].cpu().bool(), t(g["mask_" + n])), n
+    assert torch.equal(aux["index"].cpu().bool(), t(g["index"]))
+    err = rel_err(cls4t.cpu(), g["cls4t"])
+    print("f16x2", tag, "cls4t rel err vs the reference's golden:", err)
+    assert err < 1e-4
+
+
 def test_hipgraph_replay_matches_eager_training():
     """The whole training step (forward, HIP loss head, backward with the side-stream weight gradients, fused SGD with
     drop-path) captured into a hipGraph and replayed == the same number of eager steps: identical kernels on identical
