@@ -64,7 +64,7 @@ constexpr int kMaxV = 4;   // float4 chunks per lane: D <= 64*4*4 = 1024
 // LayerNorm forward: y = (x-mean)*rstd*gamma+beta, optionally * rowmask (AttentionMask / MlpMasked zero
 // the LN output of unselected tokens, vit_pytorch.py:245,162).  One wave per row.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool SPLIT = false>     // SPLIT: y as the half pair (y, y_lo) of the split-precision forward
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, long M, int D, const uint8_t* __restrict__ rowmask, int mask_period,
     T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, const int* __restrict__ m_live,
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         o.y = ((v[i].y - mean) * rstd * g.y + bt.y) * keep;
         o.z = ((v[i].z - mean) * rstd * g.z + bt.z) * keep;
         o.w = ((v[i].w - mean) * rstd * g.w + bt.w) * keep;
-        if (y_lo) st_split(yr + c0, y_lo + row * D + c0, o);
+        if constexpr (SPLIT) st_split(yr + c0, y_lo + row * D + c0, o);
         else Vec4<T>::st(yr + c0, o);
     }
     if (lane == 0) { if (mean_out) mean_out[row] = mean; if (rstd_out) rstd_out[row] = rstd; }
@@ -823,7 +823,7 @@ extern "C" int editor_layernorm_fwd_f16x2(const float* x, const float* gamma, co
     hipStream_t stream)
 {
     if (D % 256 || D > 1024 || M <= 0 || !y_hi || !y_lo) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_fwd_kernel<f16_t>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream,
+    hipLaunchKernelGGL((layernorm_fwd_kernel<f16_t, true>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream,
                        x, gamma, beta, eps, M, D, rowmask, mask_period, (f16_t*)y_hi, mean, rstd, m_live, (f16_t*)y_lo);
     EDITOR_LAUNCH_CHECK();
     return 0;

@@ -43,6 +43,16 @@ def grad_scale(dtype):
     return F16_GRAD_SCALE if dtype == torch.float16 else 1.0
 
 
+def set_model_options(grad_scale_f16=None, act_light=None):
+    """Per-MODEL options, installed by EDITOR.forward for the nodes it is about to create (every node captures them in its
+    ctx at forward time, so two models with different settings can live in one process).  None = keep."""
+    global ACT_LIGHT
+    if grad_scale_f16 is not None:
+        set_f16_grad_scale(grad_scale_f16)
+    if act_light is not None:
+        ACT_LIGHT = bool(act_light)
+
+
 def invalidate_weight_cache():
     """Call after parameters were modified by something that does not bump tensor version counters
     (editor_amd.optim.FusedSGD's raw HIP update)."""
@@ -309,6 +319,7 @@ class TransformerBlockFn(torch.autograd.Function):
             ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
                                   qkvw, projw, fc1w, fc2w, mask, attn_saved, rowscale_attn, rowscale_mlp, cu, m_live)
             ctx.light = None
+            ctx.gs = grad_scale(act_dtype)
             ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None,
                         tuple(x.shape), qk_scale, sink)
             return x2.view(x.shape)
@@ -340,6 +351,7 @@ class TransformerBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
                               qkvw, projw, fc1w, fc2w, mask, attn_saved, rowscale_attn, rowscale_mlp, cu, m_live)
         ctx.light = (n1b, n2b, float(eps)) if light else None
+        ctx.gs = grad_scale(act_dtype)               # (the model's loss scale at forward time: the backward uses THIS one)
         ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None,
                     tuple(x.shape), qk_scale, sink)
         return x2.view(x.shape)
@@ -351,7 +363,7 @@ class TransformerBlockFn(torch.autograd.Function):
         b, t, d, heads, act_dtype, hb_qkv, hb_proj, hb_fc1, hb_fc2, xshape, qk_scale, sink = ctx.meta
         # gradient outputs in forward-argument order: n1w n1b qkvw qkvb projw projb n2w n2b fc1w fc1b fc2w fc2b
         sv = sink.views if sink is not None else [None] * 12
-        gs = grad_scale(act_dtype)                   # f16: half gradients travel loss-scaled (1.0 otherwise)
+        gs = ctx.gs                                  # f16: half gradients travel loss-scaled (1.0 otherwise)
         m = x2d.shape[0]
         hd = d // heads
         amask = None if cu is not None else mask
@@ -465,6 +477,7 @@ class PatchEmbedFn(torch.autograd.Function):
         x = ops.embed_assemble(patch, cls.view(-1), pos.view(t, d), None if sie is None else sie.view(-1, d),
                                cam, coef, btot, t, d)
         ctx.save_for_backward(cols, conv_w, cam)
+        ctx.gs = grad_scale(act_dtype)
         ctx.meta = (coef, act_dtype, None if sie is None else sie.shape[0], cls.shape, pos.shape,
                     None if sie is None else sie.shape)
         return x
@@ -475,7 +488,7 @@ class PatchEmbedFn(torch.autograd.Function):
         coef, act_dtype, ncam, cls_shape, pos_shape, sie_shape = ctx.meta
         join_side_stream(dx.device)      # last node of the backbone's backward: the deferred grouped weight gradients are complete
         dx = dx.contiguous()
-        gs = grad_scale(act_dtype)
+        gs = ctx.gs
         dpatch, dpos, dsie = ops.embed_assemble_bwd(dx, cam, ncam or 0, coef, act_dtype, gs)
         d = conv_w.shape[0]
         kdim = cols.shape[1]

@@ -292,9 +292,10 @@ class EDITOR(nn.Module):
                 "%s with COMPUTE_DTYPE=%s: head widths %d (backbone) / %d (HMA) - the bf16 / f16 attention kernels need 64; "
                 "use COMPUTE_DTYPE='f32' for this architecture" % (cfg.MODEL.TRANSFORMER_TYPE, cfg.MODEL.COMPUTE_DTYPE,
                                                                    dim // base.heads, dim // self.hma_heads))
-        if hasattr(cfg.MODEL, "GRAD_SCALE"):
-            fn.set_f16_grad_scale(cfg.MODEL.GRAD_SCALE)
-        fn.ACT_LIGHT = bool(getattr(cfg.MODEL, "ACT_LIGHT", False))      # 24 instead of 36 saved bytes per token-row-element
+        # per-model options of the autograd nodes (installed at the top of every forward, captured by the nodes' ctx)
+        self.grad_scale_f16 = float(cfg.MODEL.GRAD_SCALE) if hasattr(cfg.MODEL, "GRAD_SCALE") else None
+        self.act_light = bool(getattr(cfg.MODEL, "ACT_LIGHT", False))   # 24 instead of 36 saved bytes per token-row-element
+        fn.set_model_options(self.grad_scale_f16, self.act_light)
         self.hma_compact = bool(getattr(cfg.MODEL, "HMA_COMPACT", True))
         self.rollout_probs = bool(getattr(cfg.MODEL, "ROLLOUT_PROBS", False))
         self.teacher_index = None            # optional (B,N) bool: force the SFTS selection (bf16 protocol)
@@ -465,6 +466,7 @@ class EDITOR(nn.Module):
 
     # -- forward (make_model.py:150-258) ----------------------------------------------------------
     def forward(self, x, cam_label=None, label=None, view_label=None, img_path=None, mode=1, writer=None, epoch=None):
+        fn.set_model_options(self.grad_scale_f16, self.act_light)
         mods = [x[m_[0]].contiguous() for m_ in self.modalities]             # make_model.py:153-155
         rgb = mods[0]
         nmod = self.nmod

@@ -17,6 +17,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_grad_bucket_sinks_equal_plain_autograd(dtype):
-    cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ddp_selfcheck.py"), dtype], stdout=subprocess.PIPE,
-                        stderr=subprocess.STDOUT, text=True, timeout=900)
-    assert cp.returncode == 0 and "DDP-SELFCHECK-OK" in cp.stdout, cp.stdout[-3000:]
+    import torch
+    torch.cuda.empty_cache()           # this process may hold tens of GB of cached blocks from earlier tests: the child needs its own
+    out = ""
+    for attempt in range(2):           # (one retry: the rendezvous of a fresh process group occasionally fails on a busy box)
+        cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ddp_selfcheck.py"), dtype], stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT, text=True, timeout=900)
+        out = cp.stdout
+        if cp.returncode == 0 and "DDP-SELFCHECK-OK" in out:
+            return
+        if "AssertionError" in out or "differ" in out:
+            break                      # a real mismatch is never retried
+    raise AssertionError(out[-3000:])

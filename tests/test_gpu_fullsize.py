@@ -34,6 +34,10 @@ class _Writer:
         pass
 
 
+MEASURED = {}                      # dtype -> cls4t rel err at B = 128 (filled by test_config2_eval_b128_vs_oracle)
+NORTH_STAR_FEATURE_TOL = 1e-3      # BASELINE.json north_star: "within 1e-3 rel for bf16 features"
+
+
 def _check_selection_f32(aux, oaux, nmod=3, k=2, tie=2e-5, max_rows=8):
     """f32 parity mode at full size: the selection must equal the oracle's bit for bit EXCEPT on (sample, head) rows
     whose k-th / (k+1)-th rollout scores are tied within fp32 rounding in the oracle itself - 4608 rows per batch with a
@@ -106,6 +110,7 @@ def test_config2_eval_b128_vs_oracle(dtype, oracle_eval_c2):
                 out = m(gimg, cam_label=cam.cuda(), view_label=view.cuda())
         err = rel_err(out.cpu(), o["ref"])
         print(dtype, "B=128 cls4t rel err:", err)
+        MEASURED[dtype] = err
         assert err < TOL[dtype]["cls4t"]
         return
     agree = [(masks[i] == o["aux"]["attn_masks"][i]).float().mean().item() for i in range(3)]
@@ -117,7 +122,22 @@ def test_config2_eval_b128_vs_oracle(dtype, oracle_eval_c2):
         out = m(gimg, cam_label=cam.cuda(), view_label=view.cuda())
     err = rel_err(out.cpu(), o["ref"])
     print(dtype, "B=128 cls4t rel err (teacher-forced):", err)
+    MEASURED[dtype] = err
     assert err < TOL[dtype]["cls4t"]
+
+
+def test_feature_error_of_every_mode_against_the_north_star_bar():
+    """The north star's feature tolerance (1e-3 relative) against what every compute mode measures at B = 128 - stated, not
+    loosened: f32, f16x2 and f16 are inside it; bf16 (8-bit mantissas; the dtype BASELINE names and bench.py's default) is
+    NOT (6.5e-3: torch's own CPU bf16 autocast differs from fp32 by 7e-3), which is why the bench line
+    carries the accuracy of every mode next to its speed (`modes`).  Runs after test_config2_eval_b128_vs_oracle."""
+    if len(MEASURED) < 4:
+        pytest.skip("needs the four parametrisations of test_config2_eval_b128_vs_oracle in the same session")
+    print("cls4t rel err at B = 128 vs the north-star bar %.0e:" % NORTH_STAR_FEATURE_TOL,
+          {k: float("%.3g" % v) for k, v in MEASURED.items()})
+    assert MEASURED["f32"] < 1e-4 and MEASURED["f16x2"] < 1e-4            # fp32-class
+    assert MEASURED["f16"] < NORTH_STAR_FEATURE_TOL                       # the reference's own autocast dtype meets the bar
+    assert NORTH_STAR_FEATURE_TOL < MEASURED["bf16"] < 1e-2               # bf16 does NOT: the documented gap, visible here
 
 
 GRAD_KEYS = ["BACKBONE.base.blocks.0.attn.qkv.weight", "BACKBONE.base.blocks.0.attn.qkv.bias",
