@@ -522,6 +522,12 @@ def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True, cu
     return out, lse
 
 
+def attention_bwd_mode(fused=-1):
+    """0 (default) / 1: two-pass / fused backward for dense 129..160-token sequences (bit-identical; A/B switch); < 0: query.
+    Returns the previous setting (include/editor_hip.h: editor_attention_bwd_mode)."""
+    return int(_lib.lib().cdll.editor_attention_bwd_mode(int(fused)))
+
+
 def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None, cu=None, scale=None):
     scale = float(scale or hd ** -0.5)
     rows = qkv.shape[0]

@@ -264,6 +264,11 @@ int editor_attention_fwd_f16(const uint16_t* qkv, int B, int T, int heads, int h
 int editor_attention_bwd_f16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, int B,
                              int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv,
                              float* workspace, const int* cu, long Mtot, editor_stream_t stream);
+/* Backward form for dense unmasked sequences of 129..160 tokens (the backbone's): 0 (default) = the two-pass form every
+ * shape uses, 1 = fused (S, P, dP, dS computed once; dQ and dK / dV from one workgroup, dS handed over through LDS).
+ * Bit-identical results; the fused form measured slower (266 vs 222 us at T = 129) and exists for A/B measurements (also
+ * EDITOR_ATTN_FUSED_BWD=1 in the environment).  fused < 0: query only.  Returns the previous setting. */
+int editor_attention_bwd_mode(int fused);
 
 /* ---- compacted (variable-length) HMA: packing plan and row movement (csrc/compact.hip) ------------------ */
 /* index (B,N) uint8 -> cu (B+1): exclusive prefix sum of L_b = 1 + #selected; tok (>= cu[B] ints): token id (0 = cls,

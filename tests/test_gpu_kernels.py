@@ -143,6 +143,30 @@ def test_attention_fwd_bwd(ops, dtype, t, use_mask):
     assert rel_err(dqkv.float().cpu(), qr.grad) < _t(dtype, 3e-5, 2.5e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("t", [129, 130, 144, 145, 160])
+def test_attention_bwd_fused_equals_two_pass(ops, dtype, t):
+    """The fused backward of the dense 129..160-token sequences (S / P / dP / dS once, dS through LDS into the dQ product) is
+    the two-pass form bit for bit: same operands, same per-element expressions, same summation orders."""
+    b, heads, hd = 5, 12, 64
+    d = heads * hd
+    qkv = (torch.randn(b * t, 3 * d, generator=_g(11)) * 1.5).to(dtype).cuda()
+    do = torch.randn(b * t, d, generator=_g(12)).to(dtype).cuda()
+    o, saved = ops.attention_fwd(qkv, b, t, heads, hd, None, None)
+    prev = ops.attention_bwd_mode(0)
+    try:
+        two = ops.attention_bwd(qkv, do, b, t, heads, hd, None, saved, o).clone()
+        ops.attention_bwd_mode(1)
+        one = ops.attention_bwd(qkv, do, b, t, heads, hd, None, saved, o).clone()
+    finally:
+        ops.attention_bwd_mode(prev)
+    torch.cuda.synchronize()
+    assert torch.isfinite(one.float()).all()
+    for name, lo in (("dq", 0), ("dk", d), ("dv", 2 * d)):
+        x, y = one[:, lo:lo + d], two[:, lo:lo + d]
+        assert torch.equal(x, y), (name, int((x != y).sum()), float((x.float() - y.float()).abs().max()))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gelu(ops, dtype):
     a = (torch.randn(4096 * 4, generator=_g(1)) * 2).to(dtype)
