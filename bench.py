@@ -271,6 +271,43 @@ def modes_block(args, cfg, cams, own_value):
     return out
 
 
+def shader_clock_mhz(work, busy_ms=60.0, n=3000, sleep=6):
+    """The clock the CUs run at while `work` (a callable launching on the current stream) keeps the chip busy: one resident
+    wave samples (s_memtime = shader-clock cycles, s_memrealtime = the constant 100 MHz reference) on a second stream
+    (csrc/probe.hip: editor_probe_clock_trace; tools/clock_probe.py).  MI355X_MICROARCH.md quotes the MFMA peak at the
+    2.4 GHz boost clock and documents that the chip clocks to its power budget under dense GEMM load."""
+    import ctypes
+    from editor_amd import _lib
+    fn = _lib.probe_lib().editor_probe_clock_trace
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    fn.restype = ctypes.c_int
+    buf = torch.zeros(2 * n, dtype=torch.int64, device="cuda")
+    s_probe = torch.cuda.Stream()
+    work()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    work()
+    e1.record()
+    torch.cuda.synchronize()
+    reps = max(2, int(busy_ms / max(e0.elapsed_time(e1), 1e-3)))
+    if fn(buf.data_ptr(), n, sleep, s_probe.cuda_stream) != 0:
+        return None
+    for _ in range(reps):
+        work()
+    torch.cuda.synchronize()
+    t = buf.view(n, 2).cpu().numpy().astype("float64")
+    cyc, ref = t[:, 0] - t[0, 0], (t[:, 1] - t[0, 1]) / 100.0                  # shader cycles, microseconds
+    span = min(ref[-1], busy_ms * 1e3)
+    i0, i1 = int((ref >= 0.3 * span).argmax()), int((ref >= 0.9 * span).argmax())
+    if i1 <= i0:
+        return None
+    # (mean over the busy window, slowest and fastest 0.5 ms inside it)
+    w = 25
+    win = [(cyc[j + w] - cyc[j]) / (ref[j + w] - ref[j]) for j in range(i0, i1 - w, w) if ref[j + w] > ref[j]]
+    return float((cyc[i1] - cyc[i0]) / (ref[i1] - ref[i0])), (float(min(win)), float(max(win))) if win else None
+
+
 def _usable_cores():
     """Cores this process may really use: affinity mask, capped by the cgroup CPU quota (a container that
     reports 256 logical CPUs but is throttled to a few thrashes when handed 256 threads)."""
@@ -601,6 +638,15 @@ def main():
         if args.dtype == "f32":
             roof.update(bound="mfma (exact-f32 parity mode: v_mfma_f32_16x16x4_f32; not the performance path)",
                         achieved=None, frac=None, peak=PEAK_F32_TFLOPS)
+        if graph is not None and roof.get("frac") is not None:
+            # the peak above is priced at the 2.4 GHz boost clock; under this step's load the chip clocks to its power budget
+            try:
+                mhz = shader_clock_mhz(graph.replay)
+            except Exception:
+                mhz = None
+            if mhz:
+                roof["sclk_mhz_during_step"] = round(mhz[0], 0)
+                roof["sclk_mhz_min_max_0p5ms"] = None if mhz[1] is None else [round(mhz[1][0], 0), round(mhz[1][1], 0)]
         if not args.no_replay:
             roof["hbm_kernels"] = hbm_kernels(model, img, b, model.act_dtype)
         out = {

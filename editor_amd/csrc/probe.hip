@@ -56,7 +56,64 @@ __global__ void probe_mfma16_raw_kernel(const uint16_t* __restrict__ A, const ui
 #pragma unroll
     for (int r = 0; r < 4; ++r) D[((l >> 4) * 4 + r) * 16 + (l & 15)] = c[r];
 }
+// (s_memtime, s_memrealtime) pairs sampled by one lane every ~sleep * 64 * 127 shader cycles: the first counts the shader
+// clock, the second a constant 100 MHz reference - their ratio is the frequency the CUs actually run at while another
+// stream keeps the matrix cores busy (tools/clock_probe.py)
+__global__ void clock_trace_kernel(unsigned long long* out, int n, int sleep)
+{
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < n; ++i) {
+        out[2 * i] = __builtin_amdgcn_s_memtime();
+        out[2 * i + 1] = __builtin_amdgcn_s_memrealtime();
+        for (int j = 0; j < sleep; ++j) __builtin_amdgcn_s_sleep(127);
+    }
+}
+
+// nothing but matrix-core work: every wave issues `iters` x 8 independent v_mfma_f32_16x16x32_bf16 (register operands, no
+// memory traffic) - the rate the chip SUSTAINS on dense bf16 MFMA under its power management, to hold against the 2.5 PFLOP/s
+// that MI355X_MICROARCH.md quotes at the 2.4 GHz boost clock.  zero != 0: all-zero operands (the data-dependent part of the
+// matrix core's power draw switched off).
+typedef __attribute__((ext_vector_type(8))) short pshort8_t;
+typedef __attribute__((ext_vector_type(4))) float pfloat4_t;
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, int zero)
+{
+    const int l = threadIdx.x;
+    pshort8_t a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        a[e] = zero ? (short)0 : (short)(0x3f80 + ((l * 7 + e * 13) & 0x3f));          // bf16 values in [1, 1.5)
+        b[e] = zero ? (short)0 : (short)(0xbf80 + ((l * 5 + e * 11) & 0x3f));          // and in (-1.5, -1]
+    }
+    pfloat4_t c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = pfloat4_t{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)                 // (in place, as written: the builtin form gets its accumulators rotated through AGPR moves)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c[i]) : "v"(a), "v"(b));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += c[i][0] + c[i][1] + c[i][2] + c[i][3];
+    if (s == 12345.678f) out[0] = s;                               // (keeps the loop alive)
+}
+
 }  // namespace
+
+// grid x 4 wavefronts; FLOPs = grid * 4 * iters * 8 * 16384
+extern "C" int editor_probe_mfma_peak(float* out, int grid, int iters, int zero, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(grid), dim3(256), 0, stream, out, iters, zero);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_probe_clock_trace(unsigned long long* out, int n, int sleep, hipStream_t stream)
+{
+    hipLaunchKernelGGL(clock_trace_kernel, dim3(1), dim3(64), 0, stream, out, n, sleep);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int editor_probe_tr16(const int* addr, uint16_t* out, hipStream_t stream)
 {

@@ -22,6 +22,12 @@ int editor_probe_mfma16(const float* A, const float* B, float* D, editor_stream_
 /* D (16x16 fp32) = A (16x32) B (32x16) with the operands given as RAW 16-bit patterns (f16 != 0: IEEE half, else bf16):
  * pins the matrix core's treatment of subnormal half operands (tests/test_gpu_kernels.py) */
 int editor_probe_mfma16_raw(const uint16_t* A, const uint16_t* B, float* D, int f16, editor_stream_t stream);
+/* n (s_memtime, s_memrealtime) pairs (out: 2n u64), one every ~sleep x 8 k shader cycles, from a single resident wave:
+ * shader-clock cycles against the constant 100 MHz reference = the clock the CUs really run at (tools/clock_probe.py) */
+int editor_probe_clock_trace(unsigned long long* out, int n, int sleep, editor_stream_t stream);
+/* grid x 4 wavefronts each issuing iters x 8 independent v_mfma_f32_16x16x32_bf16 on register operands (no memory traffic):
+ * the dense bf16 rate the chip sustains under its power management.  FLOPs = grid * 4 * iters * 8 * 16384. */
+int editor_probe_mfma_peak(float* out, int grid, int iters, int zero, editor_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,28 @@ def main():
         if not only or kind_only == "wgrad":
             t = bench(lambda: ops.gemm(dy, x, dw, n, k, m, n, k, k, 1, 1, splitk=sk, epilogue=skf), iters)
             rows.append((f"wgrad(sk={sk})", n, k, fl / t / 1e9))
+    if os.environ.get("GEMM_SPLIT"):
+        # the split-precision forward products (COMPUTE_DTYPE 'f16x2'): three half products per output, rate quoted on 3x the FLOPs
+        for (n, k) in shapes:
+            x = ops.split_f32(torch.randn(m, k, device=dev, generator=g))
+            w = ops.split_f32(torch.randn(n, k, device=dev, generator=g) * 0.05, ops.SPLIT_WSCALE)
+            bias = torch.randn(n, device=dev, generator=g)
+            fl = 3 * 2.0 * m * n * k
+            yh, yl = torch.empty(m, n, device=dev, dtype=torch.float16), torch.empty(m, n, device=dev, dtype=torch.float16)
+            t = bench(lambda: ops.gemm_split(x, w, yh, yl, m, n, k, alpha=1.0 / ops.SPLIT_WSCALE, bias=bias), iters)
+            rows.append(("x2 fwd pair", n, k, fl / t / 1e9))
+            yf = torch.empty(m, n, device=dev)
+            t = bench(lambda: ops.gemm_split(x, w, yf, None, m, n, k, alpha=1.0 / ops.SPLIT_WSCALE, bias=bias), iters)
+            rows.append(("x2 fwd fp32", n, k, fl / t / 1e9))
+            aux = torch.empty(m, n, device=dev, dtype=torch.float16)
+            t = bench(lambda: ops.gemm_split(x, w, yh, yl, m, n, k, alpha=1.0 / ops.SPLIT_WSCALE, bias=bias,
+                                             epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, aux=aux), iters)
+            rows.append(("x2 fwd+gelu", n, k, fl / t / 1e9))
+            res = torch.randn(m, n, device=dev, generator=g)
+            rs = torch.rand(m, device=dev, generator=g)
+            t = bench(lambda: ops.gemm_split(x, w, yf, None, m, n, k, alpha=1.0 / ops.SPLIT_WSCALE, bias=bias, rowscale=rs,
+                                             epilogue=ops.EPI_RESIDUAL, aux=res), iters)
+            rows.append(("x2 fwd+resid", n, k, fl / t / 1e9))
     for r in rows:
         print("%-14s N=%-5d K=%-5d %8.1f TFLOP/s" % r)
 
