@@ -561,7 +561,22 @@ def main():
             for dst, src in zip((label, cam, view), stage[i & 1][1]):
                 dst.copy_(src, non_blocking=True)
 
+    if feed:
+        # the feed path itself (pinned -> staging on the copy stream, staging -> inputs, replay, device sync) once per staging
+        # buffer, untimed: on a fresh box its first pass pages in the copy kernels and the pinned buffers (measured: one
+        # 80 - 120 ms stall inside an 8-step timed region when it was first exercised there)
+        prefetch(0)
+        for i in range(2):
+            take(i)
+            prefetch(i + 1)
+            if graph is not None:
+                graph.replay()
+            else:
+                step()
+            torch.cuda.synchronize()
+
     def timed_loop(feeding):
+        iter_times = [] if os.environ.get("EDITOR_BENCH_ITER_TIMES") else None
         if feeding:
             prefetch(0)
         if use_dist:
@@ -582,9 +597,14 @@ def main():
                 probe.recording = False
             if feeding:
                 torch.cuda.synchronize()                  # engine/processor.py:107
+                if iter_times is not None:
+                    iter_times.append(time.perf_counter())
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+        if feeding and iter_times and rank == 0:          # EDITOR_BENCH_ITER_TIMES=1: per-iteration wall times to stderr
+            ts = [t0] + iter_times
+            print("iteration ms: " + " ".join("%.1f" % (1e3 * (ts[j + 1] - ts[j])) for j in range(len(ts) - 1)), file=sys.stderr)
         el_ = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(el_, op=dist.ReduceOp.MAX)

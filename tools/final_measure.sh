@@ -18,7 +18,9 @@ cp gpurun_out/prof_${tag}s/kernel_stats.csv gpurun_out/${tag}_bench_kernel_stats
 EDITOR_WGRAD_STREAM=0 bash tools/prof.sh ${tag}x2 --dtype f16x2 --no-replay --no-h2d --no-modes > gpurun_out/${tag}_prof_f16x2.txt 2>&1
 cp gpurun_out/prof_${tag}x2/kernel_stats.csv gpurun_out/${tag}_f16x2_kernel_stats_serial.csv
 TAG=${tag} bash tools/pmc_traffic.sh > gpurun_out/${tag}_pmc_traffic.log 2>&1
-GEMM_EPI=1 python tools/gemm_bench.py > gpurun_out/${tag}_gemm_bench.txt 2>&1
+GEMM_EPI=1 GEMM_SPLIT=1 python tools/gemm_bench.py > gpurun_out/${tag}_gemm_bench.txt 2>&1
+python tools/clock_probe.py > gpurun_out/${tag}_clock_probe.txt 2>&1
+python tools/attn_bench.py > gpurun_out/${tag}_attn_bench.txt 2>&1
 head -c 700 gpurun_out/${tag}_bench_line_default.json; echo
 for f in f16x2 f16 rgbnt100 msvr310 synth4l; do head -c 330 gpurun_out/${tag}_bench_line_$f.json; echo; done
 tail -4 gpurun_out/${tag}_repro_check.txt
