@@ -49,6 +49,10 @@ __device__ __forceinline__ float4_t mfma16(short8_t a, short8_t b, float4_t c)
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;          // 16 KiB per operand tile per stage
 
+#ifndef EDITOR_GEMM_GM
+#define EDITOR_GEMM_GM 4
+#endif
+
 struct GemmB16Args {
     const bf16_t* A; const bf16_t* B; void* C;
     int M, N, K;
@@ -853,7 +857,7 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
     constexpr int TH = (F0 + F1) * 16;                          // tile height
     constexpr int UNIT = 16384, KTB = 4 * UNIT;                 // per K-tile buffer: A0 | A1 | B0 | B1
     constexpr int UA0 = 0, UA1 = UNIT, UB0 = 2 * UNIT, UB1 = 3 * UNIT;
-    constexpr int GM = 4;
+    constexpr int GM = EDITOR_GEMM_GM;                          // tile rows per group (measured: tools/gm_sweep.sh)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = g.tiles_m * g.tiles_n;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
