@@ -964,9 +964,10 @@ __global__ __launch_bounds__(256) void attn_kv_long_kernel(AttnArgs a)
     }
 }
 
-// two-pass (0, default) or fused (1) backward for the dense 129..160-token sequences: EDITOR_ATTN_FUSED_BWD / editor_attention_bwd_mode.
+// two-pass (0, default) or fused (1) backward for the dense 129..160-token sequences: editor_attention_bwd_mode (the library's only
+// process-wide switch; editor_amd/ops.py sets it from EDITOR_ATTN_FUSED_BWD - no environment lookups in here).
 // Measured (MI355X, B = 384 sequences x 12 heads, T = 129, tools/attn_bench.py): two-pass 222 us, fused 266 us - see the kernel's comment.
-int g_fused_bwd = [] { const char* e = getenv("EDITOR_ATTN_FUSED_BWD"); return (e && e[0] == '1') ? 1 : 0; }();
+int g_fused_bwd = 0;
 
 template <typename K>
 int set_lds(K kern, size_t bytes)

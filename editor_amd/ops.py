@@ -522,6 +522,9 @@ def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True, cu
     return out, lse
 
 
+_ATTN_MODE_ENV = [False]
+
+
 def attention_bwd_mode(fused=-1):
     """0 (default) / 1: two-pass / fused backward for dense 129..160-token sequences (bit-identical; A/B switch); < 0: query.
     Returns the previous setting (include/editor_hip.h: editor_attention_bwd_mode)."""
@@ -536,6 +539,10 @@ def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None, c
         ws = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
         call("editor_attention_bwd_f32", qkv, dout, saved, b, t, heads, hd, scale, dqkv, ws)
     else:
+        if not _ATTN_MODE_ENV[0]:                       # EDITOR_ATTN_FUSED_BWD=1: the fused backward (A/B measurements), once
+            _ATTN_MODE_ENV[0] = True
+            if os.environ.get("EDITOR_ATTN_FUSED_BWD", "0") == "1":
+                attention_bwd_mode(1)
         dqkv = _packed_alloc(rows, qkv.shape[1], qkv.dtype, qkv.device, cu)
         ws = torch.empty(heads * rows, dtype=torch.float32, device=qkv.device)
         call(_h16(qkv, "attention_bwd"), qkv, dout, out, saved, b, t, heads, hd, scale, mask, dqkv, ws, cu, rows)

@@ -266,8 +266,9 @@ int editor_attention_bwd_f16(const uint16_t* qkv, const uint16_t* dout, const ui
                              float* workspace, const int* cu, long Mtot, editor_stream_t stream);
 /* Backward form for dense unmasked sequences of 129..160 tokens (the backbone's): 0 (default) = the two-pass form every
  * shape uses, 1 = fused (S, P, dP, dS computed once; dQ and dK / dV from one workgroup, dS handed over through LDS).
- * Bit-identical results; the fused form measured slower (266 vs 222 us at T = 129) and exists for A/B measurements (also
- * EDITOR_ATTN_FUSED_BWD=1 in the environment).  fused < 0: query only.  Returns the previous setting. */
+ * Bit-identical results; the fused form measured slower (266 vs 222 us at T = 129) and exists for A/B measurements (the
+ * Python host sets it from EDITOR_ATTN_FUSED_BWD=1; the library itself reads no environment).  Process-wide; fused < 0:
+ * query only.  Returns the previous setting. */
 int editor_attention_bwd_mode(int fused);
 
 /* ---- compacted (variable-length) HMA: packing plan and row movement (csrc/compact.hip) ------------------ */
