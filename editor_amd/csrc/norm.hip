@@ -64,7 +64,9 @@ constexpr int kMaxV = 4;   // float4 chunks per lane: D <= 64*4*4 = 1024
 // LayerNorm forward: y = (x-mean)*rstd*gamma+beta, optionally * rowmask (AttentionMask / MlpMasked zero
 // the LN output of unselected tokens, vit_pytorch.py:245,162).  One wave per row.
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool SPLIT = false>     // SPLIT: y as the half pair (y, y_lo) of the split-precision forward
+// RAGGED: D is a multiple of 4 but not of 256 (DeiT-small's 384): the last column group is guarded per lane.  A separate
+// instantiation, so that the 768 / 1024-wide path keeps its code (and its bits).
+template <typename T, bool SPLIT = false, bool RAGGED = false>     // SPLIT: y as the half pair (y, y_lo) of the split-precision forward
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, long M, int D, const uint8_t* __restrict__ rowmask, int mask_period,
     T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, const int* __restrict__ m_live,
@@ -74,19 +76,19 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m_live) M = min(M, (long)((*m_live + 63) & ~63));      // live rows, rounded up to the GEMM reduction tile (mask = 0 there)
     if (row >= M) return;
-    const int nv = D >> 8;                       // D / (64*4)
+    const int nv = RAGGED ? (D + 255) >> 8 : D >> 8;        // column groups of 64 lanes x 4
     const float* xr = x + row * D;
     float4 v[kMaxV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+    for (int i = 0; i < kMaxV; ++i) if (i < nv && (!RAGGED || (i * 64 + lane) * 4 < D)) {
         v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+    for (int i = 0; i < kMaxV; ++i) if (i < nv && (!RAGGED || (i * 64 + lane) * 4 < D)) {
         const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
         q += (a * a + b * b) + (c * c + d * d);
     }
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const float keep = (rowmask && !rowmask[mask_period ? row % mask_period : row]) ? 0.f : 1.f;
     T* yr = y + row * D;
 #pragma unroll
-    for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+    for (int i = 0; i < kMaxV; ++i) if (i < nv && (!RAGGED || (i * 64 + lane) * 4 < D)) {
         const int c0 = (i * 64 + lane) * 4;
         const float4 g = *reinterpret_cast<const float4*>(gamma + c0);
         const float4 bt = *reinterpret_cast<const float4*>(beta + c0);
@@ -123,7 +125,7 @@ __device__ __forceinline__ float round_like(float v, f16_t) { return f16_to_f32(
 // ------------------------------------------------------------------------------------------------
 // NV = D / 256 (float4 column groups per lane) and CAST (the second output) are compile-time: with worst-case-sized arrays
 // and the cast accumulators always present the kernel needed 150 registers (3 waves per SIMD) instead of <= 128.
-template <typename T, int NV, bool CAST>
+template <typename T, int NV, bool CAST, bool RAGGED = false>       // RAGGED: NV = ceil(D / 256), last group guarded (see the forward)
 __global__ __launch_bounds__(256, NV <= 3 ? 4 : 3) void layernorm_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ mean_in, const float* __restrict__ rstd_in, long M, int D,
     const uint8_t* __restrict__ rowmask, int mask_period, const float* __restrict__ dx_in, float* __restrict__ dx_out,
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 3) void layernorm_bwd_kernel(con
     for (int i = 0; i < NV; ++i) {
         dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i];
         if (CAST) ccs[i] = dg[i];
-        g[i] = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
+        g[i] = (!RAGGED || (i * 64 + lane) * 4 < D) ? *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4) : dg[i];
     }
     for (long row = (long)blockIdx.x * 4 + w; row < M; row += (long)gridDim.x * 4) {
         const bool keep = !(rowmask && !rowmask[mask_period ? row % mask_period : row]);
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 3) void layernorm_bwd_kernel(con
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c0 = (i * 64 + lane) * 4;
+            if (RAGGED && c0 >= D) { xh[i] = make_float4(0.f, 0.f, 0.f, 0.f); d[i] = xh[i]; continue; }   // (adds zeros to every sum)
             const float4 xv = *reinterpret_cast<const float4*>(x + row * D + c0);
             d[i] = keep ? Vec4<T>::ld(dy + row * D + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
             d[i].x *= dy_scale; d[i].y *= dy_scale; d[i].z *= dy_scale; d[i].w *= dy_scale;   // (loss-scaled f16 gradients)
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 3) void layernorm_bwd_kernel(con
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c0 = (i * 64 + lane) * 4;
+            if (RAGGED && c0 >= D) continue;
             float4 o;
             o.x = rstd * (d[i].x - s1 - xh[i].x * s2);
             o.y = rstd * (d[i].y - s1 - xh[i].y * s2);
@@ -655,9 +659,14 @@ extern "C" int editor_layernorm_fwd(const float* x, const float* gamma, const fl
     const uint8_t* rowmask, int mask_period, void* y, int y_bf16, float* mean, float* rstd, const int* m_live,
     hipStream_t stream)
 {
-    if (D % 256 || D > 1024 || M <= 0) return (int)hipErrorInvalidValue;
-    DISPATCH_T(y_bf16, hipLaunchKernelGGL(layernorm_fwd_kernel<TT>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream,
-               x, gamma, beta, eps, M, D, rowmask, mask_period, (TT*)y, mean, rstd, m_live));
+    if (D % 4 || D > 1024 || M <= 0) return (int)hipErrorInvalidValue;
+    if (D % 256) {
+        DISPATCH_T(y_bf16, hipLaunchKernelGGL((layernorm_fwd_kernel<TT, false, true>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
+                   stream, x, gamma, beta, eps, M, D, rowmask, mask_period, (TT*)y, mean, rstd, m_live, (TT*)nullptr));
+    } else {
+        DISPATCH_T(y_bf16, hipLaunchKernelGGL(layernorm_fwd_kernel<TT>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream,
+                   x, gamma, beta, eps, M, D, rowmask, mask_period, (TT*)y, mean, rstd, m_live));
+    }
     EDITOR_LAUNCH_CHECK();
     return 0;
 }
@@ -668,14 +677,26 @@ int layernorm_bwd_impl(const void* dy, int dy_bf16, float dy_scale, const float*
     float* dgamma, float* dbeta, float* workspace, int ws_rows, const int* m_live, void* cast_out, const float* cast_rowscale,
     float cast_scale, float* cast_colsum, float cast_colsum_scale, hipStream_t stream)
 {
-    if (D % 256 || D > 1024 || M <= 0 || ws_rows < 1) return (int)hipErrorInvalidValue;
-    if (cast_out && (dy_bf16 == 0 || m_live || rowmask)) return (int)hipErrorInvalidValue;    // dense 16-bit rows only
+    if (D % 4 || D > 1024 || M <= 0 || ws_rows < 1) return (int)hipErrorInvalidValue;
+    if (cast_out && (dy_bf16 == 0 || m_live || rowmask || D % 256)) return (int)hipErrorInvalidValue;    // dense 16-bit rows only
     long blocks = (M + 3) / 4;
     if (blocks > ws_rows) blocks = ws_rows;
     float* cast_partials = (cast_out && cast_colsum) ? workspace + (long)ws_rows * 2 * D : nullptr;   // third [ws_rows][D] region
 #define LN_BWD_LAUNCH(NVv, CASTv) DISPATCH_T(dy_bf16, hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NVv, CASTv>), dim3((unsigned)blocks), \
         dim3(256), 0, stream, (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out,                            \
         dgamma ? workspace : nullptr, m_live, dy_scale, (TT*)cast_out, cast_rowscale, cast_scale, cast_partials))
+    if (D % 256) {                       // ragged width (384): guarded instantiations, no cast output
+#define LN_BWD_RAGGED(NVv) DISPATCH_T(dy_bf16, hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NVv, false, true>), dim3((unsigned)blocks), \
+        dim3(256), 0, stream, (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out,                            \
+        dgamma ? workspace : nullptr, m_live, dy_scale, (TT*)nullptr, (const float*)nullptr, 1.f, (float*)nullptr))
+        switch ((D + 255) >> 8) {
+            case 1: LN_BWD_RAGGED(1); break;
+            case 2: LN_BWD_RAGGED(2); break;
+            case 3: LN_BWD_RAGGED(3); break;
+            default: LN_BWD_RAGGED(4); break;
+        }
+#undef LN_BWD_RAGGED
+    } else
     switch ((D >> 8) * 2 + (cast_out ? 1 : 0)) {
         case 2: LN_BWD_LAUNCH(1, false); break;
         case 3: LN_BWD_LAUNCH(1, true); break;

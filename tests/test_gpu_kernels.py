@@ -26,7 +26,7 @@ def _g(seed):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("d", [768, 256, 1024])
+@pytest.mark.parametrize("d", [768, 256, 1024, 384, 196])        # 384 (DeiT-small), 196: widths that are not multiples of 256
 def test_layernorm_fwd_bwd(ops, dtype, d):
     m = 517
     x = torch.randn(m, d, generator=_g(1)) * 2 + 0.3

@@ -95,6 +95,47 @@ def test_train_parity_f32(tag, preset, oracle):
     assert rel_err(m.FUSE_BN.running_mean[:64].cpu(), g["bn_mean"]) < 1e-4
 
 
+@pytest.mark.parametrize("arch,heads,qk", [("vit_small_patch16_224", 8, 768 ** -0.5), ("deit_small_patch16_224", 6, None)])
+def test_small_factory_architectures_f32_vs_oracle(arch, heads, qk, oracle):
+    """The reference factory's other backbones (vit_pytorch.py:704-727): ViT-small (8 heads of 96, qk_scale 768^-0.5) and
+    DeiT-small (width 384: LayerNorm rows that are not a multiple of 256 columns, HMA heads of 32) run in the f32 parity mode
+    (the 16-bit attention kernels are written for 64-wide heads) - eval forward and one training step
+    against the oracle: selection bit-identical, outputs <= 1e-3, gradients <= 2e-3."""
+    seed, batch = 5, 4
+    m, cfg, c, cams = _model("RGBNT201", seed, "f32", drop_path=0.0, transformer_type=arch)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    img, label, cam, view = synth.make_batch(seed, batch, 256, 128, cams, instances=2)
+    kw = dict(al=cfg.MODEL.AL, heads=heads, hma_heads=12, qk_scale=qk)
+    with torch.no_grad():
+        ref, aux = oracle.editor_forward({k: v.clone() for k, v in sd.items()}, img, cam, training=False, return_aux=True, **kw)
+    gimg, glabel, gcam, gview = _cuda_batch(img, label, cam, view)
+    m.eval()
+    with torch.no_grad():
+        out = m(gimg, cam_label=gcam, view_label=gview)
+    assert torch.equal(m.last_aux["index"].cpu().bool(), aux["index"])
+    assert rel_err(out.cpu(), ref) < 1e-3
+    # one training step: outputs and a spread of parameter gradients
+    leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and "centers" not in k else v.clone())
+            for k, v in sd.items()}
+    ref_out = oracle.editor_forward(leaf, img, cam, label=label, training=True, **kw)
+    oracle.projection_loss(list(ref_out)).backward()
+    m.train()
+    outs = m(gimg, label=glabel, cam_label=gcam, view_label=gview, writer=_Writer(), epoch=1)
+    assert len(outs) == len(ref_out)
+    for i, (o, r) in enumerate(zip(outs, ref_out)):
+        assert rel_err(o.detach().cpu(), r.detach()) < 1e-3, i
+    total = outs[-1]
+    for i, o in enumerate(outs[:-1]):
+        total = total + (o * synth.uniform(5, "proj/%d" % i, tuple(o.shape)).cuda()).mean()
+    total.backward()
+    named = dict(m.named_parameters())
+    for key in ("BACKBONE.base.blocks.0.norm1.weight", "BACKBONE.base.blocks.0.attn.qkv.weight", "BACKBONE.base.blocks.3.mlp.fc2.bias",
+                "BACKBONE.base.blocks.7.attn.proj.weight", "BACKBONE.base.patch_embed.proj.weight", "BACKBONE.base.cls_token",
+                "BACKBONE.base.pos_embed", "FUSE_block.attn1.qkv.weight", "FUSE_block.normR.weight", "FUSE_HEAD.weight",
+                "RGB_REDUCE.weight"):
+        assert rel_err(named[key].grad.cpu(), leaf[key].grad) < 2e-3, key
+
+
 def test_forward_rejects_cpu():
     from editor_amd.modeling import make_model
     cfg, c, cams = config.preset("RGBNT201")
