@@ -843,9 +843,13 @@ extern "C" int editor_layernorm_fwd_f16x2(const float* x, const float* gamma, co
     const uint8_t* rowmask, int mask_period, uint16_t* y_hi, uint16_t* y_lo, float* mean, float* rstd, const int* m_live,
     hipStream_t stream)
 {
-    if (D % 256 || D > 1024 || M <= 0 || !y_hi || !y_lo) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((layernorm_fwd_kernel<f16_t, true>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream,
-                       x, gamma, beta, eps, M, D, rowmask, mask_period, (f16_t*)y_hi, mean, rstd, m_live, (f16_t*)y_lo);
+    if (D % 4 || D > 1024 || M <= 0 || !y_hi || !y_lo) return (int)hipErrorInvalidValue;
+    if (D % 256)
+        hipLaunchKernelGGL((layernorm_fwd_kernel<f16_t, true, true>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream,
+                           x, gamma, beta, eps, M, D, rowmask, mask_period, (f16_t*)y_hi, mean, rstd, m_live, (f16_t*)y_lo);
+    else
+        hipLaunchKernelGGL((layernorm_fwd_kernel<f16_t, true>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream,
+                           x, gamma, beta, eps, M, D, rowmask, mask_period, (f16_t*)y_hi, mean, rstd, m_live, (f16_t*)y_lo);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

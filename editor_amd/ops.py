@@ -448,6 +448,11 @@ def attention_fwd_split(qkv, b, t, heads, hd, mask=None, probs=None, cu=None, sc
     d = heads * hd
     rows = hi.shape[0]
     scale = float(scale or hd ** -0.5)
+    if hd != 64:                                         # (see attention_fwd) the pair is summed back into fp32 - exact - first
+        if cu is not None:
+            raise RuntimeError("variable-length attention needs 64-wide heads (use the dense-masked HMA form)")
+        out32, probs = attention_fwd(hi.float() + lo.float(), b, t, heads, hd, mask, probs, cu=None, scale=scale)
+        return split_f32(out32), probs
     out_hi = _packed_alloc(rows, d, torch.float16, hi.device, cu)
     out_lo = _packed_alloc(rows, d, torch.float16, hi.device, cu)
     lse = torch.empty(heads * rows, dtype=torch.float32, device=hi.device)
@@ -515,6 +520,16 @@ def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True, cu
             probs = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
         call("editor_attention_fwd_f32", qkv, b, t, heads, hd, scale, mask, out, probs)
         return out, probs
+    if hd != 64:
+        # head widths other than 64 (ViT-small: 96, DeiT-small's HMA: 32; no shipped config): the 16-bit kernels are written
+        # for 64-wide heads, so this product runs on the exact-f32 attention kernels between two casts - correct, not fast.
+        # `saved` is then the fp32 probability tensor (4-D), which attention_bwd recognises.
+        if cu is not None:
+            raise RuntimeError("variable-length attention needs 64-wide heads (use the dense-masked HMA form)")
+        if probs is not None and probs.shape[-1] != t:
+            raise RuntimeError("attention_fwd: probability rows of a non-64-wide head must be unpadded (ldp == T)")
+        out32, probs = attention_fwd(qkv.float(), b, t, heads, hd, mask, probs, cu=None, scale=scale)
+        return out32.to(qkv.dtype), probs
     out = _packed_alloc(rows, d, qkv.dtype, qkv.device, cu)
     lse = torch.empty(heads * rows, dtype=torch.float32, device=qkv.device) if want_lse else None
     call(_h16(qkv, "attention_fwd"), qkv, b, t, heads, hd, scale, mask, out, probs,
@@ -538,6 +553,8 @@ def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None, c
         dqkv = torch.empty_like(qkv)
         ws = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
         call("editor_attention_bwd_f32", qkv, dout, saved, b, t, heads, hd, scale, dqkv, ws)
+    elif hd != 64:                                      # (see attention_fwd: exact-f32 kernels between two casts)
+        dqkv = attention_bwd(qkv.float(), dout.float(), b, t, heads, hd, mask, saved, None, None, scale).to(qkv.dtype)
     else:
         if not _ATTN_MODE_ENV[0]:                       # EDITOR_ATTN_FUSED_BWD=1: the fused backward (A/B measurements), once
             _ATTN_MODE_ENV[0] = True

@@ -136,6 +136,61 @@ def test_small_factory_architectures_f32_vs_oracle(arch, heads, qk, oracle):
         assert rel_err(named[key].grad.cpu(), leaf[key].grad) < 2e-3, key
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f16x2"])
+@pytest.mark.parametrize("arch,heads,qk", [("vit_small_patch16_224", 8, 768 ** -0.5), ("deit_small_patch16_224", 6, None)])
+def test_small_factory_architectures_16bit_modes(arch, heads, qk, dtype, oracle):
+    """The same two backbones in the 16-bit modes: GEMMs, LayerNorms and every other kernel as usual; the attention products
+    of their non-64-wide heads run on the exact-f32 kernels between two casts (ops.attention_fwd), the rollout reads the
+    materialised probabilities and the HMA head takes its dense-masked form.  Checked like the ViT-B modes: features with
+    the oracle's selection teacher-forced (bf16 1e-2, f16 1e-3), f16x2 free-running with bit-identical selection; one
+    training step against the oracle's gradients."""
+    seed, batch = 5, 8
+    m, cfg, c, cams = _model("RGBNT201", seed, dtype, drop_path=0.0, transformer_type=arch)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    img, label, cam, view = synth.make_batch(seed, batch, 256, 128, cams, instances=4)
+    kw = dict(al=cfg.MODEL.AL, heads=heads, hma_heads=12, qk_scale=qk)
+    with torch.no_grad():
+        ref, aux = oracle.editor_forward({k: v.clone() for k, v in sd.items()}, img, cam, training=False, return_aux=True, **kw)
+    gimg, glabel, gcam, gview = _cuda_batch(img, label, cam, view)
+    m.eval()
+    if dtype != "f16x2":
+        m.teacher_index = aux["index"]
+    with torch.no_grad():
+        out = m(gimg, cam_label=gcam, view_label=gview)
+    if dtype == "f16x2":
+        assert torch.equal(m.last_aux["index"].cpu().bool(), aux["index"])
+    err = rel_err(out.cpu(), ref)
+    print(arch, dtype, "cls4t rel err:", err)
+    assert err < {"bf16": 1.0e-2, "f16": 1.0e-3, "f16x2": 1.0e-4}[dtype]
+    # training step (selection teacher-forced in every mode: the gradients are compared on the same graph)
+    m.teacher_index = aux["index"]
+    leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and "centers" not in k else v.clone())
+            for k, v in sd.items()}
+    ref_out = oracle.editor_forward(leaf, img, cam, label=label, training=True, teacher_index=aux["index"], **kw)
+    oracle.projection_loss(list(ref_out)).backward()
+    m.train()
+    outs = m(gimg, label=glabel, cam_label=gcam, view_label=gview, writer=_Writer(), epoch=1)
+    errs = [rel_err(o.detach().float().cpu(), r.detach()) for o, r in zip(outs, ref_out)]
+    print(arch, dtype, "train outputs rel err:", ["%.2e" % e for e in errs])
+    ftol = {"bf16": 1.8e-2, "f16": 2.1e-3, "f16x2": 1.0e-4}[dtype]
+    assert max(errs) < ftol, errs
+    total = outs[-1]
+    for i, o in enumerate(outs[:-1]):
+        total = total + (o * synth.uniform(5, "proj/%d" % i, tuple(o.shape)).cuda()).mean()
+    total.backward()
+    named = dict(m.named_parameters())
+    gtol = {"bf16": 7.5e-2, "f16": 4.0e-3, "f16x2": 2.5e-3}[dtype]      # measured x 1.5: 4.8e-2 (DeiT-small), 2.6e-3, 1.4e-3
+    worst = 0.0
+    for key in ("BACKBONE.base.blocks.0.norm1.weight", "BACKBONE.base.blocks.0.attn.qkv.weight", "BACKBONE.base.blocks.3.mlp.fc2.bias",
+                "BACKBONE.base.blocks.7.attn.proj.weight", "BACKBONE.base.cls_token", "FUSE_block.attn1.qkv.weight",
+                "FUSE_block.normR.weight", "FUSE_HEAD.weight", "RGB_REDUCE.weight"):
+        e = rel_err(named[key].grad.float().cpu(), leaf[key].grad)
+        print("   ", key, "%.2e" % e)
+        worst = max(worst, e)
+    print(arch, dtype, "worst gradient rel err:", worst)
+    assert worst < gtol
+
+
 def test_forward_rejects_cpu():
     from editor_amd.modeling import make_model
     cfg, c, cams = config.preset("RGBNT201")
