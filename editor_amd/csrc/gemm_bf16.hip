@@ -74,6 +74,8 @@ struct GemmB16Args {
     // leading dimension; the product is hi.hi + lo.hi + hi.lo in one fp32 accumulator (three passes over K)
     const bf16_t* A_lo; const bf16_t* B_lo;
     void* C_lo;                              // 16-bit outputs leave as a pair too (C = hi, C_lo = lo); NULL for fp32 outputs
+    int linear_ids;                          // ping-pong kernel: `bid` already is the position in the grouped tile order (the
+                                             // grouped weight-gradient launch does its own XCD mapping)
 };
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: remember it per device index, so a
@@ -861,7 +863,7 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = g.tiles_m * g.tiles_n;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int wgid = g.linear_ids ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int grp = GM * g.tiles_n;
     const int gm0 = (wgid / grp) * GM, rem = wgid % grp;
     const int gsz = min(GM, g.tiles_m - gm0);
@@ -1275,11 +1277,19 @@ struct GemmGroupArgs { GemmB16Args p[kMaxGroup]; int start[kMaxGroup + 1]; int n
 template <bool F16>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_group_kernel(GemmGroupArgs ga)
 {
+    // 1-D grid of tiles x splits.  Consecutive workgroups go to consecutive XCDs; each XCD takes a CONTIGUOUS range of the
+    // split-major order, i.e. (almost) one split = one range of token rows: the tiles resident on an XCD then read the same
+    // rows of dy and x at the same time and share them through its L2.  (Tile-major across XCDs - round 3's first version -
+    // had every (tile, split) stream its own panels: 5.5 GB fetched per block for 1.3 GB of operands.)
+    const int ntile = ga.start[ga.n], total = (int)gridDim.x;
+    const int L = (int)blockIdx.x, xcd = L & 7, q = total >> 3, r = total & 7;
+    const int Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    const int split = Lp / ntile, t = Lp % ntile;
     int pi = 0;
 #pragma unroll
-    for (int i = 1; i < kMaxGroup; ++i) pi += (i < ga.n && (int)blockIdx.x >= ga.start[i]) ? 1 : 0;
+    for (int i = 1; i < kMaxGroup; ++i) pi += (i < ga.n && t >= ga.start[i]) ? 1 : 0;
     pi = __builtin_amdgcn_readfirstlane(pi);
-    pp_body<F16, false, false, true, 8, 8, false>(ga.p[pi], (int)blockIdx.x - ga.start[pi], blockIdx.y);
+    pp_body<F16, false, false, true, 8, 8, false>(ga.p[pi], t - ga.start[pi], split);
 }
 
 __global__ void scale_c_kernel(float* C, long rows, int cols, long ld, float beta)
@@ -1554,7 +1564,7 @@ int gemm_wgrad_group(int count, const uint16_t* const* dy, const uint16_t* const
         // output (N_i, K_i); "A" = dy stored (Kred = M, N_i) row-k, "B" = x stored (Kred = M, K_i) row-k
         GemmB16Args g{(const bf16_t*)dy[i], (const bf16_t*)x[i], (void*)slab[i], N[i], K[i], M, (long)N[i], (long)K[i], (long)K[i],
                       alpha, 0.f, nullptr, nullptr, splitk, N[i] / 256, K[i] / 256, EDITOR_EPI_NONE, nullptr, (long)K[i], 1,
-                      m_live, 1, 1, nullptr, nullptr, 1, 0, 0, nullptr, nullptr, nullptr};
+                      m_live, 1, 1, nullptr, nullptr, 1, 0, 0, nullptr, nullptr, nullptr, 1};
         ga.p[i] = g;
         ga.start[i] = tiles;
         tiles += g.tiles_m * g.tiles_n;
@@ -1563,7 +1573,7 @@ int gemm_wgrad_group(int count, const uint16_t* const* dy, const uint16_t* const
     ga.start[count] = tiles;
     constexpr int LDS = 256 * (256 * 2 + 16) + (int)kLutBytes;
     if (int e = ensure_lds<gemm_bf16_pp_group_kernel<F16>>(LDS)) return e;
-    hipLaunchKernelGGL(gemm_bf16_pp_group_kernel<F16>, dim3(tiles, splitk), dim3(512), LDS, stream, ga);
+    hipLaunchKernelGGL(gemm_bf16_pp_group_kernel<F16>, dim3(tiles * splitk), dim3(512), LDS, stream, ga);
     EDITOR_LAUNCH_CHECK();
     for (int i = 0; i < count; ++i) {
         const long n4 = (long)N[i] * K[i] / 4;
