@@ -514,7 +514,8 @@ def main():
             # (config 5 at B = 64: ~120 GB of saved activations) need twice their memory
             torch.cuda.empty_cache()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            from editor_amd.ddp import graph_capture_kwargs
+            with torch.cuda.graph(graph, **graph_capture_kwargs()):        # (RCCL in the step: thread-local capture mode)
                 static_loss = step()
             graph.replay()                                        # one untimed replay
             torch.cuda.synchronize()

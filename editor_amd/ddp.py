@@ -371,3 +371,24 @@ class GradBuckets:
     def describe(self):
         return {"buckets": len(self.buckets) + 1, "bucket_mib": [round(b["flat"].numel() * 4 / 2 ** 20, 1) for b in self.buckets],
                 "segments": len(self.segments)}
+
+
+def graph_capture_kwargs(settle=0.3):
+    """Keyword arguments for `torch.cuda.graph(...)` when the captured step contains RCCL collectives, after giving the process
+    group's watchdog thread time to retire the work of the eager warm-up steps.
+
+    ProcessGroupNCCL's watchdog polls the completion events of enqueued collectives from ITS thread (`hipEventQuery`).  Under
+    the default capture mode ('global') any such call made by ANY thread while a capture is open fails with
+    hipErrorStreamCaptureUnsupported, the watchdog rethrows and the process aborts - intermittently: it needs a warm-up
+    collective that the watchdog has not reaped yet when the capture starts (measured: 1 run in 6 of tools/ddp_selfcheck.py).
+    'thread_local' restricts the check to the capturing thread; collectives issued INSIDE the capture are not handed to the
+    watchdog at all.  No process group: nothing to do."""
+    import time
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return {}
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    time.sleep(settle)                      # (the watchdog's polling interval is 100 ms)
+    return {"capture_error_mode": "thread_local"}
+

@@ -100,7 +100,8 @@ def main(dtype):
     torch.cuda.synchronize()
     opt1.zero_grad(set_to_none=True)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    from editor_amd.ddp import graph_capture_kwargs
+    with torch.cuda.graph(graph, **graph_capture_kwargs()):
         static_loss = s1()
     for _ in range(3):
         graph.replay()
