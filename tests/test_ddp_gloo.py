@@ -31,8 +31,11 @@ class _Toy(nn.Module):
 
 def _worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from editor_amd.ddp import GradReducer, graph_capture_kwargs
+    no_group = graph_capture_kwargs(settle=0.0)          # no process group: plain capture
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from editor_amd.ddp import GradReducer
+    # a step with collectives inside is captured in thread-local mode (the process group's watchdog thread polls events)
+    ret["cap%d" % rank] = (no_group == {} and graph_capture_kwargs(settle=0.0) == {"capture_error_mode": "thread_local"})
     torch.manual_seed(0)
     m = _Toy()
     red = GradReducer(m, bucket_bytes=64 * 1024)        # several buckets
@@ -63,6 +66,7 @@ def test_grad_reducer_world2():
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world))
+    assert all(ret["cap%d" % r] for r in range(world))
 
 
 def _worker_flat(rank, world, port, ret):
