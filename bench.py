@@ -386,7 +386,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f16x2", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
-    ap.add_argument("--graph", action="store_true", help="time a hipGraph replay of the captured step in THIS process")
+    ap.add_argument("--graph", action="store_true", help="time a hipGraph replay of the captured step in THIS process "
+                    "(default for 1 GPU, through a child process; opt-in for N > 1, where the eager step is the default)")
     ap.add_argument("--no-graph", action="store_true", help="time the eager step (no hipGraph attempt)")
     ap.add_argument("--no-replay", action="store_true", help="skip the GEMM replay / kernel micro-timings (clean rocprof totals)")
     ap.add_argument("--no-h2d", action="store_true", help="time the bare step instead of the reference loop's feeding (no H2D, no per-step sync)")
@@ -477,7 +478,11 @@ def main():
         opt.step()
         return loss
 
-    want_graph = args.graph or (use_dist and not args.no_graph)
+    # N > 1 (or EDITOR_FORCE_DDP): the EAGER step is timed unless --graph asks for the captured one.  Measured with a 1-rank RCCL
+    # group on one GPU, same box: eager 46.3 ms, graph replay with the bucket all-reduces inside 47.9 ms (the graph executor
+    # serialises the comm-stream branch more than the streams themselves do), and at N = 1 eager and replay tie (2 925 vs 2 937
+    # img/s) - so the captured form buys nothing there and is the one path no multi-rank box has ever run.
+    want_graph = args.graph
     side = torch.cuda.Stream() if want_graph else None
     if want_graph:
         # every eager step before the capture runs on a SIDE stream: AccumulateGrad nodes remember the stream they were
