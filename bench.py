@@ -308,6 +308,24 @@ def shader_clock_mhz(work, busy_ms=60.0, n=3000, sleep=6):
     return float((cyc[i1] - cyc[i0]) / (ref[i1] - ref[i0])), (float(min(win)), float(max(win))) if win else None
 
 
+def torch_gpu_yardstick():
+    """Plain PyTorch-ROCm (vendor BLAS + ATen, autocast) on THIS GPU for the dominant part of the step - the 12 ViT-B blocks over
+    3 x 128 sequences of 129 tokens, forward + backward + SGD, written as the reference writes them
+    (tools/torch_backbone_reference.py, run in a child process after this process has released its memory).  A yardstick for
+    the reader, beside `value`, which times the WHOLE step; nothing on the product path uses it."""
+    import subprocess
+    torch.cuda.empty_cache()
+    try:
+        cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "torch_backbone_reference.py")], stdout=subprocess.PIPE,
+                            stderr=subprocess.DEVNULL, text=True, timeout=600)
+        ms = {ln.split()[1]: float(ln.split()[2]) for ln in cp.stdout.splitlines() if ln.startswith("YARDSTICK")}
+    except Exception as e:
+        return {"error": type(e).__name__}
+    return {"what": "plain PyTorch-ROCm, autocast: ONLY the 12 ViT-B/16 blocks over the 3 x 128 stacked sequences (explicit q k^T softmax, "
+                    "attention maps kept for the rollout, as vit_pytorch.py:184-198,215-220), forward + backward + torch.optim.SGD, same GPU",
+            "ms_per_step": ms, "this_repo_whole_step_is": "ms_per_step of this line (patch embedding, blocks, SFTS, HMA, loss head, backward, SGD)"}
+
+
 def _usable_cores():
     """Cores this process may really use: affinity mask, capped by the cgroup CPU quota (a container that
     reports 256 logical CPUs but is throttled to a few thrashes when handed 256 threads)."""
@@ -700,6 +718,8 @@ def main():
             out["modes"] = modes_block(args, cfg, cams, out["value"])
         if world == 1 and not args.no_cpu_baseline and not force_ddp:
             out["cpu_baseline"] = cpu_baseline(model, cfg, cams, b, args.cpu_iters)
+            if args.preset == "RGBNT201" and b == 128:
+                out["torch_gpu_yardstick"] = torch_gpu_yardstick()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

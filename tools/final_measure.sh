@@ -21,6 +21,8 @@ TAG=${tag} bash tools/pmc_traffic.sh > gpurun_out/${tag}_pmc_traffic.log 2>&1
 GEMM_EPI=1 GEMM_SPLIT=1 python tools/gemm_bench.py > gpurun_out/${tag}_gemm_bench.txt 2>&1
 python tools/clock_probe.py > gpurun_out/${tag}_clock_probe.txt 2>&1
 python tools/attn_bench.py > gpurun_out/${tag}_attn_bench.txt 2>&1
+python tools/blas_reference.py > gpurun_out/${tag}_blas_reference.txt 2>&1
+python tools/torch_backbone_reference.py > gpurun_out/${tag}_torch_backbone_reference.txt 2>&1
 head -c 700 gpurun_out/${tag}_bench_line_default.json; echo
 for f in f16x2 f16 rgbnt100 msvr310 synth4l; do head -c 330 gpurun_out/${tag}_bench_line_$f.json; echo; done
 tail -4 gpurun_out/${tag}_repro_check.txt
