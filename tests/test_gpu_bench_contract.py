@@ -1,0 +1,40 @@
+"""The driver-facing contract of bench.py: ONE JSON line on stdout, with the fields the round instructions name - run here on a
+small batch (the default run is the BASELINE configuration at B = 128) through the same code path: child-process hipGraph
+capture, reference-loop timing (H2D + sync per iteration), GEMM replay for `roofline`, the bounded CPU baseline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "16",
+                         "--no-modes", "--cpu-iters", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200,
+                        cwd=ROOT)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    lines = [ln for ln in cp.stdout.splitlines() if ln.strip()]
+    assert lines and lines[-1].startswith("{"), cp.stdout[-500:]
+    assert sum(1 for ln in lines if ln.startswith("{") and '"metric"' in ln) == 1
+    j = json.loads(lines[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["higher_is_better"] is True
+    assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "bf16" and j["data"] == "synthetic"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert j["value"] > 0 and abs(j["value"] - 16 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 0.02      # value = B / s per step
+    r = j["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None                 # (the PMC figure belongs to the B = 128 configuration only)
+    c = j["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
