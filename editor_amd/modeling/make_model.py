@@ -289,8 +289,8 @@ class EDITOR(nn.Module):
         # the 32-wide HMA heads of DeiT-small - factory entries no shipped config uses) keep their 16-bit GEMMs and run the
         # attention product itself on the exact-f32 kernels between two casts (ops.attention_fwd): the probabilities are then
         # materialised for the rollout as in the f32 mode, and the HMA head takes its dense-masked form
-        self.bb_wide = self.act_dtype != torch.float32 and dim // base.heads != 64
-        self.hma_wide = self.act_dtype != torch.float32 and dim // self.hma_heads != 64
+        self.bb_attn_f32 = self.act_dtype != torch.float32 and dim // base.heads != 64
+        self.hma_attn_f32 = self.act_dtype != torch.float32 and dim // self.hma_heads != 64
         # per-model options of the autograd nodes (installed at the top of every forward, captured by the nodes' ctx)
         self.grad_scale_f16 = float(cfg.MODEL.GRAD_SCALE) if hasattr(cfg.MODEL, "GRAD_SCALE") else None
         self.act_light = bool(getattr(cfg.MODEL, "ACT_LIGHT", False))   # 24 instead of 36 saved bytes per token-row-element
@@ -363,8 +363,8 @@ class EDITOR(nn.Module):
         # block hands back its (qkv, row log-sum-exp) instead and the rollout recomputes the probabilities from them
         # (cfg.MODEL.ROLLOUT_PROBS = True keeps the materialised form: rows padded to a multiple of 4 floats).
         # (split-precision mode: the fp32 probabilities of the split attention kernel are materialised, as in f32 mode)
-        recompute = self.act_dtype != torch.float32 and not self.rollout_probs and not self.split_fwd and not self.bb_wide
-        ldp = t if (self.act_dtype == torch.float32 or self.bb_wide) else (t + 3) // 4 * 4
+        recompute = self.act_dtype != torch.float32 and not self.rollout_probs and not self.split_fwd and not self.bb_attn_f32
+        ldp = t if (self.act_dtype == torch.float32 or self.bb_attn_f32) else (t + 3) // 4 * 4
         probs = [] if recompute else torch.empty(base.depth, btot, base.heads, t, ldp, dtype=torch.float32,
                                                  device=dev)
         scales = None
@@ -502,7 +502,7 @@ class EDITOR(nn.Module):
             else:
                 mod_scores = [fn.LinearFn.apply(self._bn(self.BACKBONE_BN, c), self.BACKBONE_HEAD.weight, None)
                               for c in cls_tri]
-        if self.hma_compact and self.act_dtype != torch.float32 and b * t >= 256 and not self.hma_wide:
+        if self.hma_compact and self.act_dtype != torch.float32 and b * t >= 256 and not self.hma_attn_f32:
             pooled, num, loss_ocfr = self._hma_compact(feats_s, index, label)
         else:                      # dense-masked form, as the reference computes it (always used in f32 parity mode)
             fused, loss_ocfr = self._hma(feats_s, index, label)
