@@ -394,6 +394,64 @@ def cpu_baseline(model, cfg, cams, batch, iters):
     return res
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves, one process per GPU, exactly as the
+    reference is started (train_net.py:45-46,63-64: torch.distributed.launch + NCCL) - re-exec this file under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>`, pass the
+    ranks' stderr through, relay rank 0's JSON line as the LAST line of stdout and return the launcher's exit code.
+    N = 1 (`--spawn` / EDITOR_BENCH_SPAWN=1) goes the same way with a real 1-rank RCCL group, so the launcher is exercised on every
+    single-GPU box (tests/test_gpu_bench_contract.py)."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write(f"[bench] --gpus {n} asked for, but this node shows {have} GPU(s) (torch.cuda.device_count()); not starting\n")
+        return 2
+    env = dict(os.environ)
+    env["EDITOR_BENCH_RANK_CHILD"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, _usable_cores() // max(n, 1))))
+    if n == 1:
+        env["EDITOR_FORCE_DDP"] = "1"
+    child_argv = [a for a in argv if a != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + child_argv
+    sys.stderr.write("[bench] launching " + " ".join(cmd[1:]) + "\n")
+    sys.stderr.flush()
+    timeout = float(os.environ.get("EDITOR_BENCH_LAUNCH_TIMEOUT", "3000"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGKILL)                # the launcher AND its ranks (own session), nothing else
+        stdout, _ = proc.communicate()
+        sys.stderr.write(f"[bench] the {n}-rank run did not finish within {timeout:.0f} s; killed\n")
+        sys.stdout.write(stdout)
+        return 124
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    other = [ln for ln in stdout.splitlines() if not (ln.startswith("{") and '"metric"' in ln)]
+    if other:
+        sys.stderr.write("\n".join(other[-40:]) + "\n")  # RCCL banners etc.: not on stdout, the JSON line is the only line there
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(f"[bench] the {n}-rank run failed (rc={proc.returncode}, {len(lines)} JSON line(s))\n")
+        return proc.returncode or 1
+    try:
+        j = json.loads(lines[-1])
+        assert j["n_gpus"] == n and j.get("rccl_ranks") == n, (j.get("n_gpus"), j.get("rccl_ranks"))
+    except Exception as e:
+        sys.stderr.write(f"[bench] rank 0's line does not describe an {n}-rank run ({type(e).__name__}: {e})\n")
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -412,9 +470,17 @@ def main():
     ap.add_argument("--act-light", action="store_true", help="activation-light blocks (cfg.MODEL.ACT_LIGHT): 24 B instead of 36 B "
                     "saved per token-row-element (config 5 at B = 64 per GPU)")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-mode block (speed + accuracy of bf16 / f16 / f16x2 / f32)")
+    ap.add_argument("--spawn", action="store_true", help="go through the rank launcher even for --gpus 1 (a real 1-rank RCCL group; "
+                    "also EDITOR_BENCH_SPAWN=1)")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 32 if args.preset == "SYNTH4L" else 128
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn or os.environ.get("EDITOR_BENCH_SPAWN") == "1"):
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -440,8 +506,8 @@ def main():
         except Exception as e:                                            # timeout, unparsable output ...
             sys.stderr.write(f"[bench] hipGraph child failed ({type(e).__name__}); timing the eager step\n")
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or force_ddp
@@ -623,6 +689,8 @@ def main():
                 torch.cuda.synchronize()                  # engine/processor.py:107
                 if iter_times is not None:
                     iter_times.append(time.perf_counter())
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0                    # this rank's K steps, before it waits for the others
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -632,8 +700,12 @@ def main():
         el_ = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(el_, op=dist.ReduceOp.MAX)
+            owns = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(owns, torch.tensor([own], dtype=torch.float64, device=dev))
+            rank_ms[:] = [round(1e3 * float(o.item()) / args.steps, 3) for o in owns]
         return float(el_.item()), loss_
 
+    rank_ms = []
     elapsed, loss = timed_loop(feed)
     replay_only = None
     if feed and world == 1 and not force_ddp:            # the bare step beside it (inputs resident, no per-iteration sync)
@@ -712,6 +784,13 @@ def main():
                        "grad_buckets": None if buckets is None else buckets.describe()},
             "roofline": roof,
         }
+        if use_dist:
+            # what the driver needs to see that RCCL really ran N ranks: the group's size as torch.distributed reports it after
+            # init, and every rank's own time for its K steps (before the closing barrier; `ms_per_step` is the max incl. it)
+            out["rccl_ranks"] = dist.get_world_size()
+            out["rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms}
+            out["not_in_this_line"] = ("modes, cpu_baseline, replay_only and torch_gpu_yardstick are single-process blocks of the "
+                                       "N = 1 line (python bench.py --gpus 1)")
         if replay_only is not None:
             out["replay_only"] = replay_only
         if world == 1 and not args.no_modes and not force_ddp and args.preset in ("RGBNT201", "RGBNT100", "MSVR310"):

@@ -40,14 +40,15 @@ bool build_huff(HuffTab& t, const uint8_t* bits /* [1..16] */, const uint8_t* va
     for (int l = 1; l <= 16; ++l) {
         t.valoff[l] = k - code;
         for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
-            if (k >= nvals) return false;
+            // (checked BEFORE anything is written: a table with more codes of a length than that length can hold - the
+            //  Kraft sum libjpeg's jpeg_make_d_derived_tbl rejects - would index past look[512])
+            if (k >= nvals || code >= (1 << l)) return false;
             if (l <= 9) {
                 const int first = code << (9 - l);
                 for (int f = 0; f < (1 << (9 - l)); ++f) t.look[first + f] = (uint16_t)((l << 8) | vals[k]);
             }
         }
         t.maxcode[l] = bits[l] ? code - 1 : -1;
-        if (code > (1 << l)) return false;
         code <<= 1;
     }
     t.maxcode[17] = 0x7fffffff;
@@ -107,12 +108,14 @@ struct Jpeg {
     bool progressive = false, unsupported = false, have_sof = false;
     int adobe_transform = -1; bool jfif = false;
     long total_blocks = 0;
+    bool covered[3] = {false, false, false};      // components some scan has delivered
 };
 
 inline int rd16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 
-// Parses the markers up to (and including the header of) each SOS.  `coef` NULL: headers only.
-int decode(const uint8_t* d, long n, Jpeg& j, int16_t* coef)
+// Parses the markers up to (and including the header of) each SOS.  `coef` NULL: headers only; otherwise `coef` holds
+// `coef_blocks` blocks of 64 coefficients and every scan is checked against that size before it writes.
+int decode(const uint8_t* d, long n, Jpeg& j, int16_t* coef, long coef_blocks)
 {
     if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return EDITOR_JPEG_CORRUPT;
     long pos = 2;
@@ -154,6 +157,7 @@ int decode(const uint8_t* d, long n, Jpeg& j, int16_t* coef)
             }
         } else if (m == 0xC0 || m == 0xC1 || m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
             if (m != 0xC0 && m != 0xC1) { j.unsupported = true; return EDITOR_JPEG_UNSUPPORTED; }   // progressive / lossless / arithmetic
+            if (j.have_sof) return EDITOR_JPEG_CORRUPT;                   // one frame per file (a second SOF would re-size the block grid under the scans)
             if (sl < 6 || s[0] != 8) { j.unsupported = true; return EDITOR_JPEG_UNSUPPORTED; }
             j.H = rd16(s + 1); j.W = rd16(s + 3); j.ncomp = s[5];
             if ((j.ncomp != 1 && j.ncomp != 3) || j.W <= 0 || j.H <= 0 || sl < 6 + 3 * j.ncomp) return EDITOR_JPEG_UNSUPPORTED;
@@ -204,9 +208,13 @@ int decode(const uint8_t* d, long n, Jpeg& j, int16_t* coef)
                 while (pos + 1 < n && !(d[pos] == 0xFF && d[pos + 1] != 0x00 && !(d[pos + 1] >= 0xD0 && d[pos + 1] <= 0xD7))) ++pos;
                 continue;
             }
-            for (int i = 0; i < ns; ++i)
+            if (j.total_blocks > coef_blocks) return EDITOR_JPEG_CORRUPT;  // (the frame this scan belongs to must fit the caller's buffer)
+            for (int i = 0; i < ns; ++i) {
                 if (!j.dc[j.comp[idx[i]].td].present || !j.ac[j.comp[idx[i]].ta].present || !j.qt_ok[j.comp[idx[i]].tq])
                     return EDITOR_JPEG_CORRUPT;
+                if (j.covered[idx[i]]) return EDITOR_JPEG_CORRUPT;          // sequential coding: one scan per component
+                j.covered[idx[i]] = true;
+            }
             BitReader br{d + pos, d + n};
             int pred[3] = {0, 0, 0};
             // MCU geometry of this scan: interleaved -> hs x vs blocks per component per MCU over mcux x mcuy MCUs;
@@ -269,6 +277,9 @@ int decode(const uint8_t* d, long n, Jpeg& j, int16_t* coef)
         pos += 2 + len;
     }
     if (!j.have_sof || !seen_scan) return EDITOR_JPEG_CORRUPT;
+    if (coef)                                                             // every component delivered by some scan, or the planes
+        for (int c = 0; c < j.ncomp; ++c)                                 // of the missing ones would be whatever the buffer held
+            if (!j.covered[c]) return EDITOR_JPEG_CORRUPT;
     return 0;
 }
 
@@ -461,7 +472,7 @@ extern "C" int editor_jpeg_parse(const uint8_t* data, long n, int* info)
 {
     if (!data || !info) return EDITOR_JPEG_CORRUPT;
     Jpeg j;
-    const int rc = decode(data, n, j, nullptr);
+    const int rc = decode(data, n, j, nullptr, 0);
     if (rc) return rc;
     fill_info(j, info);
     return 0;
@@ -471,11 +482,13 @@ extern "C" int editor_jpeg_entropy_decode(const uint8_t* data, long n, int16_t* 
 {
     if (!data || !coef || !qt || !info) return EDITOR_JPEG_CORRUPT;
     Jpeg j;
-    int rc = decode(data, n, j, nullptr);                     // geometry first: the caller's buffer must hold it
+    int rc = decode(data, n, j, nullptr, 0);                  // geometry first: the caller's buffer must hold it
     if (rc) return rc;
     if (j.total_blocks > coef_blocks) return EDITOR_JPEG_CORRUPT;
+    // blocks no scan covers (the MCU padding of a per-component scan) are zero, never what the caller's buffer held
+    memset(coef, 0, (size_t)j.total_blocks * 128);
     Jpeg k;
-    rc = decode(data, n, k, coef);
+    rc = decode(data, n, k, coef, coef_blocks);
     if (rc) return rc;
     fill_info(k, info);
     for (int c = 0; c < 3; ++c)

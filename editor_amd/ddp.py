@@ -241,6 +241,7 @@ class GradBuckets:
                     off += p.numel()
                     p.grad = v                       # the parameter's gradient IS the bucket slot, permanently
                     p._grad_sink = v                 # (FusedSGD.zero_grad restores it instead of dropping it)
+                    p._grad_owner = self             # (... and tells these buckets that a new step begins)
                     views.append(v)
                 self.sinks[si] = BlockSink(self, si, views, list(segments[si][1]))
                 self.seg_bucket[si] = bi
@@ -251,6 +252,20 @@ class GradBuckets:
 
     def sink(self, seg_index):
         return self.sinks[seg_index]
+
+    def reset_step(self):
+        """A new step begins: forget which segments the previous backward wrote.  finish() does this; FusedSGD.zero_grad()
+        does it too, so that a backward that raised half-way (out of memory, a NaN assert) or a loop that uses the in-place
+        slots with a plain optimizer and never calls finish() does not poison every later step with the 'written twice'
+        error.  Collectives already in flight are waited for and dropped."""
+        self._written.clear()
+        for b in self.buckets:
+            b["pending"] = len(b["segs"])
+        for b in self._inflight:
+            if b["work"] is not None:
+                b["work"].wait()
+                b["work"] = None
+        self._inflight = []
 
     def segment_done(self, si):
         # The slots are OVERWRITTEN by a backward, not accumulated into: a second backward before finish() / the optimizer
@@ -318,6 +333,12 @@ class GradBuckets:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             self._tail = (flat, views, live, key)
+        if capturing and self._tail[3] != key:
+            # the captured graph would copy from the EAGER step's tail set: parameters that have since gained / lost a gradient
+            # would be exchanged from stale or missing tensors
+            raise RuntimeError("GradBuckets.finish(): the set of small parameters that carry a gradient differs from the one the "
+                               "last eager step built the tail bucket for; run one eager step with the final configuration "
+                               "before capturing")
         flat, views, live, _ = self._tail
         if live:
             torch._foreach_copy_(views, [p.grad for p in live])

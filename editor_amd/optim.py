@@ -111,10 +111,15 @@ class FusedSGD:
 
     # -- torch.optim.Optimizer surface --------------------------------------------------------------------
     def zero_grad(self, set_to_none=True):
+        owners = []
         for _, p in self.params:
             sink = getattr(p, "_grad_sink", None)
             if sink is not None:
                 p.grad = sink                    # gradient lives in an all-reduce bucket slot that the backward overwrites
+                owner = getattr(p, "_grad_owner", None)
+                if owner is not None and all(owner is not o for o in owners):
+                    owners.append(owner)
+                    owner.reset_step()           # a new step: a backward that raised half-way must not poison this one
             elif set_to_none or p.grad is None:
                 p.grad = None
             else:
@@ -142,9 +147,15 @@ class FusedSGD:
 
     def found_inf(self, reset=True):
         """True if any step since the last reset saw an inf / nan gradient (synchronises: call it every N steps, as the
-        reference's GradScaler bookkeeping does once per step, engine/processor.py:95-96).  Such a step was SKIPPED on the
-        device (check_overflow): nothing was written.  With the static in-backward scale (cfg.MODEL.GRAD_SCALE) halve it
-        on a hit; a DeviceGradScaler backs its own scale off without the host."""
+        reference's GradScaler bookkeeping does once per step, engine/processor.py:95-96).
+
+        Whether the offending step was APPLIED depends on the mode: with `check_overflow` on (the f16 / f16x2 default, and
+        whenever a DeviceGradScaler drives the step) the gradients are checked before the update and the update kernel wrote
+        nothing - parameters, momentum and 16-bit shadows are those of the previous step.  With `check_overflow` off (bf16 / f32
+        default) the flag is raised by the update kernel ITSELF while it applies the inf / nan gradient: the weights are
+        poisoned and the caller must restore a checkpoint (or construct the optimizer with check_overflow=True).
+        `self.check_overflow` says which.  With the static in-backward scale (cfg.MODEL.GRAD_SCALE) halve it on a hit; a
+        DeviceGradScaler backs its own scale off without the host."""
         bad = bool(self._nonfinite.item())
         if reset:
             self._nonfinite.zero_()

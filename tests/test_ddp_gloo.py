@@ -220,6 +220,20 @@ def _worker_contract(rank, world, port, ret):
     tail_b.grad = torch.full((7,), float(2 * rank))
     gb.finish()
     ok &= bool((tail_b.grad == 1.0).all()) and bool((tail_a.grad == 0.5).all())
+    # step 3: a backward that raised half-way (slots written, finish() never reached) must not poison the next step:
+    # FusedSGD.zero_grad() -> reset_step()
+    for j, v in enumerate(sink.views):
+        v.fill_(7.0)
+    sink.done()                                              # ... and then the step dies before finish()
+    ok &= all(getattr(p, "_grad_owner", None) is gb for p in blk)
+    gb.reset_step()                                          # what FusedSGD.zero_grad() calls through p._grad_owner
+    for j, v in enumerate(sink.views):
+        v.fill_(float(rank))
+    sink.done()                                              # accepted again
+    tail_a.grad = torch.full((5,), float(rank))
+    tail_b.grad = torch.full((7,), float(2 * rank))
+    gb.finish()
+    ok &= bool((blk[0].grad == 0.5).all()) and bool((tail_b.grad == 1.0).all())
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 

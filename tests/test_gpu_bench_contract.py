@@ -38,3 +38,33 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` must work unaided (VERDICT r3 missing #1): N > 1 re-execs through torch.distributed.run; the
+    same launcher is exercised here with one rank (`--spawn`): a real 1-rank RCCL group, bucket all-reduces issued from inside
+    the backward, rank 0's JSON line relayed as the only line of stdout."""
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--steps", "3", "--warmup", "1",
+                         "--batch", "16"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200, cwd=ROOT)
+    assert cp.returncode == 0, cp.stderr[-3000:]
+    lines = [ln for ln in cp.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), cp.stdout[-800:]
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "rccl_ranks", "rank_ms_per_step"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1 and j["config"]["parallelism"] == "dp1" and j["config"]["global_batch"] == 16
+    assert "RCCL" in j["config"]["launch"]
+    import math
+    assert math.isfinite(j["config"]["loss"]) and j["config"]["loss"] > 0
+    assert j["value"] > 0 and abs(j["value"] - 16 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 0.02
+    assert len(j["rank_ms_per_step"]["all"]) == 1 and j["rank_ms_per_step"]["max"] <= j["ms_per_step"] * 1.001
+    assert j["config"]["grad_buckets"]
+
+
+def test_bench_refuses_more_ranks_than_gpus_loudly():
+    import torch
+    n = torch.cuda.device_count() + 1
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT)
+    assert cp.returncode != 0 and "GPU(s)" in cp.stderr and not cp.stdout.strip()

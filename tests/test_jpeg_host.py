@@ -61,3 +61,125 @@ def test_matches_live_pillow_when_available(golden):
     for name in ("stitched_420_q75", "odd_422_q95", "gray_q80"):
         live = np.asarray(PIL.open(io.BytesIO(golden[name + ".jpg"].tobytes())).convert("RGB"))
         assert np.array_equal(live, golden[name + ".rgb"])
+
+
+# ---- malformed files (ADVICE r3): the parser sees dataset bytes directly; every one of these must come back as an error code ----
+def _segments(data):
+    """[(marker, start, end)] of the marker segments before the first SOS (end exclusive, start at the 0xFF)."""
+    d = bytes(data)
+    pos, out = 2, []
+    while pos + 4 <= len(d):
+        assert d[pos] == 0xFF
+        m = d[pos + 1]
+        ln = (d[pos + 2] << 8) | d[pos + 3]
+        out.append((m, pos, pos + 2 + ln))
+        if m == 0xDA:
+            break
+        pos += 2 + ln
+    return out
+
+
+def _u8(b):
+    return np.frombuffer(bytes(b), dtype=np.uint8)
+
+
+def test_dht_with_too_many_short_codes_is_refused_not_written():
+    # 280-byte file of the advisor's report: SOI + DHT whose bits[1] = 255 (a length-1 code space holds two codes)
+    for bits1 in (3, 255):
+        cnt = bits1
+        body = bytes([0x00, bits1] + [0] * 15) + bytes([i & 0xFF for i in range(cnt)])
+        seg = bytes([0xFF, 0xC4]) + (len(body) + 2).to_bytes(2, "big") + body
+        rc, _, _, _ = host_decode(_u8(b"\xFF\xD8" + seg + b"\xFF\xD9"))
+        assert rc == 9001, (bits1, rc)
+    # over-subscribed at a longer length: 2 codes of length 1 (full) + 1 of length 2
+    body = bytes([0x10, 2, 1] + [0] * 14) + bytes([1, 2, 3])
+    seg = bytes([0xFF, 0xC4]) + (len(body) + 2).to_bytes(2, "big") + body
+    rc, _, _, _ = host_decode(_u8(b"\xFF\xD8" + seg + b"\xFF\xD9"))
+    assert rc == 9001
+    # length-9/10 boundary of the lookahead table: 2^9 codes would need 512 values; > 256 values is refused by the count check
+    body = bytes([0x00] + [0] * 8 + [255] + [0] * 7) + bytes(255)
+    seg = bytes([0xFF, 0xC4]) + (len(body) + 2).to_bytes(2, "big") + body
+    rc, _, _, _ = host_decode(_u8(b"\xFF\xD8" + seg + b"\xFF\xD9"))
+    assert rc == 9001                                            # no SOF / scan follows: still an error, and no crash
+
+
+def test_second_frame_header_is_refused(golden):
+    """A large SOF + its scan followed by a small SOF before EOI must not size the buffer from the small one."""
+    big = bytes(golden["stitched_420_q75.jpg"])
+    small = bytes(golden["tiny_420_q50.jpg"])
+    sof_small = [s for s in _segments(small) if s[0] == 0xC0][0]
+    assert big[-2:] == b"\xFF\xD9"
+    crafted = big[:-2] + small[sof_small[1]:sof_small[2]] + b"\xFF\xD9"
+    rc, _, _, _ = host_decode(_u8(crafted))
+    assert rc == 9001
+    # and directly against the entropy decoder with a buffer sized for the SMALL frame (what a headers-only pass would say)
+    from editor_amd import _lib
+    cd = _lib.lib().cdll
+    info = np.zeros(16, dtype=np.int32)
+    sbuf = _u8(small)
+    assert cd.editor_jpeg_parse(ctypes.c_void_p(sbuf.ctypes.data), sbuf.size, ctypes.c_void_p(info.ctypes.data)) == 0
+    nsmall = int(info[8])
+    guard = np.full((nsmall + 64, 64), 0x5A5A, dtype=np.int16)
+    qt = np.zeros((3, 64), dtype=np.uint16)
+    bbuf = _u8(big)
+    rc = cd.editor_jpeg_entropy_decode(ctypes.c_void_p(bbuf.ctypes.data), bbuf.size, ctypes.c_void_p(guard.ctypes.data),
+                                       ctypes.c_long(nsmall), ctypes.c_void_p(qt.ctypes.data), ctypes.c_void_p(info.ctypes.data))
+    assert rc == 9001 and (guard[nsmall:] == 0x5A5A).all()       # nothing written past what the caller offered
+
+
+def test_truncations_and_oversized_counts_never_crash(golden):
+    data = bytes(golden["odd_422_q95.jpg"])
+    segs = _segments(data)
+    sos_end = segs[-1][2]
+    for cut in list(range(2, sos_end + 40, 7)) + [len(data) - 1, len(data) - 2]:
+        rc, _, _, _ = host_decode(_u8(data[:cut]))
+        assert rc in (0, 9001), (cut, rc)
+    # a segment length that runs past the end of the file
+    for m, a, b in segs:
+        bad = bytearray(data)
+        bad[a + 2], bad[a + 3] = 0xFF, 0xFF
+        rc, _, _, _ = host_decode(_u8(bad))
+        assert rc in (9001, 9002), (hex(m), rc)
+    # SOS naming more components than the frame has / an unknown component id / table ids out of range
+    m, a, b = segs[-1]
+    for off, val in ((4, 4), (5, 99), (6, 0x44)):
+        bad = bytearray(data)
+        bad[a + off] = val
+        rc, _, _, _ = host_decode(_u8(bad))
+        assert rc == 9001, (off, rc)
+    # DQT with a table id > 3, SOF with zero sampling factors
+    dqt = [s for s in segs if s[0] == 0xDB][0]
+    bad = bytearray(data); bad[dqt[1] + 4] = 0x07
+    assert host_decode(_u8(bad))[0] == 9001
+    sof = [s for s in segs if s[0] == 0xC0][0]
+    bad = bytearray(data); bad[sof[1] + 11] = 0x00
+    assert host_decode(_u8(bad))[0] == 9001
+
+
+def test_file_whose_scans_miss_a_component_is_refused():
+    """Per-component scans truncated after Y: Cb / Cr would be reconstructed from whatever the buffer held."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    rng = np.random.default_rng(5)
+    img = PIL.fromarray(rng.integers(0, 256, (32, 48, 3), dtype=np.uint8))
+    buf = io.BytesIO()
+    img.save(buf, "JPEG", quality=80, subsampling=0)
+    data = buf.getvalue()
+    segs = _segments(data)
+    m, a, b = segs[-1]
+    assert data[a + 4] == 3                                      # interleaved 3-component scan as Pillow writes it
+    # rewrite the scan header to claim ONE component (Y): the entropy data then decodes as a Y-only scan (garbage, but legal
+    # Huffman), and Cb / Cr never arrive
+    hdr = bytes([0xFF, 0xDA, 0x00, 0x08, 0x01, data[a + 5], data[a + 6], 0x00, 0x3F, 0x00])
+    crafted = data[:a] + hdr + data[b:]
+    rc, _, _, _ = host_decode(_u8(crafted))
+    assert rc == 9001
+
+
+def test_jpeg_entry_points_have_declared_argument_types():
+    from editor_amd import _lib
+    cd = _lib.lib().cdll
+    for name in ("editor_jpeg_parse", "editor_jpeg_entropy_decode", "editor_jpeg_planes_bytes"):
+        fn = getattr(cd, name)
+        assert fn.argtypes is not None and fn.restype is ctypes.c_int, name
+    assert cd.editor_jpeg_parse.argtypes[1] is ctypes.c_long     # `long n`: never passed as a C int
