@@ -20,10 +20,12 @@ One JSON line on rank 0.
   roofline      the dominant kernel family (16-bit MFMA GEMM): algorithmic FLOPs of every launch of one step / their
                 HIP-event durations (replayed back to back after the timed region), against the 2.5 PFLOP/s dense peak;
                 `traffic` = HBM bytes per step of those launches from the committed PMC profile of the same command
-                (profiles/r03_pmc_traffic.json, tools/pmc_traffic.sh), null when absent; `step_frac` = SURVEY.md 8(d)'s
+                (the newest profiles/rNN_pmc_traffic.json, tools/pmc_traffic.sh; `traffic_source` names it - PMC counters need their
+                own rocprofv3 passes and are not collected by this run), null when absent; `step_frac` = SURVEY.md 8(d)'s
                 algorithmic FLOPs of the WHOLE step / ms_per_step / peak;
                 `hbm_kernels` = the memory-bound select / gather / normalisation kernels timed live with HIP events
                 against the 8 TB/s HBM peak (algorithmic bytes).
+  eval          forward-only throughput of model.eval() at the same batch (do_inference, engine/processor.py:217-270)
   modes         every compute mode beside the benchmarked one - bf16, f16, f16x2 (split-precision forward), f32 (exact-f32
                 parity mode): images/sec of the same timed loop (child process each) AND its accuracy against the oracle
                 (cls4t relative error, token-selection agreement), so the speed is never read without the parity it buys.
@@ -142,21 +144,44 @@ class _GemmProbe:
         return by_kind
 
 
-def _event_us(fn, reps=20, warm=3):
-    for _ in range(warm):
-        fn()
+def _event_us(fn, nsets=1, reps=24, warm=None):
+    """Average HIP-event duration of fn(i), i cycling over `nsets` operand sets (the caller sizes the sets so that their
+    footprint exceeds 512 MB: the 256 MB Infinity Cache cannot serve a set that was last touched nsets - 1 launches ago)."""
+    for i in range(warm if warm is not None else nsets):
+        fn(i % nsets)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    for i in range(reps):
+        fn(i % nsets)
     e1.record()
     torch.cuda.synchronize()
     return 1e3 * e0.elapsed_time(e1) / reps
 
 
+def _in_situ_us():
+    """{kernel-name prefix: average us} from the newest committed rocprofv3 --kernel-trace --stats summary of the bench command
+    with the side stream off (profiles/rNN_bench_kernel_stats_serial.csv): the durations the kernels have INSIDE the step, on
+    operands the previous kernels pushed out of the caches."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_kernel_stats_serial.csv")))
+    if not files:
+        return None, {}
+    out = {}
+    try:
+        for r in csv.DictReader(open(files[-1])):
+            out[r["Name"].replace("void ", "").replace("(anonymous namespace)::", "")] = float(r["AverageNs"]) / 1e3
+    except Exception:
+        return None, {}
+    return os.path.relpath(files[-1], ROOT), out
+
+
 def hbm_kernels(model, img, b, act_dtype):
     """The memory-bound kernels of the path (north_star: "achieved HBM GB/s for the memory-bound select/gather"), each
-    timed live on this GPU with HIP events on its real operand shapes; algorithmic bytes per launch from SURVEY.md 8(d)."""
+    timed live on this GPU with HIP events on its real operand shapes; algorithmic bytes per launch from SURVEY.md 8(d).
+    Every kernel rotates over `sets` independent operand sets whose footprint exceeds 512 MB, so the figure is HBM, not the
+    256 MB Infinity Cache (round 3 repeated one set: freq_counts read 0.47 there and 0.29 inside the step).  `in_situ_us` is
+    the same kernel's average duration in the committed rocprofv3 profile of the whole step."""
     from editor_amd import ops
     dev = img[next(iter(img))].device
     base = model.BACKBONE.base
@@ -165,37 +190,58 @@ def hbm_kernels(model, img, b, act_dtype):
     m = nmod * b * t
     mods = [v for v in img.values()]
     out = []
+    src, situ = _in_situ_us()
 
-    def add(name, alg_bytes, fn):
-        us = _event_us(fn)
+    def nsets_for(footprint):
+        return max(3, int(600e6 // max(footprint, 1)) + 1)
+
+    def add(name, alg_bytes, fn, nsets, match):
+        us = _event_us(fn, nsets)
         gbs = alg_bytes / us / 1e3
-        out.append({"kernel": name, "alg_bytes": int(alg_bytes), "us": round(us, 1), "GB/s": round(gbs, 0),
-                    "frac": round(gbs / PEAK_HBM_GBS, 3)})
+        ent = {"kernel": name, "alg_bytes": int(alg_bytes), "us": round(us, 1), "GB/s": round(gbs, 0),
+               "frac": round(gbs / PEAK_HBM_GBS, 3), "sets": nsets}
+        hit = [v for k, v in situ.items() if all(tok in k for tok in match)]
+        if hit:
+            ent["in_situ_us"] = round(max(hit), 1)
+            ent["in_situ_frac"] = round(alg_bytes / max(hit) / 1e3 / PEAK_HBM_GBS, 3)
+        out.append(ent)
 
     px = mods[0].numel() * 4
+    n = nsets_for(nmod * px)
+    imgs = [[v.clone() for v in mods] for _ in range(n)]
     add("freq_counts_kernel (Haar DWT -> mean -> IDWT -> positive count)", nmod * px,
-        lambda: ops.freq_counts(mods[0], mods[1], mods[2], mods[3] if nmod > 3 else None))
-    feat = torch.randn(nmod, b, t, d, device=dev)
+        lambda i: ops.freq_counts(imgs[i][0], imgs[i][1], imgs[i][2], imgs[i][3] if nmod > 3 else None), n, ("freq_counts_kernel",))
+    del imgs
+    n = nsets_for(2 * nmod * b * t * d * 4)
+    feats = [torch.randn(nmod, b, t, d, device=dev) for _ in range(n)]
     index = (torch.rand(b, t - 1, device=dev) > 0.5).to(torch.uint8)
-    add("sfts_apply_kernel (mask apply + BCC partial sums)", 2 * feat.numel() * 4, lambda: ops.sfts_apply(feat, index, True))
-    x = torch.randn(m, d, device=dev)
+    add("sfts_apply_kernel (mask apply + BCC partial sums)", 2 * feats[0].numel() * 4, lambda i: ops.sfts_apply(feats[i], index, True),
+        n, ("sfts_apply_kernel",))
+    del feats
     g = torch.ones(d, device=dev)
     bb = torch.zeros(d, device=dev)
     if act_dtype != torch.float32:
-        qkv = (torch.randn(m, 3 * d, device=dev) * 0.5).to(act_dtype)
-        _, lse = ops.attention_fwd(qkv, nmod * b, t, heads, d // heads)
+        n = nsets_for(m * 3 * d * 2)
+        qkvs = [(torch.randn(m, 3 * d, device=dev) * 0.5).to(act_dtype) for _ in range(n)]
+        lses = [ops.attention_fwd(q, nmod * b, t, heads, d // heads)[1] for q in qkvs]
         add("attn_rollout_step_kernel (one layer: q,k + lse in, r out)", m * 2 * d * 2 + 2 * heads * m * 4,
-            lambda: ops.attn_rollout_qk([(qkv, lse)], nmod * b, t, heads, d // heads))
+            lambda i: ops.attn_rollout_qk([(qkvs[i], lses[i])], nmod * b, t, heads, d // heads), n, ("attn_rollout_step_kernel",))
         add("attn_q_pass_kernel fwd (qkv in, o out)", m * 4 * d * 2,
-            lambda: ops.attention_fwd(qkv, nmod * b, t, heads, d // heads))
-        del qkv, lse
+            lambda i: ops.attention_fwd(qkvs[i], nmod * b, t, heads, d // heads), n, ("attn_q_pass_kernel", "false, true, false, false"))
+        del qkvs, lses
     esz = 4 if act_dtype == torch.float32 else 2
-    y, mean, rstd = ops.layernorm_fwd(x, g, bb, 1e-6, act_dtype)
-    add("layernorm_fwd_kernel", m * d * (4 + esz), lambda: ops.layernorm_fwd(x, g, bb, 1e-6, act_dtype))
-    dx_in = torch.randn(m, d, device=dev)
+    n = nsets_for(m * d * (4 + esz))
+    xs = [torch.randn(m, d, device=dev) for _ in range(n)]
+    add("layernorm_fwd_kernel", m * d * (4 + esz), lambda i: ops.layernorm_fwd(xs[i], g, bb, 1e-6, act_dtype), n,
+        ("layernorm_fwd_kernel", "unsigned short" if esz == 2 else "float"))
+    n = 3
+    xs = xs[:n]
+    ys, means, rstds = zip(*[ops.layernorm_fwd(x, g, bb, 1e-6, act_dtype) for x in xs])
+    dxs = [torch.randn(m, d, device=dev) for _ in range(n)]
     add("layernorm_bwd_kernel (+ residual-gradient add)", m * d * (esz + 4 + 4 + 4),
-        lambda: ops.layernorm_bwd(y, x, g, mean, rstd, dx_in=dx_in))
-    return out
+        lambda i: ops.layernorm_bwd(ys[i], xs[i], g, means[i], rstds[i], dx_in=dxs[i]), n,
+        ("layernorm_bwd_kernel", "unsigned short, 3, false" if esz == 2 else "float"))
+    return out, src
 
 
 def mode_accuracy(preset, dtypes, batch=16, seed=31):
@@ -241,7 +287,7 @@ def mode_accuracy(preset, dtypes, batch=16, seed=31):
     return res, batch
 
 
-def modes_block(args, cfg, cams, own_value):
+def modes_block(args, cfg, cams, own_value, own_eval=None):
     """{mode: img/s (the same timed loop, in a child process per mode) + accuracy vs the oracle}."""
     import subprocess
     modes = ["bf16", "f16", "f16x2", "f32"]
@@ -252,6 +298,8 @@ def modes_block(args, cfg, cams, own_value):
         entry = dict(acc[dt])
         if dt == args.dtype:
             entry["value"] = own_value
+            if own_eval is not None:
+                entry["eval"] = own_eval.get("value")
         else:
             steps, warm = (3, 1) if dt == "f32" else (args.steps, args.warmup)
             cmd = [sys.executable, os.path.abspath(__file__), "--dtype", dt, "--preset", args.preset, "--batch", str(args.batch),
@@ -264,6 +312,8 @@ def modes_block(args, cfg, cams, own_value):
                 j = json.loads(lines[-1])
                 entry["value"] = j["value"]
                 entry["ms_per_step"] = j["ms_per_step"]
+                if "eval" in j:
+                    entry["eval"] = j["eval"].get("value")
             except Exception as e:                       # a mode that fails to run is reported, not hidden
                 entry["value"] = None
                 entry["error"] = type(e).__name__
@@ -306,6 +356,54 @@ def shader_clock_mhz(work, busy_ms=60.0, n=3000, sleep=6):
     w = 25
     win = [(cyc[j + w] - cyc[j]) / (ref[j + w] - ref[j]) for j in range(i0, i1 - w, w) if ref[j + w] > ref[j]]
     return float((cyc[i1] - cyc[i0]) / (ref[i1] - ref[i0])), (float(min(win)), float(max(win))) if win else None
+
+
+def eval_throughput(model, img, cam, view, b, steps):
+    """Forward-only throughput of the boundary's OTHER caller, do_inference (engine/processor.py:217-270): model.eval(), no_grad,
+    `model(img, cam_label=, view_label=)` -> (B, 2304) features, inputs resident, timed as `steps` back-to-back forwards between
+    two synchronisations - as a hipGraph replay like the training step, and eagerly (the serial selection kernels are on
+    the critical path here: nothing hides them behind a side stream's weight gradients)."""
+    was_training = model.training
+    model.eval()
+    res = {"what": "model.eval() forward at the same batch (do_inference, engine/processor.py:217-270): images/sec, inputs resident"}
+    try:
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    out = model(img, cam_label=cam, view_label=view)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = model(img, cam_label=cam, view_label=view)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            res["eager"] = {"value": round(b * steps / el, 1), "ms_per_batch": round(1e3 * el / steps, 3)}
+            try:
+                torch.cuda.empty_cache()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = model(img, cam_label=cam, view_label=view)
+                g.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    g.replay()
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                res["graph"] = {"value": round(b * steps / el, 1), "ms_per_batch": round(1e3 * el / steps, 3)}
+                del g
+            except Exception as e:
+                res["graph"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+                torch.cuda.synchronize()
+            res["value"] = max(v["value"] for v in (res.get("eager"), res.get("graph")) if v and "value" in v)
+            res["features_finite"] = bool(torch.isfinite(out).all())
+    except Exception as e:
+        res["error"] = f"{type(e).__name__}: {e}"[:300]
+    model.train(was_training)
+    return res
 
 
 def torch_gpu_yardstick():
@@ -470,6 +568,9 @@ def main():
     ap.add_argument("--act-light", action="store_true", help="activation-light blocks (cfg.MODEL.ACT_LIGHT): 24 B instead of 36 B "
                     "saved per token-row-element (config 5 at B = 64 per GPU)")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-mode block (speed + accuracy of bf16 / f16 / f16x2 / f32)")
+    ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"], help="N > 1: dtype of the gradient buckets on the wire "
+                    "(bf16: 237.8 instead of 475.7 MB per step over the xGMI ring; the strong-scaling series needs it)")
+    ap.add_argument("--no-eval", action="store_true", help="skip the forward-only (do_inference) throughput block")
     ap.add_argument("--spawn", action="store_true", help="go through the rank launcher even for --gpus 1 (a real 1-rank RCCL group; "
                     "also EDITOR_BENCH_SPAWN=1)")
     args = ap.parse_args()
@@ -534,7 +635,7 @@ def main():
     # remaining backward in the eager step AND in the captured hipGraph (the collectives are part of the graph).
     # (N = 1 as well: the in-place gradient slots are how the backward hands its weight gradients over - no process group, no
     # collective; editor_amd.functional.GROUP_WGRAD)
-    buckets = model.enable_grad_buckets(force=force_ddp)
+    buckets = model.enable_grad_buckets(force=force_ddp, wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None)
     buckets.broadcast_parameters(model)
 
     # solver/make_optimizer.py:4-29: SGD, momentum 0.9, wd 1e-4, bias lr x2 (BASE_LR 0.001) - fused HIP update
@@ -715,6 +816,9 @@ def main():
     probe.recording = False
     probe.remove()
     lossv = float(loss.detach())
+    eval_block = None
+    if rank == 0 and world == 1 and not force_ddp and not args.no_eval:
+        eval_block = eval_throughput(model, img, cam, view, b, max(args.steps, 3))
 
     if rank == 0:
         kinds = {} if args.no_replay else probe.replay()
@@ -724,18 +828,22 @@ def main():
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         ms_step = 1e3 * elapsed / args.steps
         arch = cfg.MODEL.TRANSFORMER_TYPE.replace("_patch16_224", "").replace("vit_", "ViT-").replace("base", "B").replace("large", "L")
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if os.path.exists(tpath) and args.preset == "RGBNT201" and b == 128 and args.dtype == "bf16":
+        # `traffic` / `alg_bytes_per_step` are NOT measured in this run: PMC counters need their own rocprofv3 passes
+        # (MI355X_MICROARCH.md), so the figure is read from the newest committed profile of this same command
+        # (tools/pmc_traffic.sh -> profiles/rNN_pmc_traffic.json) and labelled as such (`traffic_source`)
+        import glob
+        traffic, tsrc = None, None
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+        if tfiles and args.preset == "RGBNT201" and b == 128 and args.dtype == "bf16":
             try:
-                traffic = json.load(open(tpath))
+                traffic = json.load(open(tfiles[-1]))
+                tsrc = os.path.relpath(tfiles[-1], ROOT) + " (builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.sh; not measured in this run)"
             except Exception:
                 traffic = None
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS, 4),
                 "traffic": None if traffic is None else traffic.get("gemm_hbm_bytes_per_step"),
+                "traffic_source": tsrc,
                 "traffic_note": None if traffic is None else traffic.get("note"),
                 "kernel": "16-bit GEMM family: gemm_bf16_pp_kernel (256x256x64 ping-pong; fwd, dgrad, and wgrad as one round of "
                           "split-K workgroups + slab reduction), v_mfma_f32_16x16x32_" + ("bf16" if args.dtype == "bf16" else "f16") +
@@ -747,7 +855,7 @@ def main():
                             for k, (f, m_, n) in kinds.items()}}
         # whole-step view: SURVEY.md 8(d)'s algorithmic FLOPs of one step (240.5 GF per tri-modal 256x128 ViT-B image fwd+bwd,
         # scaled by tokens / width for the other presets through the measured GEMM list when available) over the step time
-        alg_step = {"RGBNT201": 240.5e9, "RGBNT100": 240.5e9, "MSVR310": 368e9}.get(args.preset)
+        alg_step = {"RGBNT201": 240.5e9, "RGBNT100": 240.5e9, "MSVR310": 368e9, "SYNTH4L": 4.4e12}.get(args.preset)
         if alg_step is not None:
             roof["step_alg_tflop"] = round(alg_step * b / 1e12, 2)
             roof["step_frac"] = round(alg_step * b / (ms_step * 1e-3) / 1e12 / PEAK_TFLOPS, 4)
@@ -764,7 +872,7 @@ def main():
                 roof["sclk_mhz_during_step"] = round(mhz[0], 0)
                 roof["sclk_mhz_min_max_0p5ms"] = None if mhz[1] is None else [round(mhz[1][0], 0), round(mhz[1][1], 0)]
         if not args.no_replay:
-            roof["hbm_kernels"] = hbm_kernels(model, img, b, model.act_dtype)
+            roof["hbm_kernels"], roof["hbm_kernels_in_situ_source"] = hbm_kernels(model, img, b, model.act_dtype)
         out = {
             "metric": "tri-modal images/sec fwd+bwd @ B=128 ViT-B",
             "value": round(world * b * args.steps / elapsed, 2),
@@ -791,10 +899,12 @@ def main():
             out["rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms}
             out["not_in_this_line"] = ("modes, cpu_baseline, replay_only and torch_gpu_yardstick are single-process blocks of the "
                                        "N = 1 line (python bench.py --gpus 1)")
+        if eval_block is not None:
+            out["eval"] = eval_block
         if replay_only is not None:
             out["replay_only"] = replay_only
         if world == 1 and not args.no_modes and not force_ddp and args.preset in ("RGBNT201", "RGBNT100", "MSVR310"):
-            out["modes"] = modes_block(args, cfg, cams, out["value"])
+            out["modes"] = modes_block(args, cfg, cams, out["value"], eval_block)
         if world == 1 and not args.no_cpu_baseline and not force_ddp:
             out["cpu_baseline"] = cpu_baseline(model, cfg, cams, b, args.cpu_iters)
             if args.preset == "RGBNT201" and b == 128:

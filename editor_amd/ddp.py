@@ -203,8 +203,17 @@ class GradBuckets:
       usual and go through one packed tail bucket in `finish()`, which also waits for everything in flight.
     Backends: nccl (= RCCL, AVG in the collective) and gloo (SUM + scale; CPU tests)."""
 
-    def __init__(self, segments, tail_params, bucket_bytes=64 << 20, process_group=None, force=False):
-        """segments: list of (name, [12 parameters or None]) in gradient-READY order.  tail_params: the rest."""
+    def __init__(self, segments, tail_params, bucket_bytes=64 << 20, process_group=None, force=False, wire_dtype=None):
+        """segments: list of (name, [12 parameters or None]) in gradient-READY order.  tail_params: the rest.
+        wire_dtype: None / torch.float32 = the buckets travel as they are (fp32, 475.7 MB per step for EDITOR); torch.bfloat16 =
+        16-bit exchange ("flat bucketed grads (bf16 or fp32)"; what DDP's bf16_compress_hook does): a ready
+        bucket is cast into a persistent bf16 twin on the comm stream, the twin is all-reduced (half the bytes on the xGMI
+        ring: 237.8 MB) and cast back into the fp32 slots the optimizer reads.  bfloat16 whatever the compute mode: fp32's
+        range, so unscaled gradient sums cannot overflow on the wire.  The averaged gradient then equals the fp32 exchange to
+        bf16 rounding (2^-9 relative per element; tests/test_ddp_gloo.py)."""
+        if wire_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("GradBuckets: wire_dtype must be None / torch.float32 / torch.bfloat16")
+        self.wire_dtype = torch.bfloat16 if wire_dtype == torch.bfloat16 else None
         self.group = process_group
         inited = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if inited else 1
@@ -282,6 +291,17 @@ class GradBuckets:
             if self.active:
                 self._launch(b)
 
+    def _wire(self, b):
+        """The tensor that travels: the bucket itself, or its persistent 16-bit twin (allocated once: a captured graph replays
+        launches that hold its address)."""
+        if self.wire_dtype is None:
+            return b["flat"]
+        w = b.get("wire")
+        if w is None or w.numel() != b["flat"].numel():
+            w = b["wire"] = torch.empty(b["flat"].numel(), dtype=self.wire_dtype, device=b["flat"].device)
+        w.copy_(b["flat"])                   # fp32 -> bf16, on the stream the collective is issued from
+        return w
+
     def _launch(self, b):
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         if b["flat"].is_cuda:
@@ -297,9 +317,9 @@ class GradBuckets:
             if side is not None:
                 comm.wait_stream(side)
             with torch.cuda.stream(comm):
-                b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
+                b["work"] = dist.all_reduce(self._wire(b), op=op, group=self.group, async_op=True)
         else:
-            b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
+            b["work"] = dist.all_reduce(self._wire(b), op=op, group=self.group, async_op=True)
         self._inflight.append(b)
 
     def _comm_stream(self, dev):
@@ -349,6 +369,8 @@ class GradBuckets:
             torch.cuda.current_stream(self._comm.device).wait_stream(self._comm)     # (re-joins the issuing stream: capture)
         for b in self._inflight:
             b["work"].wait()
+            if self.wire_dtype is not None:
+                b["flat"].copy_(b["wire"])          # bf16 -> the fp32 slots the optimizer reads
             if not self._avg:
                 b["flat"].mul_(inv)
             b["work"] = None
@@ -390,8 +412,10 @@ class GradBuckets:
             self._broadcast_coalesced(bufs, src)
 
     def describe(self):
+        esz = 2 if self.wire_dtype is not None else 4
         return {"buckets": len(self.buckets) + 1, "bucket_mib": [round(b["flat"].numel() * 4 / 2 ** 20, 1) for b in self.buckets],
-                "segments": len(self.segments)}
+                "segments": len(self.segments), "wire_dtype": "bf16" if self.wire_dtype is not None else "f32",
+                "wire_mb_per_step": round(sum(b["flat"].numel() for b in self.buckets) * esz / 1e6, 1)}
 
 
 def graph_capture_kwargs(settle=0.3):

@@ -329,10 +329,10 @@ class EDITOR(nn.Module):
         tail = [p for p in self.parameters() if id(p) not in inseg]
         return segs, tail
 
-    def enable_grad_buckets(self, bucket_bytes=64 << 20, process_group=None, force=False):
+    def enable_grad_buckets(self, bucket_bytes=64 << 20, process_group=None, force=False, wire_dtype=None):
         from ..ddp import GradBuckets
         segs, tail = self.grad_segments()
-        self.grad_buckets = GradBuckets(segs, tail, bucket_bytes, process_group, force)
+        self.grad_buckets = GradBuckets(segs, tail, bucket_bytes, process_group, force, wire_dtype)
         self._seg_index = {name: i for i, (name, _) in enumerate(segs)}
         return self.grad_buckets
 

@@ -34,6 +34,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
     assert 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None                 # (the PMC figure belongs to the B = 128 configuration only)
+    ev = j["eval"]                              # forward-only throughput of do_inference's call (VERDICT r3 missing #5)
+    assert ev["value"] > j["value"] and ev["features_finite"] is True and "eager" in ev
+    hk = r["hbm_kernels"]
+    assert len(hk) >= 5 and all(k["sets"] >= 3 and 0.0 < k["frac"] < 1.0 for k in hk)      # rotating operand sets: HBM, not Infinity Cache
     c = j["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "bf16 wire16"])
 def test_grad_bucket_sinks_equal_plain_autograd(dtype):
     import torch
     torch.cuda.empty_cache()           # this process may hold tens of GB of cached blocks from earlier tests: the child needs its own
@@ -23,7 +23,7 @@ def test_grad_bucket_sinks_equal_plain_autograd(dtype):
     for attempt in range(2):           # (one retry for a failed rendezvous.  The intermittent abort this test used to show - 1 run in 6 -
                                        #  was the process group's watchdog querying an event while the capture was open: fixed
                                        #  by editor_amd.ddp.graph_capture_kwargs, thread-local capture mode)
-        cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ddp_selfcheck.py"), dtype], stdout=subprocess.PIPE,
+        cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ddp_selfcheck.py")] + dtype.split(), stdout=subprocess.PIPE,
                             stderr=subprocess.STDOUT, text=True, timeout=900)
         out = cp.stdout
         if cp.returncode == 0 and "DDP-SELFCHECK-OK" in out:

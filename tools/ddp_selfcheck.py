@@ -22,6 +22,9 @@ class _Quiet:
         pass
 
 
+WIRE = None          # torch.bfloat16: the 16-bit gradient exchange (python tools/ddp_selfcheck.py bf16 wire16)
+
+
 def _build(dtype, buckets):
     from editor_amd.modeling import make_model
     from editor_amd import solver
@@ -31,7 +34,7 @@ def _build(dtype, buckets):
         m = make_model(cfg, c, cams)
     synth.fill_state_dict_(m.state_dict(), 31)
     m = m.cuda().train()
-    gb = m.enable_grad_buckets(force=True) if buckets else None
+    gb = m.enable_grad_buckets(force=True, wire_dtype=WIRE) if buckets else None
     if gb is not None:
         gb.broadcast_parameters(m)
     opt, _ = solver.make_optimizer(cfg, m, None)
@@ -81,15 +84,20 @@ def main(dtype):
         gb.finish()
         torch.cuda.synchronize()
         n0, n1 = dict(m0.named_parameters()), dict(m1.named_parameters())
+        # (16-bit wire: a 1-rank AVG all-reduce of the bf16 twin is the identity on it, so every exchanged gradient is EXACTLY the
+        #  plain gradient rounded to bf16 once - bucket slots and tail alike)
+        want = (lambda g: g.to(WIRE).float()) if WIRE is not None else (lambda g: g)
         bad = [k for k in n0 if (n0[k].grad is None) != (n1[k].grad is None) or
-               (n0[k].grad is not None and not torch.equal(n0[k].grad, n1[k].grad))]
+               (n0[k].grad is not None and not torch.equal(want(n0[k].grad), n1[k].grad))]
         assert not bad, ("gradients differ", bad[:8])
+        if WIRE is not None:
+            assert all(p.grad.dtype == torch.float32 for p in m1.parameters() if p.grad is not None)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     # (2) five eager steps without the exchange == two eager + one captured step replayed three times with it
-    m0, opt0, _, _ = _build(dtype, False)
+    m0, opt0, gb0, _ = _build(dtype, WIRE is not None)     # (16-bit wire: the eager reference exchanges in 16 bits too)
     m1, opt1, gb, _ = _build(dtype, True)
-    s0, s1 = _step_fn(m0, opt0, None, batch), _step_fn(m1, opt1, gb, batch)
+    s0, s1 = _step_fn(m0, opt0, gb0, batch), _step_fn(m1, opt1, gb, batch)
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(5):
@@ -110,10 +118,12 @@ def main(dtype):
     sd0, sd1 = m0.state_dict(), m1.state_dict()
     diff = [k for k in sd0 if not torch.equal(sd0[k], sd1[k])]
     assert not diff, ("parameters differ after capture + replay", diff[:8])
-    print("DDP-SELFCHECK-OK", dtype, "buckets", len(gb.buckets), flush=True)
+    print("DDP-SELFCHECK-OK", dtype, "buckets", len(gb.buckets), "wire", gb.describe()["wire_dtype"], flush=True)
     sys.stdout.flush()
     os._exit(0)          # (RCCL's destructors at interpreter exit are not part of the check)
 
 
 if __name__ == "__main__":
+    if "wire16" in sys.argv[2:]:
+        WIRE = torch.bfloat16
     main(sys.argv[1] if len(sys.argv) > 1 else "bf16")
