@@ -76,6 +76,7 @@ struct GemmB16Args {
     void* C_lo;                              // 16-bit outputs leave as a pair too (C = hi, C_lo = lo); NULL for fp32 outputs
     int linear_ids;                          // ping-pong kernel: `bid` already is the position in the grouped tile order (the
                                              // grouped weight-gradient launch does its own XCD mapping)
+    int prefer_pipe;                         // EDITOR_EPI_PIPE128
 };
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: remember it per device index, so a
@@ -1420,7 +1421,9 @@ int launch_pipe(const GemmB16Args& g, hipStream_t stream)
 #ifdef EDITOR_DEBUG_TRACE
     if (const char* e = getenv("EDITOR_GEMM_PP")) pp_mode = atoi(e);
 #endif
-    const bool pp_auto = g.M >= 2048 && g.splitk == 1 && AK && g.N >= 512;
+    // EDITOR_EPI_PIPE128 (the caller's tile-count heuristic, editor_amd.ops.gemm): few token rows - the strong-scaling series'
+    // B_local = 16 gives M = 6 192, i.e. 72 - 90 tiles of a 768-wide output on 256 CUs - take the 256x128 tiles instead
+    const bool pp_auto = g.M >= 2048 && g.splitk == 1 && AK && g.N >= 512 && !g.prefer_pipe;
     if (g.N >= 256 && (pp_mode == 1 || g.colsum || (pp_mode < 0 && pp_auto))) return launch_pp<F16, AK, BK_, CF>(g, stream);
     return launch_pipe_t<F16, AK, BK_, CF, 256, 128, 3, 8>(g, stream);
 }
@@ -1444,7 +1447,8 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
     const bool aux_grad = (epilogue & EDITOR_EPI_AUX_GRAD) != 0;
     const int tile_frags = (epilogue >> 12) & 15;                       // EDITOR_EPI_TILE_ROWS(h): h / 16, 0 = full tiles
     if (tile_frags != 0 && tile_frags != 13) return (int)hipErrorInvalidValue;
-    epilogue &= ~(EDITOR_EPI_COLSUM | EDITOR_EPI_FORCE_PP | EDITOR_EPI_AUX_GRAD | 0xF000);
+    const bool prefer_pipe = (epilogue & EDITOR_EPI_PIPE128) != 0 && !want_colsum && !force_pp && tile_frags == 0;
+    epilogue &= ~(EDITOR_EPI_COLSUM | EDITOR_EPI_FORCE_PP | EDITOR_EPI_AUX_GRAD | EDITOR_EPI_PIPE128 | 0xF000);
     if (aux_grad && epilogue != EDITOR_EPI_GELU && epilogue != EDITOR_EPI_GELU_BWD) return (int)hipErrorInvalidValue;
     if (want_colsum && (c_f32 || epilogue == EDITOR_EPI_RESIDUAL || splitk > 1 || !splitk_ws || transA || M < 2048 || N < 512 ||
                         (N & 7) || (ldc & 7) || (ldaux & 7) || (K % BK) || beta != 0.f || m_live))
@@ -1473,7 +1477,7 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
                   slabs ? 0.f : beta, bias, rowscale, splitk, (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux,
                   slabs ? 1 : 0,
                   m_live, transA ? 1 : 0, 0, want_colsum ? splitk_ws : nullptr, nullptr, force_pp ? 1 : 0, aux_grad ? 1 : 0,
-                  tile_frags, nullptr, nullptr, nullptr};
+                  tile_frags, nullptr, nullptr, nullptr, 0, prefer_pipe ? 1 : 0};
     if (m_live && (!pipe || (splitk > 1 && !slabs))) return (int)hipErrorInvalidValue;   // live-row form: pipelined path only
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
     int rc;

@@ -145,12 +145,179 @@ __global__ __launch_bounds__(256) void freq_counts_kernel(
     if (lane == 0) counts[tile] = cnt;
 }
 
+// ---- round 4: 4 x 4 pixels per lane ------------------------------------------------------------------------------------
+// The kernel above is VALU-bound, not shuffle- or HBM-bound: a lane owns 2 x 2 pixels and levels 2-4 are computed by EVERY lane
+// of the 2x2 / 4x4 / 8x8 lane groups that share a coefficient block (4x, 16x, 64x redundant), plus 39 IEEE divisions by the
+// modality count per lane - ~1 470 VALU instructions per 4 pixels, i.e. ~7.7 bytes per clock and CU at full issue rate, under
+// the ~10 B/clk a CU can pull from HBM (measured: 0.47 of HBM warm, 0.29 inside the step).
+// Here a lane owns 4 x 4 pixels of a plane (four 16-byte loads: full 256-byte row segments per wave instruction), levels 1 and 2
+// are register-local, only levels 3 and 4 cross lanes (xor 1 / 4 and 2 / 8 inside a row of 16 lanes: DPP quad permutes and
+// ds_swizzle, no address registers), a wave covers FOUR patches, and x / 3 is the three-instruction correctly-rounded form
+// (q = RN(x * RN(1/3)); r = fma(-q, 3, x) exact; RN(q + r * RN(1/3)) = RN(x / 3): Markstein) with the IEEE sequence kept for
+// the inputs it does not cover (denormals, infinities: a wave-uniform, never-taken branch on image data).  ~1 600 instructions
+// per 16 pixels: 3.7x fewer per pixel, same arithmetic per element (same haar_fwd / haar_inv expressions, same summation
+// orders) - bit-identical counts (tests/test_gpu_select.py against the reference's goldens and against the kernel above).
+template <int XM> __device__ __forceinline__ float lane_xor16(float v)
+{
+    // value of lane (l ^ XM), XM < 16: inside a row of 16 lanes
+    if constexpr (XM == 1) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    else if constexpr (XM == 2) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    else return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x1F | (XM << 10)));
+}
+template <int BX, int BY> __device__ __forceinline__ Quad gather_level16(float v, int lane)
+{
+    const float vx = lane_xor16<BX>(v), vy = lane_xor16<BY>(v), vxy = lane_xor16<BX | BY>(v);
+    const bool cx = lane & BX, cy = lane & BY;
+    const float x00 = cy ? (cx ? vxy : vy) : (cx ? vx : v);
+    const float x01 = cy ? (cx ? vy : vxy) : (cx ? v : vx);
+    const float x10 = cy ? (cx ? vx : v) : (cx ? vxy : vy);
+    const float x11 = cy ? (cx ? v : vx) : (cx ? vy : vxy);
+    return haar_fwd(x00, x01, x10, x11);
+}
+// x / DIV, correctly rounded.  `rare` collects the inputs the short form does not cover.
+template <int DIV> __device__ __forceinline__ float div_small(float x, bool& rare)
+{
+    if constexpr (DIV == 4 || DIV == 2 || DIV == 1) return x * (1.0f / DIV);     // exact scaling (true division rounds the same way)
+    else {
+        constexpr float c = (float)DIV, rc = 1.0f / (float)DIV;                  // RN(1 / DIV)
+        rare |= __builtin_amdgcn_classf(x, 0x010 | 0x080 | 0x004 | 0x200);   // +-denormal, +-infinity
+        const float q = __fmul_rn(x, rc);
+        const float r = __fmaf_rn(-q, c, x);
+        return __fmaf_rn(r, rc, q);
+    }
+}
+
+template <int NMOD, int NC>
+__global__ __launch_bounds__(256) void freq_counts4_kernel(
+    const float* __restrict__ m0, const float* __restrict__ m1, const float* __restrict__ m2, const float* __restrict__ m3,
+    int B, int H, int W, int32_t* __restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    const int tiles_x = W >> 4, tiles_y = H >> 4, ntile = tiles_x * tiles_y;
+    const long total = (long)B * ntile;
+    const long tile_raw = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);     // four patches per wave
+    const long tile = tile_raw < total ? tile_raw : total - 1;                                // (a clamped slot never writes)
+    const int b = (int)(tile / ntile), p = (int)(tile % ntile);
+    const int ty = p / tiles_x, tx = p % tiles_x;
+    const int lx = lane & 3, ly = (lane >> 2) & 3;                                            // 4 x 4 lanes per patch
+    const int y0 = ty * 16 + ly * 4, x0 = tx * 16 + lx * 4;
+    const float* mods[4] = {m0, m1, m2, m3};
+
+    float sum[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum[i][j] = 0.f;
+    bool rare = false;
+
+    float4 cur[NMOD][4], nxt[NMOD][4];
+    auto load = [&](float4 (&dst)[NMOD][4], int c) {
+#pragma unroll
+        for (int m = 0; m < NMOD; ++m) {
+            const float* base = mods[m] + (((long)b * NC + c) * H + y0) * W + x0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[m][r] = *reinterpret_cast<const float4*>(base + (long)r * W);
+        }
+    };
+    constexpr bool AHEAD = NMOD <= 3;                      // (four modalities: 128 more registers would leave one wave per SIMD)
+    load(cur, 0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (AHEAD && c + 1 < NC) load(nxt, c + 1);         // the next channel's rows are in flight under this channel's arithmetic
+        // ---- analysis, modality by modality, coefficients summed in modality order (Frequency.py:71-74)
+        Quad a1[2][2], a2, a3, a4;                         // level-1 quads of the lane's four 2x2 blocks, levels 2-4
+        float ll4 = 0.f;
+#pragma unroll
+        for (int m = 0; m < NMOD; ++m) {
+            const float4 r0 = cur[m][0], r1 = cur[m][1], r2 = cur[m][2], r3 = cur[m][3];
+            const Quad q00 = haar_fwd(r0.x, r0.y, r1.x, r1.y), q01 = haar_fwd(r0.z, r0.w, r1.z, r1.w);
+            const Quad q10 = haar_fwd(r2.x, r2.y, r3.x, r3.y), q11 = haar_fwd(r2.z, r2.w, r3.z, r3.w);
+            const Quad q2 = haar_fwd(q00.ll, q01.ll, q10.ll, q11.ll);
+            const Quad q3 = gather_level16<1, 4>(q2.ll, lane);
+            const Quad q4 = gather_level16<2, 8>(q3.ll, lane);
+            if (m == 0) { a1[0][0] = q00; a1[0][1] = q01; a1[1][0] = q10; a1[1][1] = q11; a2 = q2; a3 = q3; a4 = q4; ll4 = q4.ll; }
+            else {
+                a1[0][0].lh += q00.lh; a1[0][0].hl += q00.hl; a1[0][0].hh += q00.hh;
+                a1[0][1].lh += q01.lh; a1[0][1].hl += q01.hl; a1[0][1].hh += q01.hh;
+                a1[1][0].lh += q10.lh; a1[1][0].hl += q10.hl; a1[1][0].hh += q10.hh;
+                a1[1][1].lh += q11.lh; a1[1][1].hl += q11.hl; a1[1][1].hh += q11.hh;
+                a2.lh += q2.lh; a2.hl += q2.hl; a2.hh += q2.hh;
+                a3.lh += q3.lh; a3.hl += q3.hl; a3.hh += q3.hh;
+                a4.lh += q4.lh; a4.hl += q4.hl; a4.hh += q4.hh;
+                ll4 += q4.ll;
+            }
+        }
+        // ---- mean over the modalities
+        float* dv[22] = {&a1[0][0].lh, &a1[0][0].hl, &a1[0][0].hh, &a1[0][1].lh, &a1[0][1].hl, &a1[0][1].hh,
+                         &a1[1][0].lh, &a1[1][0].hl, &a1[1][0].hh, &a1[1][1].lh, &a1[1][1].hl, &a1[1][1].hh,
+                         &a2.lh, &a2.hl, &a2.hh, &a3.lh, &a3.hl, &a3.hh, &a4.lh, &a4.hl, &a4.hh, &ll4};
+        float raw[22];
+        bool rare_c = false;
+#pragma unroll
+        for (int i = 0; i < 22; ++i) { raw[i] = *dv[i]; *dv[i] = div_small<NMOD>(raw[i], rare_c); }
+        if (__builtin_amdgcn_ballot_w64(rare_c) != 0ull) {           // denormal / infinite coefficient somewhere in the wave
+            const float fnm = (float)NMOD;
+#pragma unroll
+            for (int i = 0; i < 22; ++i) *dv[i] = raw[i] / fnm;
+        }
+        a4.ll = ll4;
+        // ---- synthesis: every lane rebuilds its own LL chain (no communication), then its 16 pixels
+        a3.ll = haar_inv(a4, (lane >> 3) & 1, (lane >> 1) & 1);
+        a2.ll = haar_inv(a3, (lane >> 2) & 1, lane & 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                a1[i][j].ll = haar_inv(a2, i, j);
+#pragma unroll
+                for (int ry = 0; ry < 2; ++ry)
+#pragma unroll
+                    for (int rx = 0; rx < 2; ++rx) sum[2 * i + ry][2 * j + rx] += haar_inv(a1[i][j], ry, rx);
+            }
+        if (c + 1 < NC) {
+            if constexpr (AHEAD) {
+#pragma unroll
+                for (int m = 0; m < NMOD; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cur[m][r] = nxt[m][r];
+            } else {
+                load(cur, c + 1);
+            }
+        }
+    }
+    // sign(mean over channels): torch.mean then .gt(0) (Frequency.py:44,54) - the division is kept (a sum that underflows to
+    // zero when divided is not positive)
+    float mean[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mean[i] = div_small<NC>(sum[i >> 2][i & 3], rare);
+    if (__builtin_amdgcn_ballot_w64(rare) != 0ull) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mean[i] = sum[i >> 2][i & 3] / (float)NC;
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cnt += mean[i] > 0.f;
+    // sum over the 16 lanes of the patch
+    cnt += __builtin_amdgcn_mov_dpp(cnt, 0xB1, 0xF, 0xF, true);
+    cnt += __builtin_amdgcn_mov_dpp(cnt, 0x4E, 0xF, 0xF, true);
+    cnt += __builtin_amdgcn_ds_swizzle(cnt, 0x1F | (4 << 10));
+    cnt += __builtin_amdgcn_ds_swizzle(cnt, 0x1F | (8 << 10));
+    if ((lane & 15) == 0 && tile_raw < total) counts[tile] = cnt;
+}
+
 static int freq_counts_launch(const float* m0, const float* m1, const float* m2, const float* m3, int nmod, int B, int C, int H, int W,
-                              int32_t* counts, hipStream_t stream)
+                              int32_t* counts, hipStream_t stream, int variant = 0)
 {
     const long tiles = (long)B * (H >> 4) * (W >> 4);
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-    if (nmod == 3 && C == 3)
+    const dim3 grid4((unsigned)((tiles + 15) / 16));            // 4 x 4 pixels per lane: four patches per wave, 16 per block
+    const bool al16 = ((reinterpret_cast<uintptr_t>(m0) | reinterpret_cast<uintptr_t>(m1) | reinterpret_cast<uintptr_t>(m2) |
+                        reinterpret_cast<uintptr_t>(m3)) & 15) == 0;
+    if (nmod == 3 && C == 3 && al16 && variant == 0)
+        hipLaunchKernelGGL((freq_counts4_kernel<3, 3>), grid4, block, 0, stream, m0, m1, m2, m3, B, H, W, counts);
+    else if (nmod == 4 && C == 3 && al16 && variant == 0)
+        hipLaunchKernelGGL((freq_counts4_kernel<4, 3>), grid4, block, 0, stream, m0, m1, m2, m3, B, H, W, counts);
+    else if (nmod == 3 && C == 3)
         hipLaunchKernelGGL((freq_counts_kernel<3, 3>), grid, block, 0, stream, m0, m1, m2, m3, nmod, B, C, H, W, counts);
     else if (nmod == 4 && C == 3)
         hipLaunchKernelGGL((freq_counts_kernel<4, 3>), grid, block, 0, stream, m0, m1, m2, m3, nmod, B, C, H, W, counts);
@@ -162,20 +329,27 @@ static int freq_counts_launch(const float* m0, const float* m1, const float* m2,
 
 // ------------------------------------------------------------------------------------------------
 // K7/K9b  top-k with torch.topk's CPU tie order (libstdc++ partial_sort / nth_element on (value,index)
-//         pairs).  One lane owns one row; rows live lane-interleaved in LDS.
+//         pairs).
+// The two algorithms are serial walks whose every step depends on the previous one, so a row is ONE lane's work - but lanes
+// of a wave that walk different rows diverge at every data-dependent branch and the wave pays the union of their paths
+// (rounds 1-3: 64 rows per wave, 222 us for the 128 frequency rows on TWO wavefronts of the whole chip, 91 us for the 4 608
+// attention rows).  Here a row is one WAVE's: its 64 lanes load the row (coalesced), lane 0 walks it in LDS with each
+// (value, index) pair packed into ONE 8-byte word (a move is one ds_read_b64 + one ds_write_b64), and the lanes share the
+// mask write.  128 rows -> 128 waves on 32+ CUs, 4 608 rows -> 1 152 workgroups: the kernel takes one row's serial time.
 // ------------------------------------------------------------------------------------------------
+template <typename V> struct Pair { V v; uint32_t i; };
+static_assert(sizeof(Pair<float>) == 8 && sizeof(Pair<int>) == 8, "one LDS word per pair");
 template <typename V> struct Row {
-    V* val; uint16_t* idx; int stride;      // element j of this lane's row at [j*stride]
-    __device__ __forceinline__ V& v(int j) { return val[j * stride]; }
-    __device__ __forceinline__ uint16_t& i(int j) { return idx[j * stride]; }
+    Pair<V>* q;
+    __device__ __forceinline__ V v(int j) const { return q[j].v; }
+    __device__ __forceinline__ uint32_t i(int j) const { return q[j].i; }
 };
-template <typename V> struct Pair { V v; uint16_t i; };
 
 __device__ __forceinline__ bool before(float x, float y) { return (isnan(x) && !isnan(y)) || (x > y); }
 __device__ __forceinline__ bool before(int x, int y) { return x > y; }
 
-template <typename V> __device__ __forceinline__ Pair<V> get(Row<V>& r, int j) { return Pair<V>{r.v(j), r.i(j)}; }
-template <typename V> __device__ __forceinline__ void put(Row<V>& r, int j, Pair<V> p) { r.v(j) = p.v; r.i(j) = p.i; }
+template <typename V> __device__ __forceinline__ Pair<V> get(Row<V>& r, int j) { return r.q[j]; }
+template <typename V> __device__ __forceinline__ void put(Row<V>& r, int j, Pair<V> p) { r.q[j] = p; }
 template <typename V> __device__ __forceinline__ void swp(Row<V>& r, int a, int b) {
     Pair<V> t = get(r, a); put(r, a, get(r, b)); put(r, b, t);
 }
@@ -215,11 +389,28 @@ template <typename V> __device__ void heap_select_(Row<V>& r, int base, int midd
             parent--;
         }
     }
-    for (int i = middle; i < last; ++i)
-        if (before(r.v(base + i), r.v(base))) {
+    // the scan: eight candidates are requested together (independent LDS reads), the heap top lives in a register and is
+    // re-read only after a replacement
+    V top = r.v(base);
+    int i = middle;
+    for (; i + 8 <= last; i += 8) {
+        Pair<V> c[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c[e] = get(r, base + i + e);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (before(c[e].v, top)) {
+                put(r, base + i + e, get(r, base));
+                adjust_heap_(r, base, 0, middle, c[e]);
+                top = r.v(base);
+            }
+    }
+    for (; i < last; ++i)
+        if (before(r.v(base + i), top)) {
             Pair<V> val = get(r, base + i);
             put(r, base + i, get(r, base));
             adjust_heap_(r, base, 0, middle, val);
+            top = r.v(base);
         }
 }
 template <typename V> __device__ void insertion_sort_(Row<V>& r, int first, int last) {
@@ -268,34 +459,27 @@ template <typename V> __device__ void introselect_(Row<V>& r, int first, int nth
 }
 
 template <typename V>
-__global__ __launch_bounds__(64) void topk_mask_kernel(const V* __restrict__ vals, int rows, int n, int k,
-                                                       int group, uint8_t* __restrict__ mask, int rows_per_block)
+__global__ __launch_bounds__(256) void topk_mask_kernel(const V* __restrict__ vals, int rows, int n, int k,
+                                                        int group, uint8_t* __restrict__ mask)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    V* sval = reinterpret_cast<V*>(smem);
-    uint16_t* sidx = reinterpret_cast<uint16_t*>(smem + (size_t)rows_per_block * n * sizeof(V));
-    const int lane = threadIdx.x;
-    const long row0 = (long)blockIdx.x * rows_per_block;
-    // coalesced fill: consecutive threads read consecutive elements of the block's rows
-    const long total = (long)rows_per_block * n;
-    for (long e = lane; e < total; e += 64) {
-        const int rl = (int)(e / n), j = (int)(e % n);
-        if (row0 + rl < rows) {
-            sval[j * rows_per_block + rl] = vals[(row0 + rl) * n + j];
-            sidx[j * rows_per_block + rl] = (uint16_t)j;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (row >= rows) return;                                     // (whole wave; no block-level barrier below)
+    Pair<V>* q = reinterpret_cast<Pair<V>*>(smem) + (size_t)wave * n;
+    for (int j = lane; j < n; j += 64) q[j] = Pair<V>{vals[row * n + j], (uint32_t)j};
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        Row<V> r{q};
+        if ((long)k * 64 <= n) heap_select_(r, 0, k, n);             // std::partial_sort's selection half
+        else {
+            int lg = 0; for (int t = n; t > 1; t >>= 1) ++lg;
+            introselect_(r, 0, k - 1, n, 2 * lg);                    // std::nth_element
         }
     }
-    __syncthreads();
-    const long row = row0 + lane;
-    if (lane >= rows_per_block || row >= rows) return;
-    Row<V> r{sval + lane, sidx + lane, rows_per_block};
-    if ((long)k * 64 <= n) heap_select_(r, 0, k, n);             // std::partial_sort's selection half
-    else {
-        int lg = 0; for (int t = n; t > 1; t >>= 1) ++lg;
-        introselect_(r, 0, k - 1, n, 2 * lg);                    // std::nth_element
-    }
+    __builtin_amdgcn_wave_barrier();
     uint8_t* out = mask + (row / group) * (long)n;
-    for (int j = 0; j < k; ++j) out[r.i(j)] = 1;                 // benign same-value races across heads
+    for (int j = lane; j < k; j += 64) out[q[j].i] = 1;          // benign same-value races across heads
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -373,15 +557,10 @@ static int topk_mask_launch(const V* vals, int rows, int n, int k, int group, ui
     if (k <= 0 || k > n || n > 4096 || group <= 0 || rows % group) return (int)hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(mask, 0, (size_t)(rows / group) * n, stream);
     if (e != hipSuccess) return (int)e;
-    int rpb = 64;
-    while ((size_t)rpb * n * (sizeof(V) + 2) > 96 * 1024 && rpb > 1) rpb >>= 1;
-    const size_t lds = (size_t)rpb * n * (sizeof(V) + 2);
-    auto kern = topk_mask_kernel<V>;
-    if (lds > 48 * 1024) {
-        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(kern, dim3((rows + rpb - 1) / rpb), dim3(64), lds, stream, vals, rows, n, k, group, mask, rpb);
+    // one wave per row, 4 rows per workgroup while that fits 32 KiB of LDS (8 bytes per element), else one
+    const int wpb = (size_t)4 * n * 8 <= 32 * 1024 ? 4 : 1;
+    const size_t lds = (size_t)wpb * n * 8;
+    hipLaunchKernelGGL(topk_mask_kernel<V>, dim3((rows + wpb - 1) / wpb), dim3(64 * wpb), lds, stream, vals, rows, n, k, group, mask);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

@@ -298,6 +298,7 @@ EPI_NONE, EPI_RESIDUAL, EPI_GELU, EPI_GELU_BWD = 0, 1, 2, 3
 EPI_COLSUM = 0x100
 EPI_AUX_GRAD = 0x400          # with EPI_GELU / EPI_GELU_BWD (16-bit): aux = gelu'(pre-activation) instead of the pre-activation
 EPI_FORCE_PP = 0x200          # run the 256x256 ping-pong kernel whatever the shape heuristic says (tests)
+EPI_PIPE128 = 0x800           # prefer the 256x128 three-stage kernel (few token rows; gemm_tile_plan below)
 SHORT_TILES = os.environ.get("EDITOR_SHORT_TILES", "1") != "0"      # gemm_tile_rows below (measurement switch)
 
 
@@ -321,6 +322,20 @@ def gemm_tile_rows(m, n, cus=256):
         if best_cost is None or cost < best_cost * 0.99:
             best, best_cost = h, cost
     return best
+
+
+def gemm_tile_plan(m, n, cus=256):
+    """-> (tile rows of the ping-pong kernel, prefer the 256x128 kernel?) for a forward / dgrad product with k-major operands.
+    Rounds of `cus` workgroups x relative tile time: a 208-row tile costs 0.95 of a 256-row one (gemm_tile_rows); a 256x128 tile
+    of the three-stage kernel is half the work at ~0.72 of the ping-pong kernel's rate (measured at M = 49 536: 596 vs 828
+    TFLOP/s).  The 256x128 kernel wins only when the 256-wide tiles leave most CUs idle: the strong-scaling series' B_local = 16
+    (M = 6 192 rows x 768 columns: 90 tiles) - measured there: 1 369 -> 1 421 img/s."""
+    th = gemm_tile_rows(m, n, cus)
+    tiles_pp = -(-m // th) * ((n + 255) // 256)
+    tiles_pipe = -(-m // 256) * ((n + 127) // 128)
+    cost_pp = -(-tiles_pp // cus) * (0.95 if th == 208 else 1.0)
+    cost_pipe = -(-tiles_pipe // cus) * 0.69
+    return th, cost_pipe < 0.97 * cost_pp
 
 
 def gemm_colsum_ok(m, n, k, c_dtype, trans_a, splitk, m_live):
@@ -371,8 +386,10 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
         th = ((int(epilogue) >> 12) & 15) * 16 or 256            # explicit EPI_TILE_ROWS, else the shape heuristic
         if (SHORT_TILES and not trans_a and not trans_b and splitk == 1 and beta == 0.0 and m_live is None and m >= 2048
                 and n >= 512 and n % 8 == 0 and ldc % 8 == 0 and k % 64 == 0 and not (int(epilogue) & 0xF000)):
-            th = gemm_tile_rows(m, n)
-            if th != 256:
+            th, narrow = gemm_tile_plan(m, n)
+            if narrow and colsum is None and not (int(epilogue) & EPI_FORCE_PP):
+                th, epilogue = 256, int(epilogue) | EPI_PIPE128
+            elif th != 256:
                 epilogue = int(epilogue) | EPI_TILE_ROWS(th)
         if colsum is not None:
             # colsum (n) fp32 <- column sums of the rounded output (bias gradient of the layer this gradient feeds):

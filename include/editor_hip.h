@@ -42,6 +42,9 @@ typedef struct ihipStream_t* editor_stream_t;   /* == hipStream_t */
                                    * the dgrad epilogue is one multiply instead of an erfc + exponential per element */
 #define EDITOR_EPI_FORCE_PP 0x200 /* OR-able: run the 256x256 ping-pong kernel whatever the shape heuristic says (N >= 256,
                                    * whole 64-deep K-tiles); tests use it to reach that kernel's edge cases */
+#define EDITOR_EPI_PIPE128 0x800 /* OR-able: prefer the 256x128 three-stage kernel over the 256x256 ping-pong kernel (few token rows:
+                                  * twice the tiles fill more of the 256 CUs; the caller's tile-count heuristic decides,
+                                  * editor_amd.ops.gemm).  Ignored with EDITOR_EPI_COLSUM / _FORCE_PP / _TILE_ROWS. */
 #define EDITOR_EPI_TILE_ROWS(h) ((((h) / 16) & 15) << 12) /* OR-able, h = 208 | 256 (ping-pong kernel, both operands k-major,
                                    * split-K 1, beta 0): rows per output tile.  M = 49 536 token rows x 768 columns are 582 full
                                    * tiles = 2.27 rounds of the 256 CUs; 208-row tiles make it 2.8 rounds of smaller tiles.

@@ -34,6 +34,32 @@ def test_frequency_two_modalities(ops, oracle):
     assert torch.equal(counts.cpu(), ref)
 
 
+def test_frequency_special_values_and_odd_grids(ops, oracle):
+    """The 4x4-pixels-per-lane kernel (round 4) divides by the modality count with the three-instruction correctly-rounded form
+    and keeps the IEEE sequence for what that form does not cover: flat regions (exact zeros in every detail band), saturated
+    pixels, denormal and huge magnitudes, an infinity, and a patch grid whose width is not a multiple of the four patches a wave
+    takes (W = 48: three patches per row) must all count exactly as the oracle does; four modalities and two take other
+    instantiations."""
+    g = torch.Generator().manual_seed(41)
+    b, h, w = 6, 64, 48
+    base = torch.rand(3, b, 3, h, w, generator=g) * 2 - 1
+    base[:, 0, :, :32] = 0.0                                   # flat zero region
+    base[:, 1, :, 16:48, 16:32] = 1.0                          # saturated block (all modalities agree: zero detail bands)
+    base[:, 2] *= 1e-41                                        # denormal pixels -> denormal coefficients
+    base[:, 3] *= 1e30                                         # large magnitudes
+    base[1, 4, 1, 5, 7] = float("inf")                         # an infinity in one patch
+    base[:, 5, :, ::2] = base[:, 5, :, 1::2]                   # row pairs equal: level-1 row-high bands exactly zero
+    r, n_, t_ = base[0].contiguous(), base[1].contiguous(), base[2].contiguous()
+    ref, _ = oracle.frequency_counts(r, n_, t_)
+    got = ops.freq_counts(r.cuda(), n_.cuda(), t_.cuda())
+    assert torch.equal(got.cpu(), ref)
+    ref2, _ = oracle.frequency_counts(r, n_, None)
+    assert torch.equal(ops.freq_counts(r.cuda(), n_.cuda(), None).cpu(), ref2)
+    m4 = (torch.rand(b, 3, h, w, generator=g) * 2 - 1)
+    ref4, _ = oracle.frequency_counts(r[:4], n_[:4], t_[:4], extra=(m4[:4],))
+    assert torch.equal(ops.freq_counts(r[:4].cuda(), n_[:4].cuda(), t_[:4].cuda(), m4[:4].cuda()).cpu(), ref4)
+
+
 @pytest.mark.parametrize("n", [128, 192, 512])
 @pytest.mark.parametrize("k", [1, 2, 10])
 def test_topk_tie_torture(ops, oracle, n, k):
@@ -44,6 +70,21 @@ def test_topk_tie_torture(ops, oracle, n, k):
         ref = oracle.topk_mask(x, k)
         got = ops.topk_mask(x.cuda(), k).cpu().bool()
         assert torch.equal(ref, got)
+
+
+def test_topk_wide_rows_and_nan(ops, oracle):
+    """One wave per row (round 4): rows longer than a wave's first pass (n = 2048: the one-row-per-workgroup form), k > 64
+    (the mask write loops), NaNs (ordered first by torch.topk) and the introselect depth limit (sorted / organ-pipe rows)."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(40, 2048, generator=g)
+    x[::3, ::7] = float("nan")
+    for k in (3, 70, 300):
+        assert torch.equal(oracle.topk_mask(x, k), ops.topk_mask(x.cuda(), k).cpu().bool()), k
+    asc = torch.arange(512, dtype=torch.int32).repeat(8, 1)
+    pipe = torch.cat([torch.arange(256), torch.arange(255, -1, -1)]).int().repeat(8, 1)
+    for xx in (asc, asc.flip(1).contiguous(), pipe, torch.zeros(8, 512, dtype=torch.int32)):
+        for k in (10, 100):
+            assert torch.equal(oracle.topk_mask(xx, k), ops.topk_mask(xx.cuda(), k).cpu().bool())
 
 
 def test_topk_group_or(ops, oracle):
