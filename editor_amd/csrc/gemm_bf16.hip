@@ -1338,6 +1338,32 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
+// The same fold for the up-to-four weight gradients of a grouped launch, as ONE launch (blockIdx.y = problem): 65 -> 17 launches
+// per step; every element is summed in the same fixed order as slab_reduce_kernel does it (bit-identical).
+struct SlabJobs { const float* slabs[kMaxGroup]; float* out[kMaxGroup]; long n4[kMaxGroup]; int nsplit; };
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(SlabJobs j)
+{
+    const int p = blockIdx.y;
+    const long n4 = j.n4[p];
+    const float4* __restrict__ sl = reinterpret_cast<const float4*>(j.slabs[p]);
+    float4* __restrict__ out = reinterpret_cast<float4*>(j.out[p]);
+    const int nsplit = j.nsplit;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = 0; s0 < nsplit; s0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                v[q] = s0 + q < nsplit ? sl[(long)(s0 + q) * n4 + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (s0 + q < nsplit) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
+            }
+        }
+        out[e] = a;
+    }
+}
+
 template <bool F16, bool AK, bool BK_, bool CF, int PBM, int PBN, int STAGES, int NWAVES>
 int launch_pipe_t(GemmB16Args g, hipStream_t stream)
 {
@@ -1579,13 +1605,18 @@ int gemm_wgrad_group(int count, const uint16_t* const* dy, const uint16_t* const
     if (int e = ensure_lds<gemm_bf16_pp_group_kernel<F16>>(LDS)) return e;
     hipLaunchKernelGGL(gemm_bf16_pp_group_kernel<F16>, dim3(tiles * splitk), dim3(512), LDS, stream, ga);
     EDITOR_LAUNCH_CHECK();
+    SlabJobs sj;
+    memset(&sj, 0, sizeof(sj));
+    sj.nsplit = splitk;
+    long n4max = 0;
     for (int i = 0; i < count; ++i) {
-        const long n4 = (long)N[i] * K[i] / 4;
-        long blocks = (n4 + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slab[i], splitk, n4, dw[i], 0.f);
-        EDITOR_LAUNCH_CHECK();
+        sj.slabs[i] = slab[i]; sj.out[i] = dw[i]; sj.n4[i] = (long)N[i] * K[i] / 4;
+        if (sj.n4[i] > n4max) n4max = sj.n4[i];
     }
+    long blocks = (n4max + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, stream, sj);
+    EDITOR_LAUNCH_CHECK();
     return 0;
 }
 

@@ -9,9 +9,13 @@
 //   jidctint.c  jpeg_idct_islow      13-bit constants, two passes, DESCALE rounding, range-limit table
 //   jdsample.c  h2v1 / h2v2 fancy    triangle filter (3/4, 1/4), edge replication at the TRUE (unpadded) plane size
 //   jdcolor.c   ycc_rgb_convert      16-bit fixed-point tables, ONE_HALF folded into the Cb->G term
-// Supported: 8-bit baseline / extended sequential Huffman (SOF0 / SOF1), 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0,
-// interleaved or per-component scans, restart intervals, JFIF (YCbCr) and Adobe transform 0 / 1.  Progressive and
-// arithmetic-coded files return EDITOR_JPEG_UNSUPPORTED (the caller decides; there is no silent fallback here).
+// Supported: 8-bit baseline / extended sequential Huffman (SOF0 / SOF1) and PROGRESSIVE Huffman (SOF2, round 4: spectral
+// selection + successive approximation, jdphuff.c - the scans only refine the same quantised coefficient planes, which is all
+// the device side consumes), 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, interleaved or per-component scans, restart intervals,
+// JFIF (YCbCr) and Adobe transform 0 / 1.  A progressive file whose scans do not deliver every coefficient at full precision
+// (truncated download) is EDITOR_JPEG_CORRUPT: libjpeg would blend neighbouring blocks there (block smoothing), which the
+// device kernels do not restate.  Arithmetic-coded, lossless, 12-bit and 4-component files return EDITOR_JPEG_UNSUPPORTED
+// (the caller decides; there is no silent fallback here).
 #include "common.h"
 #include "../../include/editor_hip.h"
 #include <string.h>
@@ -79,6 +83,7 @@ struct BitReader {
     int peek(int n) { if (nbits < n) fill(); return (int)((acc >> (nbits - n)) & ((1u << n) - 1)); }
     void drop(int n) { nbits -= n; }
     int get(int n) { if (n == 0) return 0; const int v = peek(n); drop(n); return v; }
+    int get1() { const int v = peek(1); drop(1); return v; }
     void restart() { acc = 0; nbits = 0; marker = false; }
 };
 
@@ -109,6 +114,7 @@ struct Jpeg {
     int adobe_transform = -1; bool jfif = false;
     long total_blocks = 0;
     bool covered[3] = {false, false, false};      // components some scan has delivered
+    int8_t coef_al[3][64];                        // progressive: successive-approximation bit each coefficient has reached (-1: none yet)
 };
 
 inline int rd16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
@@ -156,7 +162,9 @@ int decode(const uint8_t* d, long n, Jpeg& j, int16_t* coef, long coef_blocks)
                 o += 17 + cnt;
             }
         } else if (m == 0xC0 || m == 0xC1 || m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-            if (m != 0xC0 && m != 0xC1) { j.unsupported = true; return EDITOR_JPEG_UNSUPPORTED; }   // progressive / lossless / arithmetic
+            if (m != 0xC0 && m != 0xC1 && m != 0xC2) { j.unsupported = true; return EDITOR_JPEG_UNSUPPORTED; }   // lossless / arithmetic / hierarchical
+            j.progressive = m == 0xC2;
+            memset(j.coef_al, -1, sizeof(j.coef_al));
             if (j.have_sof) return EDITOR_JPEG_CORRUPT;                   // one frame per file (a second SOF would re-size the block grid under the scans)
             if (sl < 6 || s[0] != 8) { j.unsupported = true; return EDITOR_JPEG_UNSUPPORTED; }
             j.H = rd16(s + 1); j.W = rd16(s + 3); j.ncomp = s[5];
@@ -209,14 +217,36 @@ int decode(const uint8_t* d, long n, Jpeg& j, int16_t* coef, long coef_blocks)
                 continue;
             }
             if (j.total_blocks > coef_blocks) return EDITOR_JPEG_CORRUPT;  // (the frame this scan belongs to must fit the caller's buffer)
+            // scan parameters (B.2.3): spectral selection Ss..Se, successive approximation Ah / Al - sequential scans carry 0,63,0,0
+            const uint8_t* sp = s + 1 + 2 * ns;
+            const int Ss = sp[0], Se = sp[1], Ah = sp[2] >> 4, Al = sp[2] & 15;
+            const bool prog = j.progressive;
+            if (prog) {
+                // jdphuff.c start_pass_phuff_decoder's validity rules
+                if (Ss > Se || Se > 63 || Al > 13 || (Ah != 0 && Al != Ah - 1)) return EDITOR_JPEG_CORRUPT;
+                if (Ss == 0 ? Se != 0 : ns != 1) return EDITOR_JPEG_CORRUPT;
+            }
             for (int i = 0; i < ns; ++i) {
-                if (!j.dc[j.comp[idx[i]].td].present || !j.ac[j.comp[idx[i]].ta].present || !j.qt_ok[j.comp[idx[i]].tq])
-                    return EDITOR_JPEG_CORRUPT;
-                if (j.covered[idx[i]]) return EDITOR_JPEG_CORRUPT;          // sequential coding: one scan per component
-                j.covered[idx[i]] = true;
+                const Comp& k = j.comp[idx[i]];
+                if (!j.qt_ok[k.tq]) return EDITOR_JPEG_CORRUPT;
+                if (!prog) {
+                    if (!j.dc[k.td].present || !j.ac[k.ta].present) return EDITOR_JPEG_CORRUPT;
+                    if (j.covered[idx[i]]) return EDITOR_JPEG_CORRUPT;      // sequential coding: one scan per component
+                    j.covered[idx[i]] = true;
+                } else {
+                    if (Ss == 0 && Ah == 0 && !j.dc[k.td].present) return EDITOR_JPEG_CORRUPT;
+                    if (Ss > 0 && !j.ac[k.ta].present) return EDITOR_JPEG_CORRUPT;
+                    // a refinement scan refines what a first scan delivered at exactly the bit above; a first scan delivers
+                    // coefficients nobody has delivered yet (libjpeg only warns; such files are not decodable unambiguously)
+                    for (int kk = Ss; kk <= Se; ++kk) {
+                        if (j.coef_al[idx[i]][kk] != (Ah == 0 ? -1 : Ah)) return EDITOR_JPEG_CORRUPT;
+                        j.coef_al[idx[i]][kk] = (int8_t)Al;
+                    }
+                }
             }
             BitReader br{d + pos, d + n};
             int pred[3] = {0, 0, 0};
+            int eobrun = 0;                                               // progressive AC scans: blocks still covered by an end-of-band run
             // MCU geometry of this scan: interleaved -> hs x vs blocks per component per MCU over mcux x mcuy MCUs;
             // a single-component scan -> one block per MCU over the component's own (unpadded) block grid
             int nx = j.mcux, ny = j.mcuy;
@@ -240,6 +270,7 @@ int decode(const uint8_t* d, long n, Jpeg& j, int16_t* coef, long coef_blocks)
                         br.p = q;
                         (void)rst; ++rst;
                         pred[0] = pred[1] = pred[2] = 0;
+                        eobrun = 0;
                         left = j.restart;
                     }
                     for (int i = 0; i < ns; ++i) {
@@ -249,21 +280,90 @@ int decode(const uint8_t* d, long n, Jpeg& j, int16_t* coef, long coef_blocks)
                             for (int bx = 0; bx < bw_; ++bx) {
                                 const int gx = mx * bw_ + bx, gy = my * bh_ + by;
                                 int16_t* blk = coef + (k.off + (long)gy * k.bw + gx) * 64;
-                                memset(blk, 0, 128);
-                                const int sdc = huff_decode(br, j.dc[k.td]);
-                                if (sdc < 0 || sdc > 11) return EDITOR_JPEG_CORRUPT;
-                                const int diff = sdc ? extend(br.get(sdc), sdc) : 0;
-                                pred[idx[i]] += diff;
-                                blk[0] = (int16_t)pred[idx[i]];
-                                for (int kk = 1; kk < 64;) {
-                                    const int rs = huff_decode(br, j.ac[k.ta]);
-                                    if (rs < 0) return EDITOR_JPEG_CORRUPT;
-                                    const int r = rs >> 4, sz = rs & 15;
-                                    if (sz == 0) { if (r == 15) { kk += 16; continue; } break; }
-                                    kk += r;
-                                    if (kk > 63) return EDITOR_JPEG_CORRUPT;
-                                    blk[kZigzag[kk]] = (int16_t)extend(br.get(sz), sz);
-                                    ++kk;
+                                if (!prog) {
+                                    memset(blk, 0, 128);
+                                    const int sdc = huff_decode(br, j.dc[k.td]);
+                                    if (sdc < 0 || sdc > 11) return EDITOR_JPEG_CORRUPT;
+                                    const int diff = sdc ? extend(br.get(sdc), sdc) : 0;
+                                    pred[idx[i]] += diff;
+                                    blk[0] = (int16_t)pred[idx[i]];
+                                    for (int kk = 1; kk < 64;) {
+                                        const int rs = huff_decode(br, j.ac[k.ta]);
+                                        if (rs < 0) return EDITOR_JPEG_CORRUPT;
+                                        const int r = rs >> 4, sz = rs & 15;
+                                        if (sz == 0) { if (r == 15) { kk += 16; continue; } break; }
+                                        kk += r;
+                                        if (kk > 63) return EDITOR_JPEG_CORRUPT;
+                                        blk[kZigzag[kk]] = (int16_t)extend(br.get(sz), sz);
+                                        ++kk;
+                                    }
+                                } else if (Ss == 0) {
+                                    if (Ah == 0) {                        // decode_mcu_DC_first: the DC difference, scaled by 2^Al
+                                        const int sdc = huff_decode(br, j.dc[k.td]);
+                                        if (sdc < 0 || sdc > 11) return EDITOR_JPEG_CORRUPT;
+                                        const int diff = sdc ? extend(br.get(sdc), sdc) : 0;
+                                        pred[idx[i]] += diff;
+                                        blk[0] = (int16_t)(pred[idx[i]] * (1 << Al));
+                                    } else if (br.get1()) {               // decode_mcu_DC_refine: one more bit of every DC value
+                                        blk[0] = (int16_t)(blk[0] | (1 << Al));
+                                    }
+                                } else if (Ah == 0) {                     // decode_mcu_AC_first
+                                    if (eobrun > 0) { --eobrun; continue; }
+                                    for (int kk = Ss; kk <= Se; ++kk) {
+                                        const int rs = huff_decode(br, j.ac[k.ta]);
+                                        if (rs < 0) return EDITOR_JPEG_CORRUPT;
+                                        const int r = rs >> 4, sz = rs & 15;
+                                        if (sz) {
+                                            kk += r;
+                                            if (kk > 63) return EDITOR_JPEG_CORRUPT;
+                                            blk[kZigzag[kk]] = (int16_t)(extend(br.get(sz), sz) * (1 << Al));
+                                        } else if (r == 15) {
+                                            kk += 15;                      // ZRL: sixteen zeros
+                                        } else {                           // EOBr: this block and the next 2^r + bits - 1 end here
+                                            eobrun = (1 << r) - 1;
+                                            if (r) eobrun += br.get(r);
+                                            break;
+                                        }
+                                    }
+                                } else {                                  // decode_mcu_AC_refine
+                                    const int p1 = 1 << Al, m1 = -(1 << Al);
+                                    int kk = Ss;
+                                    if (eobrun == 0) {
+                                        for (; kk <= Se; ++kk) {
+                                            const int rs = huff_decode(br, j.ac[k.ta]);
+                                            if (rs < 0) return EDITOR_JPEG_CORRUPT;
+                                            int r = rs >> 4, sv = rs & 15;
+                                            if (sv) {
+                                                if (sv != 1) return EDITOR_JPEG_CORRUPT;     // (libjpeg warns and goes on with size 1)
+                                                sv = br.get1() ? p1 : m1;
+                                            } else if (r != 15) {
+                                                eobrun = 1 << r;           // EOBr: the run includes this block, whose remaining
+                                                if (r) eobrun += br.get(r);  // non-zero coefficients still get their correction bits
+                                                break;
+                                            }
+                                            // skip r still-zero coefficients, refining every already non-zero one on the way
+                                            do {
+                                                int16_t* c = blk + kZigzag[kk];
+                                                if (*c != 0) {
+                                                    if (br.get1() && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+                                                } else if (--r < 0) {
+                                                    break;
+                                                }
+                                                ++kk;
+                                            } while (kk <= Se);
+                                            if (sv) {
+                                                if (kk > 63) return EDITOR_JPEG_CORRUPT;
+                                                blk[kZigzag[kk]] = (int16_t)sv;
+                                            }
+                                        }
+                                    }
+                                    if (eobrun > 0) {
+                                        for (; kk <= Se; ++kk) {
+                                            int16_t* c = blk + kZigzag[kk];
+                                            if (*c != 0 && br.get1() && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+                                        }
+                                        --eobrun;
+                                    }
                                 }
                             }
                     }
@@ -278,8 +378,11 @@ int decode(const uint8_t* d, long n, Jpeg& j, int16_t* coef, long coef_blocks)
     }
     if (!j.have_sof || !seen_scan) return EDITOR_JPEG_CORRUPT;
     if (coef)                                                             // every component delivered by some scan, or the planes
-        for (int c = 0; c < j.ncomp; ++c)                                 // of the missing ones would be whatever the buffer held
-            if (!j.covered[c]) return EDITOR_JPEG_CORRUPT;
+        for (int c = 0; c < j.ncomp; ++c) {                               // of the missing ones would be whatever the buffer held
+            if (!j.progressive) { if (!j.covered[c]) return EDITOR_JPEG_CORRUPT; continue; }
+            // progressive: every coefficient at full precision (an incomplete file is where libjpeg would smooth blocks)
+            for (int kk = 0; kk < 64; ++kk) if (j.coef_al[c][kk] != 0) return EDITOR_JPEG_CORRUPT;
+        }
     return 0;
 }
 

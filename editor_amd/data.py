@@ -281,7 +281,8 @@ class DeviceJpegDecoder:
         crops = dec([open(p, "rb").read() for p in paths], device)     # uint8 (ncrop, B, H, 256, 3): RGB, NI, TI
         x = DeviceResize(cfg.INPUT.SIZE_TRAIN)(crops[0])               # ... the rest of the transform on the device
 
-    Progressive / arithmetic-coded files raise (EDITOR_JPEG_UNSUPPORTED): there is no silent host fallback."""
+    Baseline, extended-sequential and progressive Huffman files (round 4) are covered; arithmetic-coded / lossless / 12-bit /
+    4-component files raise (EDITOR_JPEG_UNSUPPORTED) and an incomplete progressive file is corrupt: no silent host fallback."""
 
     def __init__(self, crop_w=256, threads=8):
         from concurrent.futures import ThreadPoolExecutor
@@ -297,7 +298,7 @@ class DeviceJpegDecoder:
         rc = self._cd.editor_jpeg_parse(ctypes.c_void_p(buf.ctypes.data), len(data), ctypes.c_void_p(info.ctypes.data))
         if rc:
             raise ValueError("JPEG %s (editor_jpeg_parse rc %d)" % ("uses a coding mode the device decoder does not cover "
-                             "(progressive / arithmetic / 4 components)" if rc == 9002 else "is corrupt", rc))
+                             "(arithmetic / lossless / 12-bit / 4 components)" if rc == 9002 else "is corrupt or incomplete", rc))
         return info
 
     def _entropy(self, data, coef_ptr, blocks, qt_ptr, info):

@@ -358,14 +358,17 @@ int editor_augment_u8(const uint8_t* in, const int* params, int B, int H, int W,
                       const float* stdv, const float* noise, unsigned long long seed, float* out,
                       editor_stream_t stream);
 
-/* ---- baseline-JPEG decode (data/datasets/bases.py:9-41 `Image.open(path).convert('RGB')` + the 256-wide
+/* ---- JPEG decode (data/datasets/bases.py:9-41 `Image.open(path).convert('RGB')` + the 256-wide
  * crops of the stitched tri-modal image) -------------------------------------------------------------------------------
  * Split: the HOST parses the markers and Huffman-decodes the scan(s) into quantised DCT coefficient blocks (the only
  * inherently serial part); the DEVICE does dequantisation + inverse DCT + chroma upsampling + YCbCr -> RGB + the crop
  * split for a whole batch per call.  Integer for integer libjpeg's default decompression path (jidctint.c islow,
  * jdsample.c fancy upsampling, jdcolor.c) - the pixels equal Pillow's bit for bit (tests/golden/f14_decode.npz).
- * Supported: 8-bit baseline / extended-sequential Huffman, 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, restart intervals,
- * interleaved or per-component scans.  Anything else -> EDITOR_JPEG_UNSUPPORTED (no silent fallback).
+ * Supported: 8-bit baseline / extended-sequential AND progressive Huffman (SOF0 / SOF1 / SOF2; the progressive scans refine
+ * the same coefficient planes: tests/golden/f15_decode_progressive.npz), 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, restart
+ * intervals, interleaved or per-component scans.  A progressive file that does not deliver every coefficient at full
+ * precision, a second frame header, an over-subscribed Huffman table, a scan set that misses a component ->
+ * EDITOR_JPEG_CORRUPT.  Arithmetic / lossless / 12-bit / 4-component files -> EDITOR_JPEG_UNSUPPORTED (no silent fallback).
  * info (16 ints, host): {W, H, ncomp, hmax, vmax, mcus_x, mcus_y, ycc_transform, blocks_per_image, tq0, tq1, tq2, ...}. */
 #define EDITOR_JPEG_CORRUPT 9001
 #define EDITOR_JPEG_UNSUPPORTED 9002

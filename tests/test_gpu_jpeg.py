@@ -47,7 +47,31 @@ def test_stitched_batch_crops_and_resize(golden):
         assert np.array_equal(got[b].cpu().numpy(), np.asarray(ref)), n
 
 
-def test_decoder_refuses_progressive(golden):
+def test_progressive_files_on_the_device():
+    """Round 4: progressive files (tests/golden/f15_decode_progressive.npz) go through the same device reconstruction; a batch
+    that MIXES a progressive and a baseline file of the same geometry is one launch group."""
     from editor_amd.data import DeviceJpegDecoder
+    g = np.load(os.path.join(HERE, "golden", "f15_decode_progressive.npz"))
+    dec = DeviceJpegDecoder(crop_w=0)
+    for name in sorted(k[:-4] for k in g.files if k.endswith(".rgb")):
+        out = dec([g[name + ".jpg"].tobytes()], "cuda")
+        assert np.array_equal(out[0, 0].cpu().numpy(), g[name + ".rgb"]), name
+    base = np.load(os.path.join(HERE, "golden", "f14_decode.npz"))
+    crops = DeviceJpegDecoder(crop_w=256)([g["prog_stitched_420_q75.jpg"].tobytes(), base["stitched_420_q75.jpg"].tobytes()], "cuda")
+    assert tuple(crops.shape) == (3, 2, 128, 256, 3)
+    for i in range(3):
+        assert np.array_equal(crops[i, 0].cpu().numpy(), g["prog_stitched_420_q75.rgb"][:, 256 * i:256 * (i + 1)])
+        assert np.array_equal(crops[i, 1].cpu().numpy(), base["stitched_420_q75.rgb"][:, 256 * i:256 * (i + 1)])
+
+
+def test_decoder_refuses_what_it_does_not_cover(golden):
+    from editor_amd.data import DeviceJpegDecoder
+    data = bytearray(golden["tiny_420_q50.jpg"].tobytes())
+    i = data.index(b"\xff\xc0")
+    data[i + 1] = 0xC9                                            # arithmetic-coded sequential: unsupported, never mis-decoded
     with pytest.raises(ValueError):
-        DeviceJpegDecoder()([golden["progressive.jpg"].tobytes()], "cuda")
+        DeviceJpegDecoder()([bytes(data)], "cuda")
+    prog = np.load(os.path.join(HERE, "golden", "f15_decode_progressive.npz"))["prog_444_q92.jpg"].tobytes()
+    cut = prog.index(b"\xff\xda", prog.index(b"\xff\xda") + 2)   # only the first scan survives: incomplete -> corrupt
+    with pytest.raises(ValueError):
+        DeviceJpegDecoder()([prog[:cut] + b"\xff\xd9"], "cuda")

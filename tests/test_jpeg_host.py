@@ -44,9 +44,65 @@ def test_host_decoder_plus_oracle_equal_pillow(golden):
         assert np.array_equal(got, want), (name, int(np.abs(got.astype(int) - want.astype(int)).max()))
 
 
+@pytest.fixture(scope="module")
+def golden_prog():
+    return np.load(os.path.join(HERE, "golden", "f15_decode_progressive.npz"))
+
+
+def test_progressive_files_equal_pillow(golden, golden_prog):
+    """Round 4: SOF2 files (spectral selection + successive approximation; DC / AC first and refinement scans, end-of-band runs,
+    restart intervals) decode to the SAME coefficient planes the sequential path delivers - pixels bit-identical with Pillow,
+    which is what the reference's `Image.open(path).convert('RGB')` returns (data/datasets/bases.py:19)."""
+    from oracle import jpeg_ref
+    names = sorted(k[:-4] for k in golden_prog.files if k.endswith(".rgb"))
+    assert len(names) >= 8
+    for name in names:
+        rc, coef, qt, info = host_decode(golden_prog[name + ".jpg"])
+        assert rc == 0, (name, rc)
+        want = golden_prog[name + ".rgb"]
+        got = jpeg_ref.reconstruct(coef, qt, info)
+        assert np.array_equal(got, want), (name, int(np.abs(got.astype(int) - want.astype(int)).max()))
+    # the round-3 fixture that used to be the "refused" example decodes now (checked against this image's Pillow when present)
+    rc, coef, qt, info = host_decode(golden["progressive.jpg"])
+    assert rc == 0
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    live = np.asarray(PIL.open(io.BytesIO(golden["progressive.jpg"].tobytes())).convert("RGB"))
+    assert np.array_equal(jpeg_ref.reconstruct(coef, qt, info), live)
+
+
+def test_incomplete_progressive_file_is_refused(golden_prog):
+    """A progressive file cut after some scans is where libjpeg smooths blocks from their neighbours' DC values: not restated on the
+    device, so such a file is an error - never a silently different image.  Whole scans removed: CORRUPT; cut inside a scan: the
+    remaining data decodes as zeros (as libjpeg feeds them) and the missing later scans make it CORRUPT as well."""
+    data = bytes(golden_prog["prog_444_q92.jpg"])
+    sos = [i for i in range(len(data) - 1) if data[i] == 0xFF and data[i + 1] == 0xDA]
+    assert len(sos) >= 6                                         # Pillow's default script: ten scans for three components
+    for cut in (sos[1], sos[3], sos[-1], sos[2] + 40):
+        rc, _, _, _ = host_decode(np.frombuffer(data[:cut] + b"\xFF\xD9", dtype=np.uint8))
+        assert rc == 9001, (cut, rc)
+    # scan-parameter rules of jdphuff.c: Ss > Se, a DC scan with Se != 0, an interleaved AC scan, Al != Ah - 1
+    for patch in ((lambda h: (h[0], 70, h[2])), (lambda h: (0, 5, h[2])), (lambda h: (h[0], h[1], 0x31))):
+        bad = bytearray(data)
+        a = sos[1]
+        ns = bad[a + 4]
+        o = a + 5 + 2 * ns
+        bad[o], bad[o + 1], bad[o + 2] = patch((bad[o], bad[o + 1], bad[o + 2]))
+        rc, _, _, _ = host_decode(np.frombuffer(bytes(bad), dtype=np.uint8))
+        assert rc == 9001, rc
+
+
 def test_unsupported_and_corrupt_files_are_refused(golden):
-    rc, _, _, _ = host_decode(golden["progressive.jpg"])
-    assert rc == 9002                                            # EDITOR_JPEG_UNSUPPORTED: never mis-decoded
+    # arithmetic coding (SOF9), lossless (SOF3), hierarchical (SOF5), 12-bit samples: EDITOR_JPEG_UNSUPPORTED, never mis-decoded
+    base = bytearray(bytes(golden["tiny_420_q50.jpg"]))
+    sof = [s_ for s_ in _segments(base) if s_[0] == 0xC0][0]
+    for marker in (0xC9, 0xC3, 0xC5, 0xCA):
+        bad = bytearray(base)
+        bad[sof[1] + 1] = marker
+        assert host_decode(np.frombuffer(bytes(bad), dtype=np.uint8))[0] == 9002, hex(marker)
+    bad = bytearray(base)
+    bad[sof[1] + 4] = 12                                         # sample precision
+    assert host_decode(np.frombuffer(bytes(bad), dtype=np.uint8))[0] == 9002
     rc, _, _, _ = host_decode(np.frombuffer(b"not a jpeg at all", dtype=np.uint8))
     assert rc == 9001
     data = golden["tiny_420_q50.jpg"].copy()
