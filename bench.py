@@ -290,7 +290,7 @@ def mode_accuracy(preset, dtypes, batch=16, seed=31):
 def modes_block(args, cfg, cams, own_value, own_eval=None):
     """{mode: img/s (the same timed loop, in a child process per mode) + accuracy vs the oracle}."""
     import subprocess
-    modes = ["bf16", "f16", "f16x2", "f32"]
+    modes = ["bf16", "f16", "f16x2", "f16x2s", "f32"]
     acc, nb = mode_accuracy(args.preset, modes)
     out = {"accuracy_sample": f"eval forward, B={nb}, {args.preset}, vs the oracle on the host cores; cls4t with the oracle's "
                               "selection teacher-forced, selection free-running (rows = (sample, modality) attention masks)"}
@@ -557,7 +557,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (BASELINE: 128; SYNTH4L default 32)")
     ap.add_argument("--preset", default="RGBNT201")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f16x2", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f16x2", "f16x2s", "f32"],
+                    help="f16x2: split-precision forward (fp32-class on the half matrix cores); f16x2s: the same only where the token "
+                         "selection depends on it (cfg.MODEL.SPLIT_SCOPE = 'selection')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--graph", action="store_true", help="time a hipGraph replay of the captured step in THIS process "
@@ -847,7 +849,7 @@ def main():
                 "traffic_note": None if traffic is None else traffic.get("note"),
                 "kernel": "16-bit GEMM family: gemm_bf16_pp_kernel (256x256x64 ping-pong; fwd, dgrad, and wgrad as one round of "
                           "split-K workgroups + slab reduction), v_mfma_f32_16x16x32_" + ("bf16" if args.dtype == "bf16" else "f16") +
-                          ("; forward products as split-precision half pairs (3 MFMA passes per algorithmic FLOP)" if args.dtype == "f16x2" else ""),
+                          ("; forward products as split-precision half pairs (3 MFMA passes per algorithmic FLOP)" if args.dtype.startswith("f16x2") else ""),
                 "launches_per_step": launches, "gemm_ms_per_step": round(ms, 3),
                 "alg_tflop_per_step": round(flops / 1e12, 2),
                 "alg_bytes_per_step": None if traffic is None else traffic.get("gemm_alg_bytes_per_step"),

@@ -34,7 +34,9 @@ def make_cfg(size_train=(256, 128), al=1, transformer_type="vit_base_patch16_224
         ATT_DROP_RATE=0.0, ID_LOSS_TYPE="softmax", HEAD_KEEP=head_keep,
         FREQUENCY_KEEP=frequency_keep, AL=al, DIST_TRAIN=False, NAME="EDITOR")
     # extension knobs of this build (absent from the reference cfg => defaults)
-    model.COMPUTE_DTYPE = extra.pop("compute_dtype", "bf16")   # 'bf16' | 'f32'
+    model.COMPUTE_DTYPE = extra.pop("compute_dtype", "bf16")   # 'bf16' | 'f16' | 'f16x2' | 'f32'
+    if model.COMPUTE_DTYPE == "f16x2s":                          # shorthand: split-precision forward, selection scope only
+        model.COMPUTE_DTYPE, model.SPLIT_SCOPE = "f16x2", "selection"
     model.HMA_COMPACT = extra.pop("hma_compact", True)
     model.ACT_LIGHT = extra.pop("act_light", False)              # blocks save 24 B instead of 36 B per token-row-element
     model.ROLLOUT_PROBS = extra.pop("rollout_probs", False)      # bf16 mode: keep the materialised (L,3B,h,T,T) probabilities

@@ -675,8 +675,10 @@ namespace {
 int layernorm_bwd_impl(const void* dy, int dy_bf16, float dy_scale, const float* x, const float* gamma, const float* mean,
     const float* rstd, long M, int D, const uint8_t* rowmask, int mask_period, const float* dx_in, float* dx_out,
     float* dgamma, float* dbeta, float* workspace, int ws_rows, const int* m_live, void* cast_out, const float* cast_rowscale,
-    float cast_scale, float* cast_colsum, float cast_colsum_scale, hipStream_t stream)
+    float cast_scale, float* cast_colsum, float cast_colsum_scale, hipStream_t stream, int* nparts = nullptr)
 {
+    // nparts != NULL: the "_parts" form - the partial rows stay in the workspace ([P][2][D] at its start, the cast output's column
+    // sums [P][D] behind ws_rows*2*D floats), *nparts = P, and the caller folds them (editor_reduce_rows_multi)
     if (D % 4 || D > 1024 || M <= 0 || ws_rows < 1) return (int)hipErrorInvalidValue;
     if (cast_out && (dy_bf16 == 0 || m_live || rowmask || D % 256)) return (int)hipErrorInvalidValue;    // dense 16-bit rows only
     long blocks = (M + 3) / 4;
@@ -709,6 +711,11 @@ int layernorm_bwd_impl(const void* dy, int dy_bf16, float dy_scale, const float*
     }
 #undef LN_BWD_LAUNCH
     EDITOR_LAUNCH_CHECK();
+    if (nparts) {
+        if (dgamma && dbeta != dgamma + D) return (int)hipErrorInvalidValue;
+        *nparts = (int)blocks;
+        return 0;
+    }
     if (cast_partials) {
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((D + 63) / 64), dim3(1024), 0, stream, cast_partials, (int)blocks, (long)D,
                            cast_colsum, 0, cast_colsum_scale);
@@ -744,8 +751,9 @@ extern "C" int editor_layernorm_bwd_cast(const void* dy, int dy_bf16, float dy_s
                               ws_rows, nullptr, cast_out, cast_rowscale, cast_scale, cast_colsum, cast_colsum_scale, stream);
 }
 
-extern "C" int editor_colsum(const void* dy, int dy_bf16, long M, int N, long ld, float* out, float* workspace,
-                             int ws_rows, float scale, hipStream_t stream)
+namespace {
+int colsum_impl(const void* dy, int dy_bf16, long M, int N, long ld, float* out, float* workspace, int ws_rows, float scale,
+                hipStream_t stream, int* nparts)
 {
     if (N % 4 || ws_rows < 1) return (int)hipErrorInvalidValue;
     int rows_per = 64;                                   // 16 rows per wave-group pass x 4
@@ -754,7 +762,95 @@ extern "C" int editor_colsum(const void* dy, int dy_bf16, long M, int N, long ld
     DISPATCH_T(dy_bf16, hipLaunchKernelGGL(colsum_kernel<TT>, dim3((N / 4 + 63) / 64, gy), dim3(256), 0, stream,
                (const TT*)dy, M, N, ld, rows_per, workspace));
     EDITOR_LAUNCH_CHECK();
+    if (nparts) { *nparts = gy; return 0; }
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 63) / 64), dim3(1024), 0, stream, workspace, gy, (long)N, out, 0, scale);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+// Up to eight fixed-order folds out_j[c] = scale_j * sum_p partials_j[p][c] as ONE launch (blockIdx.y = job): a transformer
+// block's backward leaves six sets of partial rows (two LayerNorms' dgamma / dbeta, three bias gradients, one column sum from a
+// dgrad epilogue) whose totals nothing needs before the block ends - one launch per block instead of six (round 4: 95 -> 31
+// reduce launches per step).  Same summation order per element as reduce_rows_kernel: bit-identical.
+constexpr int kMaxReduce = 8;
+struct ReduceJobs { const float* partials[kMaxReduce]; float* out[kMaxReduce]; long ncol[kMaxReduce]; int P[kMaxReduce]; float scale[kMaxReduce]; };
+
+__global__ __launch_bounds__(1024) void reduce_rows_multi_kernel(ReduceJobs j)
+{
+    __shared__ float red[16][64];
+    const int job = blockIdx.y;
+    const long ncol = j.ncol[job];
+    if ((long)blockIdx.x * 64 >= ncol) return;                          // (whole block: before the barrier)
+    const float* __restrict__ partials = j.partials[job];
+    const int P = j.P[job];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const long c = (long)blockIdx.x * 64 + lane;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < ncol) {
+        int p = rg;
+        for (; p + 112 < P; p += 128) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += partials[(long)(p + 16 * u) * ncol + c];
+        }
+        for (; p < P; p += 16) s[0] += partials[(long)p * ncol + c];
+    }
+    red[rg][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (rg == 0 && c < ncol) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][lane];
+        j.out[job][c] = t * j.scale[job];
+    }
+}
+}  // namespace
+
+extern "C" int editor_colsum(const void* dy, int dy_bf16, long M, int N, long ld, float* out, float* workspace,
+                             int ws_rows, float scale, hipStream_t stream)
+{
+    return colsum_impl(dy, dy_bf16, M, N, ld, out, workspace, ws_rows, scale, stream, nullptr);
+}
+
+extern "C" int editor_colsum_parts(const void* dy, int dy_bf16, long M, int N, long ld, float* workspace, int ws_rows, int* nparts,
+                                   hipStream_t stream)
+{
+    if (!nparts) return (int)hipErrorInvalidValue;
+    return colsum_impl(dy, dy_bf16, M, N, ld, nullptr, workspace, ws_rows, 1.f, stream, nparts);
+}
+
+extern "C" int editor_layernorm_bwd_parts(const void* dy, int dy_bf16, float dy_scale, const float* x, const float* gamma,
+    const float* mean, const float* rstd, long M, int D, const uint8_t* rowmask, int mask_period, const float* dx_in, float* dx_out,
+    float* workspace, int ws_rows, const int* m_live, int* nparts, hipStream_t stream)
+{
+    if (!nparts || !workspace) return (int)hipErrorInvalidValue;
+    // (dgamma / dbeta: any non-NULL pair tells the kernel to write its partial rows; the totals are the caller's to fold)
+    return layernorm_bwd_impl(dy, dy_bf16, dy_scale, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out, workspace,
+                              workspace + D, workspace, ws_rows, m_live, nullptr, nullptr, 1.f, nullptr, 1.f, stream, nparts);
+}
+
+extern "C" int editor_layernorm_bwd_cast_parts(const void* dy, int dy_bf16, float dy_scale, const float* x, const float* gamma,
+    const float* mean, const float* rstd, long M, int D, const float* dx_in, float* dx_out, float* workspace, int ws_rows,
+    void* cast_out, const float* cast_rowscale, float cast_scale, int want_colsum, int* nparts, hipStream_t stream)
+{
+    if (!cast_out || !nparts || !workspace) return (int)hipErrorInvalidValue;
+    return layernorm_bwd_impl(dy, dy_bf16, dy_scale, x, gamma, mean, rstd, M, D, nullptr, 0, dx_in, dx_out, workspace, workspace + D,
+                              workspace, ws_rows, nullptr, cast_out, cast_rowscale, cast_scale, want_colsum ? workspace : nullptr,
+                              1.f, stream, nparts);
+}
+
+extern "C" int editor_reduce_rows_multi(int count, const float* const* partials, const int* P, const long* ncol, float* const* out,
+                                        const float* scale, hipStream_t stream)
+{
+    if (count < 1 || count > kMaxReduce || !partials || !P || !ncol || !out || !scale) return (int)hipErrorInvalidValue;
+    ReduceJobs j;
+    memset(&j, 0, sizeof(j));
+    long maxcol = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!partials[i] || !out[i] || P[i] < 1 || ncol[i] < 1) return (int)hipErrorInvalidValue;
+        j.partials[i] = partials[i]; j.out[i] = out[i]; j.ncol[i] = ncol[i]; j.P[i] = P[i]; j.scale[i] = scale[i];
+        if (ncol[i] > maxcol) maxcol = ncol[i];
+    }
+    hipLaunchKernelGGL(reduce_rows_multi_kernel, dim3((unsigned)((maxcol + 63) / 64), (unsigned)count), dim3(1024), 0, stream, j);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }
@@ -820,6 +916,19 @@ extern "C" int editor_cast_rows(const float* in, const float* rowscale, long M, 
     DISPATCH_T(out_bf16, hipLaunchKernelGGL(cast_rows_kernel<TT>, dim3(grid_for(M * (D / 4))), dim3(256), 0, stream,
                in, rowscale, M, D, (TT*)out, m_live, scale));
     EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_cast_rows_colsum_parts(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16,
+                                             float* workspace, int ws_rows, float scale, int* nparts, hipStream_t stream)
+{
+    if ((D & 255) || D > 256 * kMaxV || ws_rows < 1 || !nparts || !workspace) return (int)hipErrorInvalidValue;
+    long blocks = (M + 3) / 4;
+    if (blocks > ws_rows) blocks = ws_rows;
+    DISPATCH_T(out_bf16, hipLaunchKernelGGL(cast_rows_colsum_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, stream,
+               in, rowscale, M, D, (TT*)out, workspace, scale));
+    EDITOR_LAUNCH_CHECK();
+    *nparts = (int)blocks;
     return 0;
 }
 

@@ -91,6 +91,10 @@ def act_weight_t(w, dtype):
 ACT_LIGHT = False
 
 F16X2 = "f16x2"      # act_dtype marker of the split-precision forward: half pairs in the forward, plain f16 in the backward
+F16X2H = "f16x2h"    # ... of a block whose attention MAP must be fp32-class but whose output need not be: LayerNorm-1, the qkv
+                     # product and the attention core on half pairs, the projection and the MLP as the plain f16 mode computes
+                     # them (cfg.MODEL.SPLIT_SCOPE = 'selection': the LAST backbone block - nothing downstream of its attention
+                     # map feeds the token selection, SFTS.py:145-164)
 
 
 def act_weight_split(w):
@@ -285,12 +289,14 @@ class TransformerBlockFn(torch.autograd.Function):
         hd = d // heads
         x2d = x.reshape(m, d)
         amask = None if cu is not None else mask           # packed sequences hold only live tokens
-        if act_dtype == F16X2:
+        head_done = split_all = False
+        if act_dtype in (F16X2, F16X2H):
             # split-precision forward: every product on half PAIRS (three MFMA passes, fp32-class), the exact softmax / GELU
             # on unrounded values; what is saved for the (16-bit) backward are the hi halves - plain f16 tensors
+            head_only = act_dtype == F16X2H
             act_dtype = torch.float16
             inv_ws = 1.0 / ops.SPLIT_WSCALE
-            wq, wp, w1, w2 = (act_weight_split(w) for w in (qkvw, projw, fc1w, fc2w))
+            wq = act_weight_split(qkvw)
             hidden = fc1w.shape[0]
             h1, h1l, mean1, rstd1 = ops.layernorm_fwd_split(x2d, n1w, n1b, eps, mask, m_live)
             qkv = torch.empty(m, 3 * d, dtype=act_dtype, device=x.device)
@@ -301,6 +307,11 @@ class TransformerBlockFn(torch.autograd.Function):
                                                             None if isinstance(probs_out, list) else probs_out, cu=cu,
                                                             scale=qk_scale)
             del qkvl
+            head_done, split_all = head_only, not head_only
+        if head_done:
+            del aol                          # F16X2H: the projection and the MLP below, on the hi halves, as the f16 mode
+        if split_all:
+            wp, w1, w2 = (act_weight_split(w) for w in (projw, fc1w, fc2w))
             x1 = torch.empty_like(x2d)
             ops.gemm_split((ao, aol), wp, x1, None, m, d, d, alpha=inv_ws, bias=projb, rowscale=rowscale_attn,
                            epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)
@@ -323,14 +334,16 @@ class TransformerBlockFn(torch.autograd.Function):
             ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None,
                         tuple(x.shape), qk_scale, sink)
             return x2.view(x.shape)
-        wq, wp, w1, w2 = (act_weight(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w))
-        h1, mean1, rstd1 = ops.layernorm_fwd(x2d, n1w, n1b, eps, act_dtype, mask, 0, m_live=m_live)
-        qkv = _linear_fwd(h1, wq, qkvb, act_dtype, m_live)
-        if isinstance(probs_out, list):            # bf16 backbone: no probability tensor; the rollout recomputes it
-            ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, None, cu=cu, scale=qk_scale)
-            probs_out.append((qkv, attn_saved))
-        else:
-            ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, probs_out, cu=cu, scale=qk_scale)
+        wp, w1, w2 = (act_weight(w, act_dtype) for w in (projw, fc1w, fc2w))
+        if not head_done:
+            wq = act_weight(qkvw, act_dtype)
+            h1, mean1, rstd1 = ops.layernorm_fwd(x2d, n1w, n1b, eps, act_dtype, mask, 0, m_live=m_live)
+            qkv = _linear_fwd(h1, wq, qkvb, act_dtype, m_live)
+            if isinstance(probs_out, list):            # bf16 backbone: no probability tensor; the rollout recomputes it
+                ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, None, cu=cu, scale=qk_scale)
+                probs_out.append((qkv, attn_saved))
+            else:
+                ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, probs_out, cu=cu, scale=qk_scale)
         x1 = torch.empty_like(x2d)                  # x1 = x + rs * (ao Wp^T + b): residual add in the GEMM epilogue
         ops.gemm(ao, wp, x1, m, d, d, d, d, d, 0, 0, bias=projb, rowscale=rowscale_attn,
                  epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)

@@ -284,6 +284,17 @@ class EDITOR(nn.Module):
         # cores, fp32-class: token selection as the f32 parity mode, at ~2/3 of the f16 mode's speed); the backward is f16's
         self.split_fwd = getattr(cfg.MODEL, "COMPUTE_DTYPE", "bf16") == "f16x2"
         self.fn_dtype = fn.F16X2 if self.split_fwd else self.act_dtype       # what the autograd nodes are told
+        # cfg.MODEL.SPLIT_SCOPE (f16x2 only): 'all' = every forward product on half pairs (features fp32-class, 9e-7);
+        # 'selection' = only what the token selection depends on - backbone blocks 0 .. L-2 whole, of the last block LayerNorm-1,
+        # the qkv product and the attention core (its MAP enters the rollout, SFTS.py:145-153; its output does not) - and the
+        # rest (last block's projection + MLP, the whole HMA head) as the f16 mode computes it: selection still bit-identical
+        # to the reference, features within the north star's 1e-3 like the f16 mode's, ~3.5 ms per step cheaper
+        scope = str(getattr(cfg.MODEL, "SPLIT_SCOPE", "all"))
+        if scope not in ("all", "selection"):
+            raise ValueError("cfg.MODEL.SPLIT_SCOPE must be 'all' or 'selection'")
+        self.split_selection_only = self.split_fwd and scope == "selection"
+        self.fn_dtype_last = fn.F16X2H if self.split_selection_only else self.fn_dtype     # last backbone block
+        self.fn_dtype_hma = self.act_dtype if self.split_selection_only else self.fn_dtype  # HMA head
         base = self.BACKBONE.base
         # the fused 16-bit attention kernels are written for 64-wide heads (ViT-B/L, DeiT-B).  Other widths (ViT-small's 96,
         # the 32-wide HMA heads of DeiT-small - factory entries no shipped config uses) keep their 16-bit GEMMs and run the
@@ -380,7 +391,8 @@ class EDITOR(nn.Module):
             if scales is not None and base.drop_rates[i] > 0.0:
                 rs_a, rs_m = scales[i, 0], scales[i, 1]
             x = fn.TransformerBlockFn.apply(x, *_block_args(blk.norm1, blk.attn, blk.norm2, blk.mlp), None,
-                                            probs if recompute else probs[i], base.heads, 1e-6, self.fn_dtype, rs_a, rs_m,
+                                            probs if recompute else probs[i], base.heads, 1e-6,
+                                            self.fn_dtype_last if i == len(base.blocks) - 1 else self.fn_dtype, rs_a, rs_m,
                                             None, None, None, base.qk_scale, self._sink("backbone.%d" % i))
         x = fn.LayerNormFn.apply(x, base.norm.weight, base.norm.bias, 1e-6, None)
         return x, probs
@@ -414,7 +426,7 @@ class EDITOR(nn.Module):
             args = _block_args(getattr(fb, "norm" + tag), getattr(fb, "attn" + tag), getattr(fb, "norm" + tag + "_"),
                                getattr(fb, "mlp" + tag))
             mods.append(fn.TransformerBlockFn.apply(feats_mod[i], *args, mask, None, self.hma_heads, 1e-5,
-                                                    self.fn_dtype, None, None, None, None, None, None,
+                                                    self.fn_dtype_hma, None, None, None, None, None, None,
                                                     self._sink("hma." + tag)))
         loss_ocfr = None
         if self.training:
@@ -422,7 +434,7 @@ class EDITOR(nn.Module):
         x = torch.cat(mods, dim=1)
         mask3 = mask.repeat(1, nmod).contiguous()
         x = fn.TransformerBlockFn.apply(x, *_block_args(fb.norm1, fb.attn1, fb.norm2, fb.mlp), mask3, None,
-                                        self.hma_heads, 1e-5, self.fn_dtype, None, None, None, None, None, None,
+                                        self.hma_heads, 1e-5, self.fn_dtype_hma, None, None, None, None, None, None,
                                         self._sink("hma.joint"))
         x = fn.LayerNormFn.apply(x, fb.out_norm.weight, fb.out_norm.bias, 1e-5, mask3.view(-1))
         return x, loss_ocfr
@@ -440,7 +452,7 @@ class EDITOR(nn.Module):
             args = _block_args(getattr(fb, "norm" + tag), getattr(fb, "attn" + tag), getattr(fb, "norm" + tag + "_"),
                                getattr(fb, "mlp" + tag))
             mods.append(fn.TransformerBlockFn.apply(xa_mod[i], *args, plan.mask_a, None,
-                                                    self.hma_heads, 1e-5, self.fn_dtype, None, None, plan.cu, t,
+                                                    self.hma_heads, 1e-5, self.fn_dtype_hma, None, None, plan.cu, t,
                                                     plan.live_a, None, self._sink("hma." + tag)))
         xa = torch.cat(mods, dim=0)
         loss_ocfr = None
@@ -450,7 +462,7 @@ class EDITOR(nn.Module):
         else:
             xb = fn.GatherRowsFn.apply(xa, plan.map_b, plan.live_a, nmod, plan.mb)
         xb = fn.TransformerBlockFn.apply(xb, *_block_args(fb.norm1, fb.attn1, fb.norm2, fb.mlp), plan.mask_b, None,
-                                         self.hma_heads, 1e-5, self.fn_dtype, None, None, plan.cu3, nmod * t, plan.live_b,
+                                         self.hma_heads, 1e-5, self.fn_dtype_hma, None, None, plan.cu3, nmod * t, plan.live_b,
                                          None, self._sink("hma.joint"))
         xb = fn.LayerNormFn.apply(xb, fb.out_norm.weight, fb.out_norm.bias, 1e-5, plan.mask_b, plan.live_b)
         pooled, num = fn.PoolPackedFn.apply(xb, plan.cu, b, nmod)

@@ -106,6 +106,27 @@ int editor_layernorm_bwd_cast(const void* dy, int dy_bf16, float dy_scale, const
                               float* dgamma, float* dbeta, float* workspace, int ws_rows, void* cast_out,
                               const float* cast_rowscale, float cast_scale, float* cast_colsum, float cast_colsum_scale,
                               editor_stream_t stream);
+/* "_parts" forms (round 4): the same kernels WITHOUT their second-stage fold - the partial rows stay in the caller's workspace
+ * and *nparts (host) receives their count P; the caller folds several such sets with ONE editor_reduce_rows_multi launch (a
+ * transformer block's backward: six sets, whose totals nothing needs before the block ends).  Layouts: layernorm: [P][2][D]
+ * (dgamma | dbeta rows) at workspace, and - cast form with want_colsum - the cast output's column sums [P][D] at
+ * workspace + ws_rows*2*D; colsum / cast_rows_colsum: [P][N] / [P][D] at workspace. */
+int editor_layernorm_bwd_parts(const void* dy, int dy_bf16, float dy_scale, const float* x, const float* gamma,
+                               const float* mean, const float* rstd, long M, int D, const uint8_t* rowmask, int mask_period,
+                               const float* dx_in, float* dx_out, float* workspace, int ws_rows, const int* m_live,
+                               int* nparts, editor_stream_t stream);
+int editor_layernorm_bwd_cast_parts(const void* dy, int dy_bf16, float dy_scale, const float* x, const float* gamma,
+                                    const float* mean, const float* rstd, long M, int D, const float* dx_in, float* dx_out,
+                                    float* workspace, int ws_rows, void* cast_out, const float* cast_rowscale,
+                                    float cast_scale, int want_colsum, int* nparts, editor_stream_t stream);
+int editor_colsum_parts(const void* dy, int dy_bf16, long M, int N, long ld, float* workspace, int ws_rows, int* nparts,
+                        editor_stream_t stream);
+int editor_cast_rows_colsum_parts(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16,
+                                  float* workspace, int ws_rows, float scale, int* nparts, editor_stream_t stream);
+/* count <= 8 folds out[j][c] = scale[j] * sum_{p < P[j]} partials[j][p * ncol[j] + c] in one launch; the five arrays are HOST
+ * arrays of `count` entries (device pointers inside).  Same fixed summation order as editor_reduce_rows. */
+int editor_reduce_rows_multi(int count, const float* const* partials, const int* P, const long* ncol, float* const* out,
+                             const float* scale, editor_stream_t stream);
 /* out[n] = scale * sum_m dy[m,n]  (bias gradients of every nn.Linear).  workspace: ws_rows*N floats. */
 int editor_colsum(const void* dy, int dy_bf16, long M, int N, long ld, float* out, float* workspace, int ws_rows,
                   float scale, editor_stream_t stream);
