@@ -8,6 +8,7 @@
 //   column sums (bias grads), partial-row reductions, dtype casts
 #include "common.h"
 #include "../../include/editor_hip.h"
+#include <string.h>
 
 namespace {
 

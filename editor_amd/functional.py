@@ -184,8 +184,11 @@ GROUP_WGRAD = os.environ.get("EDITOR_GROUP_WGRAD", "1") != "0"
 WGRAD_DEFER_JOIN = os.environ.get("EDITOR_WGRAD_DEFER", "1") != "0"       # measurement switch: 0 = join at the end of each block
 
 
+DEFER_REDUCE = os.environ.get("EDITOR_DEFER_REDUCE", "1") != "0"     # measurement switch: ops.ReduceQueue in the block backward
+
+
 def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None, gs=1.0, dw_out=None,
-                db_out=None, dxcs_out=None, w_t=None, defer=None, aux_is_grad=True):
+                db_out=None, dxcs_out=None, w_t=None, defer=None, aux_is_grad=True, rq=None):
     """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy) (or the
     caller's, when the kernel that produced dy summed its columns on the way).  dx_colsum: also return colsum(dx) - the
     bias gradient of the layer BELOW - from the dgrad's own epilogue when it can deliver it (else None).
@@ -204,11 +207,11 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, 
     # B = W stored (Kred=n, Nout=k): row-k operand (trans_b = 1); or its k-major copy W^T (Nout=k, Kred=n): trans_b = 0
     wb, ldb, tb = (w_t, n, 0) if w_t is not None else (w_act, k, 1)
     if gelu_pre is None:
-        ops.gemm(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, m_live=m_live, colsum=dxcs, colsum_scale=inv, tag="dgrad")
+        ops.gemm(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, m_live=m_live, colsum=dxcs, colsum_scale=inv, tag="dgrad", rq=rq)
     else:
         ag = ops.EPI_AUX_GRAD if (dy.dtype in ops.HALF_DTYPES and aux_is_grad) else 0   # 16-bit: gelu_pre holds gelu'(pre-activation)
         ops.gemm(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, epilogue=ops.EPI_GELU_BWD | ag, aux=gelu_pre, m_live=m_live,
-                 colsum=dxcs, colsum_scale=inv, tag="dgrad")
+                 colsum=dxcs, colsum_scale=inv, tag="dgrad", rq=rq)
     dw = dw_out if dw_out is not None else torch.empty(n, k, dtype=torch.float32, device=dy.device)
     if need_bias and db is None:
         db = db_out if db_out is not None else torch.empty(n, dtype=torch.float32, device=dy.device)
@@ -220,7 +223,7 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, 
         # the weight gradient joins the block's grouped launch (issued by the caller once the last dy exists)
         defer.append((dy, x2d, dw))
         if need_colsum:
-            ops.colsum(dy, out=db, scale=inv)
+            ops.colsum(dy, out=db, scale=inv, rq=rq)
     elif use_side:
         side = _side_stream(dy.device)
         side.wait_event(dy_ready)                    # dy is complete; the dgrad above runs concurrently
@@ -393,15 +396,18 @@ class TransformerBlockFn(torch.autograd.Function):
         jobs = [] if (GROUP_WGRAD and act_dtype in ops.HALF_DTYPES and m >= 2048 and m % 64 == 0 and d % 256 == 0
                       and hidden % 256 == 0) else None
         deferred = jobs is not None and sink is not None and WGRAD_SIDE_STREAM and WGRAD_DEFER_JOIN
+        # the block's six second-stage reductions (LayerNorm dgamma / dbeta x2, bias gradients, the fc2 dgrad's column sums) as
+        # ONE launch at the end (ops.ReduceQueue); only with the grouped weight gradients, where every producer runs on this stream
+        rq = ops.ReduceQueue(dx2.device) if (DEFER_REDUCE and jobs is not None) else None
         # ---- MLP branch:  x2 = x1 + rs * fc2(gelu(fc1(LN2(x1))))
-        dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2, gs, cs_out=sv[11])
+        dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2, gs, cs_out=sv[11], rq=rq)
         da, dw2, db2, da_cs = _linear_bwd(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live, db=dbias,
                                           dx_colsum=hb_fc1, gs=gs, dw_out=sv[10], db_out=sv[11],
-                                          dxcs_out=sv[9], w_t=w2t, defer=jobs, aux_is_grad=light is None)   # da = (dy W2) * gelu'(a)
+                                          dxcs_out=sv[9], w_t=w2t, defer=jobs, aux_is_grad=light is None, rq=rq)   # da = (dy W2) * gelu'(a)
         if light is not None:
             h2 = ops.layernorm_fwd(x1, n2w, light[1], light[2], act_dtype, mask, 0, want_stats=False, m_live=m_live)[0]
         dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs, gs=gs, dw_out=sv[8], db_out=sv[9], w_t=w1t,
-                                    defer=jobs)
+                                    defer=jobs, rq=rq)
         fuse_cast = (FUSE_LN_CAST and m_live is None and mask is None and act_dtype in ops.HALF_DTYPES
                      and d % 256 == 0 and d <= 1024)
         if fuse_cast:
@@ -409,19 +415,19 @@ class TransformerBlockFn(torch.autograd.Function):
             # gradient) that the attention branch's backward starts from: no second pass over dx1
             dx1, dn2w, dn2b, dy, dbias = ops.layernorm_bwd_cast(
                 dh2, x1, n2w, mean2, rstd2, dx2, rs_attn, gs, dy_scale=1.0 / gs,
-                dgb_out=sink.ln_pair(6) if sink is not None else None, want_colsum=hb_proj, cs_out=sv[5])
+                dgb_out=sink.ln_pair(6) if sink is not None else None, want_colsum=hb_proj, cs_out=sv[5], rq=rq)
         else:
             dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w, mean2, rstd2, mask, 0, dx_in=dx2, m_live=m_live,
-                                                dy_scale=1.0 / gs, dgb_out=sink.ln_pair(6) if sink is not None else None)
+                                                dy_scale=1.0 / gs, dgb_out=sink.ln_pair(6) if sink is not None else None, rq=rq)
             # ---- attention branch:  x1 = x + rs * proj(attn(qkv(LN1(x))))
-            dy, dbias = _scaled_cast_colsum(dx1, rs_attn, act_dtype, m_live, hb_proj, gs, cs_out=sv[5])
+            dy, dbias = _scaled_cast_colsum(dx1, rs_attn, act_dtype, m_live, hb_proj, gs, cs_out=sv[5], rq=rq)
         dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live, db=dbias, gs=gs, dw_out=sv[4], db_out=sv[5], w_t=wpt,
-                                    defer=jobs)
+                                    defer=jobs, rq=rq)
         dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, amask, attn_saved, ao, cu=cu, scale=qk_scale)
         if light is not None:
             h1 = ops.layernorm_fwd(x2d, n1w, light[0], light[2], act_dtype, mask, 0, want_stats=False, m_live=m_live)[0]
         dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live, gs=gs, dw_out=sv[2], db_out=sv[3], w_t=wqt,
-                                    defer=jobs)
+                                    defer=jobs, rq=rq)
         if jobs:
             # every dy exists: the block's four weight gradients in one launch.  Side stream (joined one block later)
             # unless a gradient sink needs them at the end of THIS block
@@ -438,7 +444,9 @@ class TransformerBlockFn(torch.autograd.Function):
             else:
                 ops.gemm_wgrad_group(jobs, m, 1.0 / gs, m_live)
         dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1, m_live=m_live,
-                                           dy_scale=1.0 / gs, dgb_out=sink.ln_pair(0) if sink is not None else None)
+                                           dy_scale=1.0 / gs, dgb_out=sink.ln_pair(0) if sink is not None else None, rq=rq)
+        if rq is not None:
+            rq.flush()                               # the block's partial rows -> dgamma / dbeta / bias gradients, one launch
         if not deferred:
             join_side_stream(dx.device)              # the four weight gradients (side stream) are complete
         grads = (dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2)
@@ -450,11 +458,11 @@ class TransformerBlockFn(torch.autograd.Function):
         return (dx.view(xshape),) + grads + (None,) * 13
 
 
-def _scaled_cast_colsum(dx, rowscale, dtype, m_live, want_colsum, gs=1.0, cs_out=None):
+def _scaled_cast_colsum(dx, rowscale, dtype, m_live, want_colsum, gs=1.0, cs_out=None, rq=None):
     """_scaled_cast, plus the (unscaled) column sums of the result when the consumer has a bias (dense 16-bit rows only)."""
     if (want_colsum and m_live is None and dtype in ops.HALF_DTYPES and dx.dtype == torch.float32
             and dx.shape[1] % 256 == 0 and dx.shape[1] <= 1024):
-        return ops.cast_rows_colsum(dx, rowscale, dtype, gs, cs_out)
+        return ops.cast_rows_colsum(dx, rowscale, dtype, gs, cs_out, rq=rq)
     return _scaled_cast(dx, rowscale, dtype, m_live, gs), None
 
 
