@@ -690,15 +690,19 @@ class GatherRowsFn(torch.autograd.Function):
     layouts of the compacted HMA head.  Every source row is gathered at most once, so backward is a plain scatter."""
 
     @staticmethod
-    def forward(ctx, x2d, src, live=None, live_mul=1, live_stride=0):
+    def forward(ctx, x2d, src, live=None, live_mul=1, live_stride=0, bwd_fill="all"):
+        # bwd_fill = "none": the gradient's rows that no index names are left UNWRITTEN instead of zero-filled (152 MB of memset,
+        # 103 us) - only where the one consumer of that gradient provably reads the gathered rows alone (the layout-A gather of
+        # the compacted HMA head: its gradient goes straight into SFTSApplyFn.backward, which reads selected rows only)
         ctx.save_for_backward(src)
         ctx.rows_in = x2d.shape[0]
+        ctx.bwd_fill = bwd_fill
         return ops.gather_rows(x2d.contiguous(), src, live, live_mul, live_stride)
 
     @staticmethod
     def backward(ctx, dy):
         (src,) = ctx.saved_tensors
-        return ops.scatter_rows(dy.contiguous(), src, ctx.rows_in), None, None, None, None
+        return ops.scatter_rows(dy.contiguous(), src, ctx.rows_in, fill=ctx.bwd_fill), None, None, None, None, None
 
 
 class GatherPairFn(torch.autograd.Function):
@@ -710,14 +714,21 @@ class GatherPairFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2d, src_cls, src_b, live, live_mul, live_stride):
         x2d = x2d.contiguous()
-        ctx.save_for_backward(src_cls, src_b)
+        ctx.save_for_backward(src_cls, src_b, live)
         ctx.rows_in = x2d.shape[0]
+        ctx.nseg = int(live_mul)
         return ops.gather_rows(x2d, src_cls), ops.gather_rows(x2d, src_b, live, live_mul, live_stride)
 
     @staticmethod
     def backward(ctx, dcls, dxb):
-        src_cls, src_b = ctx.saved_tensors
-        dx = ops.scatter_rows(dxb.contiguous(), src_b, ctx.rows_in)
+        src_cls, src_b, live = ctx.saved_tensors
+        # the input (layout A) is `nseg` segments of rows_in / nseg rows with `live` live rows each; every live row is the source
+        # of exactly one layout-B row, so the scatter writes them all: only the pad rows up to the next multiple of 64 - which the
+        # live-row kernels of the per-modality blocks read - are zeroed, not the whole 152 MB
+        if live is not None and ctx.rows_in % ctx.nseg == 0:
+            dx = ops.scatter_rows(dxb.contiguous(), src_b, ctx.rows_in, fill="tail", live=live, seg_rows=ctx.rows_in // ctx.nseg)
+        else:
+            dx = ops.scatter_rows(dxb.contiguous(), src_b, ctx.rows_in)
         if dcls is not None:
             dx.index_add_(0, src_cls.long(), dcls.contiguous())      # (every cls row once: deterministic)
         return dx, None, None, None, None, None
@@ -727,15 +738,17 @@ class PoolPackedFn(torch.autograd.Function):
     """make_model.py:186-203 on the sample-major packed layout."""
 
     @staticmethod
-    def forward(ctx, x2d, cu, b, nmod):
+    def forward(ctx, x2d, cu, b, nmod, live=None):
+        # live (device int32 scalar = nmod * cu[b], the live rows of layout B): the backward then zeroes only the pad rows the
+        # live-row LayerNorm reads beyond them instead of zero-filling the worst-case-sized gradient
         out, num = ops.pool_packed_fwd(x2d.contiguous(), cu, b, nmod)
-        ctx.save_for_backward(num, cu)
+        ctx.save_for_backward(num, cu, live)
         ctx.meta = (b, nmod, x2d.shape[0])
         ctx.mark_non_differentiable(num)
         return out, num
 
     @staticmethod
     def backward(ctx, dout, _dnum):
-        num, cu = ctx.saved_tensors
+        num, cu, live = ctx.saved_tensors
         b, nmod, rows = ctx.meta
-        return ops.pool_packed_bwd(dout.contiguous(), num, cu, b, nmod, rows), None, None, None
+        return ops.pool_packed_bwd(dout.contiguous(), num, cu, b, nmod, rows, live), None, None, None, None

@@ -445,7 +445,9 @@ class EDITOR(nn.Module):
         fb = self.FUSE_block
         nmod, b, t, d = feats_s.shape
         plan = ops.CompactPlan(index, t, nmod)
-        xa = fn.GatherRowsFn.apply(feats_s.reshape(nmod * b * t, d), plan.map_a, plan.live_a, 1, plan.ma)   # layout A
+        # (feats_s has this ONE consumer and SFTSApplyFn.backward reads the selected rows of its gradient only - exactly the rows
+        #  this gather names - so the gather's backward does not zero-fill the others: bwd_fill="none")
+        xa = fn.GatherRowsFn.apply(feats_s.reshape(nmod * b * t, d), plan.map_a, plan.live_a, 1, plan.ma, "none")   # layout A
         mods = []
         xa_mod = torch.split(xa, plan.ma, dim=0)       # (split's backward is one cat; slices would zero-fill and add)
         for i, tag in enumerate(m_[2] for m_ in self.modalities):
@@ -465,7 +467,7 @@ class EDITOR(nn.Module):
                                          self.hma_heads, 1e-5, self.fn_dtype_hma, None, None, plan.cu3, nmod * t, plan.live_b,
                                          None, self._sink("hma.joint"))
         xb = fn.LayerNormFn.apply(xb, fb.out_norm.weight, fb.out_norm.bias, 1e-5, plan.mask_b, plan.live_b)
-        pooled, num = fn.PoolPackedFn.apply(xb, plan.cu, b, nmod)
+        pooled, num = fn.PoolPackedFn.apply(xb, plan.cu, b, nmod, plan.live_b)
         self.last_aux["plan"] = plan
         return pooled, num, loss_ocfr
 

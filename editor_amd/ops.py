@@ -710,9 +710,20 @@ def gather_rows(x2d, src, live=None, live_mul=1, live_stride=0):
     return out
 
 
-def scatter_rows(dy2d, src, rows_out):
-    dx = torch.empty(rows_out, dy2d.shape[1], dtype=torch.float32, device=dy2d.device)
-    call("editor_scatter_rows", dy2d, src, src.numel(), dy2d.shape[1], rows_out, dx)
+def scatter_rows(dy2d, src, rows_out, fill="all", live=None, seg_rows=0):
+    """dx[src[r]] = dy[r].  fill: "all" = dx zero-filled first (rows no index names are 0); "none" = no fill at all - ONLY for a
+    consumer that never reads those rows; "tail" = only the pad rows [live, roundup64(live)) of every `seg_rows`-row segment are
+    zeroed (live: device int32 scalar) - what the live-row kernels read beyond the live extent."""
+    d = dy2d.shape[1]
+    dx = torch.empty(rows_out, d, dtype=torch.float32, device=dy2d.device)
+    if fill == "all":
+        call("editor_scatter_rows", dy2d, src, src.numel(), d, rows_out, dx)
+        return dx
+    call("editor_scatter_rows_nofill", dy2d, src, src.numel(), d, dx)
+    if fill == "tail":
+        seg = int(seg_rows) or rows_out
+        for s0 in range(0, rows_out, seg):
+            call("editor_zero_tail_rows", dx[s0:s0 + seg], d * 4, min(seg, rows_out - s0), live)
     return dx
 
 
@@ -724,7 +735,16 @@ def pool_packed_fwd(x2d, cu, b, nmod):
     return out, num
 
 
-def pool_packed_bwd(dout, num, cu, b, nmod, rows):
+def pool_packed_bwd(dout, num, cu, b, nmod, rows, live=None):
+    if live is not None:                      # live: device scalar = nmod * cu[b] live rows; no 152 MB zero fill
+        dx = torch.empty(rows, dout.shape[-1] // 2, dtype=torch.float32, device=dout.device)
+        call("editor_pool_packed_bwd_nofill", dout, num, cu, b, nmod, dout.shape[-1] // 2, dx)
+        call("editor_zero_tail_rows", dx, dx.shape[1] * 4, rows, live)
+        return dx
+    return _pool_packed_bwd_filled(dout, num, cu, b, nmod, rows)
+
+
+def _pool_packed_bwd_filled(dout, num, cu, b, nmod, rows):
     d = dout.shape[2] // 2
     dx = torch.empty(rows, d, dtype=torch.float32, device=dout.device)
     call("editor_pool_packed_bwd", dout, num, cu, b, nmod, d, rows, dx)

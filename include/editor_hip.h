@@ -309,11 +309,19 @@ int editor_zero_tail_rows(void* buf, long row_bytes, long rows, const int* live,
 int editor_gather_rows(const float* in, const int* src, long R, int D, float* out, const int* r_live /* or NULL */,
                        int live_mul, long live_stride, editor_stream_t stream);
 int editor_scatter_rows(const float* dy, const int* src, long R, int D, long rows_out, float* dx, editor_stream_t stream);
+/* ... without zero-filling dx first: rows no index names keep whatever the buffer held - for consumers that provably never read
+ * them (the layout-A gather's gradient -> editor_sfts_apply_bwd reads selected rows only), or together with
+ * editor_zero_tail_rows for the pad rows [live, roundup64(live)) the live-row kernels read. */
+int editor_scatter_rows_nofill(const float* dy, const int* src, long R, int D, float* dx, editor_stream_t stream);
 /* make_model.py:186-203 on layout B */
 int editor_pool_packed_fwd(const float* x, const int* cu, long B, int nmod, int D, float* out, float* num,
                            editor_stream_t stream);
 int editor_pool_packed_bwd(const float* dout, const float* num, const int* cu, long B, int nmod, int D, long rows,
                            float* dx, editor_stream_t stream);
+/* ... without the zero fill of dx (every live row of every sample is written; the caller zeroes the pad rows with
+ * editor_zero_tail_rows) */
+int editor_pool_packed_bwd_nofill(const float* dout, const float* num, const int* cu, long B, int nmod, int D, float* dx,
+                                  editor_stream_t stream);
 
 /* ---- head kernels ------------------------------------------------------------------------------------ */
 
