@@ -712,15 +712,25 @@ __global__ __launch_bounds__(256) void attn_rollout_step_kernel(const bf16_t* __
         lse_s[t] = t < T ? lse[(long)hh * Mtot + row0 + t] : INFINITY;
         w_s[t] = t < T ? (r_in ? r_in[(long)blockIdx.x * T + t] : (t == 0 ? 1.f : 0.f)) : 0.f;
     }
-    images_ready();
+    // the wave's own key fragments come straight from global memory: the first tile's are requested BEFORE the wait for the Q
+    // image and every later tile's one tile ahead, under the arithmetic of the current one (round 4: they used to be requested
+    // at the top of each trip - two to three exposed HBM latencies per wave on top of the image's)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    short8_t kn[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) kn[s] = frag_own(qbase + D, ld, w * 16, T, s, lane);
+    images_ready();
     const int li = lane & 15, lg = lane >> 4;
     const float sc = scale * kLog2e;
     for (int k0 = w * 16; k0 < T; k0 += nw * 16) {
         const int key = k0 + li;
         short8_t kf[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) kf[s] = frag_own(qbase + D, ld, k0, T, s, lane);
+        for (int s = 0; s < 2; ++s) kf[s] = kn[s];
+        if (k0 + nw * 16 < T) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) kn[s] = frag_own(qbase + D, ld, k0 + nw * 16, T, s, lane);
+        }
         float acc = 0.f;
 #pragma unroll 2
         for (int u = 0; u < nt; ++u) {

@@ -11,7 +11,7 @@ typedef __attribute__((ext_vector_type(4))) float float4_t;
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16, LDT = 80;   // LDT: LDS row stride (floats); 80 % 32 == 16 -> conflict-free
+constexpr int BM = 64, BN = 64, BK = 32, LDT = 80;   // LDT: LDS row stride (floats); 80 % 32 == 16 -> conflict-free
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
@@ -30,42 +30,62 @@ __device__ __forceinline__ float gelu_grad_f(float a) {
     return 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.3989422804014327f * __expf(-0.5f * a * a);
 }
 
-// stage a (rows x BK) tile of a row-major operand P[r][k] (ld) or its transpose P[k][r] into S[k][r]
-__device__ __forceinline__ void stage_tile(const float* __restrict__ P, long ld, int trans, int r0, int k0, int R, int K,
-                                           int kend, float (*S)[LDT])
+// One (rows x BK) tile of a row-major operand P[r][k] (ld) or of its transpose P[k][r], as two float4 per thread.  LOAD and STORE are
+// separate steps (round 4): the global loads of K-tile t+1 are issued before the MFMAs of K-tile t and written to LDS after them.
+// They used to be one step - every 16-deep K-tile paid a full global-memory latency in front of its 8 MFMAs, 24.6 us for the
+// 128-row head / REDUCE products of the step (96 serial latencies for K = 1536) - and BK was 16 (now 32: half as many trips).
+struct TileRegs { float v[2][4]; };
+
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int trans, int r0, int k0, int R, int kend, TileRegs& t)
 {
-    const int t = threadIdx.x;
-    if (!trans) {                       // k contiguous: thread -> row t/4, 4 consecutive k
-        const int r = t >> 2, kk = (t & 3) * 4;
-        const int gr = r0 + r, gk = k0 + kk;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gr < R) {
-            const float* src = P + (long)gr * ld + gk;
-            if (gk + 3 < kend && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-                const float4 q = *reinterpret_cast<const float4*>(src);
-                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-            } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (gk + i < kend) v[i] = src[i];
+    for (int h = 0; h < 2; ++h) {
+        const int c = threadIdx.x + 256 * h;            // float4 chunk 0 .. 511 of the 64 x 32 tile
+        float* v = t.v[h];
+        v[0] = v[1] = v[2] = v[3] = 0.f;
+        if (!trans) {                                   // k contiguous: chunk -> row c/8, 4 consecutive k
+            const int r = c >> 3, kk = (c & 7) * 4;
+            const int gr = r0 + r, gk = k0 + kk;
+            if (gr < R) {
+                const float* src = P + (long)gr * ld + gk;
+                if (gk + 3 < kend && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+                    const float4 q = *reinterpret_cast<const float4*>(src);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (gk + i < kend) v[i] = src[i];
+                }
+            }
+        } else {                                        // r contiguous: chunk -> k c/16, 4 consecutive rows
+            const int kk = c >> 4, r = (c & 15) * 4;
+            const int gk = k0 + kk, gr = r0 + r;
+            if (gk < kend) {
+                const float* src = P + (long)gk * ld + gr;
+                if (gr + 3 < R && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+                    const float4 q = *reinterpret_cast<const float4*>(src);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (gr + i < R) v[i] = src[i];
+                }
             }
         }
+    }
+}
+__device__ __forceinline__ void store_tile(const TileRegs& t, int trans, float (*S)[LDT])
+{
 #pragma unroll
-        for (int i = 0; i < 4; ++i) S[kk + i][r] = v[i];
-    } else {                            // r contiguous: thread -> k t/16, 4 consecutive rows
-        const int kk = t >> 4, r = (t & 15) * 4;
-        const int gk = k0 + kk, gr = r0 + r;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gk < kend) {
-            const float* src = P + (long)gk * ld + gr;
-            if (gr + 3 < R && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-                const float4 q = *reinterpret_cast<const float4*>(src);
-                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-            } else {
+    for (int h = 0; h < 2; ++h) {
+        const int c = threadIdx.x + 256 * h;
+        const float* v = t.v[h];
+        if (!trans) {
+            const int r = c >> 3, kk = (c & 7) * 4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (gr + i < R) v[i] = src[i];
-            }
+            for (int i = 0; i < 4; ++i) S[kk + i][r] = v[i];
+        } else {
+            const int kk = c >> 4, r = (c & 15) * 4;
+            *reinterpret_cast<float4*>(&S[kk][r]) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        *reinterpret_cast<float4*>(&S[kk][r]) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -93,16 +113,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
         for (int j = 0; j < 2; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
 
     // opB(B)[k][n]: transB==0 means B is stored [N][K] (nn.Linear weight) -> "rows"=n, k contiguous
+    TileRegs ra, rb;
     if (kt0 < kt1) {
-        stage_tile(A, g.lda, g.transA, m0, kt0 * BK, g.M, g.K, g.K, As[0]);
-        stage_tile(B, g.ldb, g.transB, n0, kt0 * BK, g.N, g.K, g.K, Bs[0]);
+        load_tile(A, g.lda, g.transA, m0, kt0 * BK, g.M, g.K, ra);
+        load_tile(B, g.ldb, g.transB, n0, kt0 * BK, g.N, g.K, rb);
+        store_tile(ra, g.transA, As[0]);
+        store_tile(rb, g.transB, Bs[0]);
     }
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
         const int cur = (kt - kt0) & 1;
-        if (kt + 1 < kt1) {
-            stage_tile(A, g.lda, g.transA, m0, (kt + 1) * BK, g.M, g.K, g.K, As[cur ^ 1]);
-            stage_tile(B, g.ldb, g.transB, n0, (kt + 1) * BK, g.N, g.K, g.K, Bs[cur ^ 1]);
+        const bool more = kt + 1 < kt1;
+        if (more) {                                     // next K-tile's loads in flight under this tile's MFMAs
+            load_tile(A, g.lda, g.transA, m0, (kt + 1) * BK, g.M, g.K, ra);
+            load_tile(B, g.ldb, g.transB, n0, (kt + 1) * BK, g.N, g.K, rb);
         }
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 4) {
@@ -117,6 +141,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            store_tile(ra, g.transA, As[cur ^ 1]);
+            store_tile(rb, g.transB, Bs[cur ^ 1]);
         }
         __syncthreads();
     }

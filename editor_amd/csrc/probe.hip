@@ -101,6 +101,61 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, i
 }  // namespace
 
 // grid x 4 wavefronts; FLOPs = grid * 4 * iters * 8 * 16384
+// ---- pricing experiment ("price the bf16-branch residual with a measurement"): x_out = x + rowscale * branch
+// (branch: the bf16 output of a projection / fc2 product with the PLAIN 16-bit epilogue), y = LayerNorm(x_out) in bf16 - the
+// residual add moved out of the GEMM's fp32 epilogue into the LayerNorm that follows.  D = 768, wave per row, same access
+// pattern as layernorm_fwd_kernel.  Measurement only (tools/residual_pricing.py): the product path keeps the fp32 epilogue.
+namespace {
+__global__ __launch_bounds__(256) void resid_add_ln_kernel(const float* __restrict__ x, const uint16_t* __restrict__ branch,
+    const float* __restrict__ rowscale, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, long M,
+    float* __restrict__ x_out, uint16_t* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out)
+{
+    constexpr int D = 768;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float rs = rowscale ? rowscale[row] : 1.f;
+    float v[12];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = i * 256 + lane * 4;
+        const float4 a = *reinterpret_cast<const float4*>(x + row * D + c);
+        const uint2 b = *reinterpret_cast<const uint2*>(branch + row * D + c);
+        v[4 * i + 0] = a.x + rs * bf16_to_f32((bf16_t)(b.x & 0xffffu));
+        v[4 * i + 1] = a.y + rs * bf16_to_f32((bf16_t)(b.x >> 16));
+        v[4 * i + 2] = a.z + rs * bf16_to_f32((bf16_t)(b.y & 0xffffu));
+        v[4 * i + 3] = a.w + rs * bf16_to_f32((bf16_t)(b.y >> 16));
+        *reinterpret_cast<float4*>(x_out + row * D + c) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+        s += (v[4 * i] + v[4 * i + 1]) + (v[4 * i + 2] + v[4 * i + 3]);
+    }
+    const float mean = wave_sum(s) * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) { const float d = v[e] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / D) + eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = i * 256 + lane * 4;
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c), bb = *reinterpret_cast<const float4*>(beta + c);
+        uint2 o;
+        o.x = pack_bf16x2((v[4 * i] - mean) * rstd * g.x + bb.x, (v[4 * i + 1] - mean) * rstd * g.y + bb.y);
+        o.y = pack_bf16x2((v[4 * i + 2] - mean) * rstd * g.z + bb.z, (v[4 * i + 3] - mean) * rstd * g.w + bb.w);
+        *reinterpret_cast<uint2*>(y + row * D + c) = o;
+    }
+}
+}  // namespace
+
+extern "C" int editor_probe_resid_add_layernorm(const float* x, const uint16_t* branch, const float* rowscale, const float* gamma,
+    const float* beta, float eps, long M, int D, float* x_out, uint16_t* y, float* mean, float* rstd, hipStream_t stream)
+{
+    if (D != 768 || M < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(resid_add_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, branch, rowscale, gamma, beta, eps,
+                       M, x_out, y, mean, rstd);
+    return (int)hipGetLastError();
+}
+
 extern "C" int editor_probe_mfma_peak(float* out, int grid, int iters, int zero, hipStream_t stream)
 {
     hipLaunchKernelGGL(mfma_peak_kernel, dim3(grid), dim3(256), 0, stream, out, iters, zero);

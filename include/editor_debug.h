@@ -28,6 +28,11 @@ int editor_probe_clock_trace(unsigned long long* out, int n, int sleep, editor_s
 /* grid x 4 wavefronts each issuing iters x 8 independent v_mfma_f32_16x16x32_bf16 on register operands (no memory traffic):
  * the dense bf16 rate the chip sustains under its power management.  FLOPs = grid * 4 * iters * 8 * 16384. */
 int editor_probe_mfma_peak(float* out, int grid, int iters, int zero, editor_stream_t stream);
+/* pricing experiment (tools/residual_pricing.py; not on the product path): x_out = x + rowscale[row] * branch (bf16), y =
+ * LayerNorm(x_out) in bf16, D = 768 - the residual add moved from the GEMM's fp32 epilogue into the LayerNorm that follows */
+int editor_probe_resid_add_layernorm(const float* x, const uint16_t* branch, const float* rowscale, const float* gamma,
+                                     const float* beta, float eps, long M, int D, float* x_out, uint16_t* y, float* mean,
+                                     float* rstd, editor_stream_t stream);
 #ifdef __cplusplus
 }
 #endif
