@@ -275,7 +275,7 @@ __device__ __forceinline__ void epilogue_store(const GemmB16Args& g, float4_t (&
                     const v2f_t d0 = gelu_grad2(H16<F16>::unpack2(pre.x)), d1 = gelu_grad2(H16<F16>::unpack2(pre.y));
                     sv.x = H16<F16>::pack2(d0.x, d0.y); sv.y = H16<F16>::pack2(d1.x, d1.y);
                 }
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = sv;
+                if (g.aux) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = sv;
                 const v2f_t g0 = gelu2(H16<F16>::unpack2(pre.x)), g1 = gelu2(H16<F16>::unpack2(pre.y));
                 v.x = g0.x; v.y = g0.y; v.z = g1.x; v.w = g1.y;
             } else if (g.epilogue == EDITOR_EPI_GELU_BWD) {   // C = v * gelu'(aux), aux = saved pre-activation
@@ -459,7 +459,7 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
                 uint4 p;
                 p.x = H16<F16>::pack2(gelu_grad_exact(x[0]), gelu_grad_exact(x[1])); p.y = H16<F16>::pack2(gelu_grad_exact(x[2]), gelu_grad_exact(x[3]));
                 p.z = H16<F16>::pack2(gelu_grad_exact(x[4]), gelu_grad_exact(x[5])); p.w = H16<F16>::pack2(gelu_grad_exact(x[6]), gelu_grad_exact(x[7]));
-                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = p;
+                if (g.aux) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = p;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = gelu_exact(x[e]);
             } else if (EPI == EDITOR_EPI_GELU) {                 // aux <- pre-activation (bf16), C <- gelu(rounded pre-activation)
@@ -472,7 +472,7 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
                     for (int e = 0; e < 4; ++e) { const v2f_t dv = gelu_grad2(H16<F16>::unpack2(pw[e])); dw_[e] = H16<F16>::pack2(dv.x, dv.y); }
                     p = make_uint4(dw_[0], dw_[1], dw_[2], dw_[3]);
                 }
-                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = p;
+                if (g.aux) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = p;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const v2f_t gv = gelu2(H16<F16>::unpack2(pw[e]));
@@ -1178,14 +1178,15 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
                         gw[e] = __builtin_amdgcn_perm(ent[2 * e + 1], ent[2 * e], 0x05040100u);     // {gelu(lo), gelu(hi)}
                         dw_[e] = __builtin_amdgcn_perm(ent[2 * e + 1], ent[2 * e], 0x07060302u);    // {gelu'(lo), gelu'(hi)}
                     }
-                    *reinterpret_cast<uint4*>(Ab + (long)m * g.ldaux + n) = g.aux_grad ? make_uint4(dw_[0], dw_[1], dw_[2], dw_[3]) : p;
+                    if (Ab) *reinterpret_cast<uint4*>(Ab + (long)m * g.ldaux + n) = g.aux_grad ? make_uint4(dw_[0], dw_[1], dw_[2], dw_[3]) : p;
                     p = make_uint4(gw[0], gw[1], gw[2], gw[3]);
                     looked_up = true;
                 }
             }
             if (gelu && !looked_up) {
                 uint32_t pw[4] = {p.x, p.y, p.z, p.w};
-                if (g.aux_grad) {        // the backward only needs gelu'(pre-activation): save THAT (one multiply there instead of
+                if (!Ab) {               // (no-grad forward: nothing is saved)
+                } else if (g.aux_grad) { // the backward only needs gelu'(pre-activation): save THAT (one multiply there instead of
                     uint32_t dw_[4];     // an erfc + exponential per element in the dgrad epilogue)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const v2f_t dv = gelu_grad2(H16<F16>::unpack2(pw[e])); dw_[e] = H16<F16>::pack2(dv.x, dv.y); }
@@ -1479,7 +1480,8 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
     if (want_colsum && (c_f32 || epilogue == EDITOR_EPI_RESIDUAL || splitk > 1 || !splitk_ws || transA || M < 2048 || N < 512 ||
                         (N & 7) || (ldc & 7) || (ldaux & 7) || (K % BK) || beta != 0.f || m_live))
         return (int)hipErrorInvalidValue;                        // the column sums exist in the one-pass 256x256 epilogue only
-    if (epilogue != EDITOR_EPI_NONE && (!aux || (ldaux & 3) || splitk > 1)) return (int)hipErrorInvalidValue;
+    // (aux may be NULL for EDITOR_EPI_GELU: a no-grad forward - model.eval() / do_inference - saves nothing for a backward)
+    if (epilogue != EDITOR_EPI_NONE && ((!aux && epilogue != EDITOR_EPI_GELU) || (ldaux & 3) || splitk > 1)) return (int)hipErrorInvalidValue;
     if (splitk < 1) splitk = 1;
     const int ktiles = (K + BK - 1) / BK;
     if (splitk > ktiles) splitk = ktiles;
@@ -1560,7 +1562,7 @@ int gemm_f16x2(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi,
     const bool aux_grad = (epilogue & EDITOR_EPI_AUX_GRAD) != 0;
     epilogue &= ~(EDITOR_EPI_FORCE_PP | EDITOR_EPI_AUX_GRAD | 0xF000);
     if (epilogue != EDITOR_EPI_NONE && epilogue != EDITOR_EPI_RESIDUAL && epilogue != EDITOR_EPI_GELU) return (int)hipErrorInvalidValue;
-    if (epilogue != EDITOR_EPI_NONE && !aux) return (int)hipErrorInvalidValue;
+    if (epilogue != EDITOR_EPI_NONE && !aux && epilogue != EDITOR_EPI_GELU) return (int)hipErrorInvalidValue;   // (GELU, aux NULL: no-grad forward)
     if (epilogue == EDITOR_EPI_GELU && (c_f32 || !aux_grad)) return (int)hipErrorInvalidValue;   // aux = gelu'(x) for the backward
     if (epilogue == EDITOR_EPI_RESIDUAL && !c_f32) return (int)hipErrorInvalidValue;
     GemmB16Args g{(const bf16_t*)A_hi, (const bf16_t*)B_hi, C, M, N, K, lda, ldb, ldc, alpha, 0.f, bias, rowscale, 1, 0, 0,

@@ -11,7 +11,7 @@ typedef __attribute__((ext_vector_type(4))) float float4_t;
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32, LDT = 80;   // LDT: LDS row stride (floats); 80 % 32 == 16 -> conflict-free
+constexpr int BM = 64, BN = 64, BK = 16, LDT = 80;   // LDT: LDS row stride (floats); 80 % 32 == 16 -> conflict-free
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
@@ -32,19 +32,20 @@ __device__ __forceinline__ float gelu_grad_f(float a) {
 
 // One (rows x BK) tile of a row-major operand P[r][k] (ld) or of its transpose P[k][r], as two float4 per thread.  LOAD and STORE are
 // separate steps (round 4): the global loads of K-tile t+1 are issued before the MFMAs of K-tile t and written to LDS after them.
-// They used to be one step - every 16-deep K-tile paid a full global-memory latency in front of its 8 MFMAs, 24.6 us for the
-// 128-row head / REDUCE products of the step (96 serial latencies for K = 1536) - and BK was 16 (now 32: half as many trips).
-struct TileRegs { float v[2][4]; };
+// They used to be one step: every 16-deep K-tile paid a full global-memory latency in front of its 8 MFMAs.  (BK = 32 with the same
+// split measured SLOWER - 0.67 vs 0.54 ms per step over the 22 head / REDUCE products: 8-way instead of 4-way LDS write conflicts.)
+constexpr int NH = BK / 16;                        // float4 chunks per thread and operand tile
+struct TileRegs { float v[NH][4]; };
 
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int trans, int r0, int k0, int R, int kend, TileRegs& t)
 {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int c = threadIdx.x + 256 * h;            // float4 chunk 0 .. 511 of the 64 x 32 tile
+    for (int h = 0; h < NH; ++h) {
+        const int c = threadIdx.x + 256 * h;            // float4 chunk of the 64 x BK tile
         float* v = t.v[h];
         v[0] = v[1] = v[2] = v[3] = 0.f;
-        if (!trans) {                                   // k contiguous: chunk -> row c/8, 4 consecutive k
-            const int r = c >> 3, kk = (c & 7) * 4;
+        if (!trans) {                                   // k contiguous: chunk -> row, 4 consecutive k
+            const int r = c / (BK / 4), kk = (c % (BK / 4)) * 4;
             const int gr = r0 + r, gk = k0 + kk;
             if (gr < R) {
                 const float* src = P + (long)gr * ld + gk;
@@ -75,11 +76,11 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, 
 __device__ __forceinline__ void store_tile(const TileRegs& t, int trans, float (*S)[LDT])
 {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
         const int c = threadIdx.x + 256 * h;
         const float* v = t.v[h];
         if (!trans) {
-            const int r = c >> 3, kk = (c & 7) * 4;
+            const int r = c / (BK / 4), kk = (c % (BK / 4)) * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) S[kk + i][r] = v[i];
         } else {

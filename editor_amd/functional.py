@@ -320,7 +320,7 @@ class TransformerBlockFn(torch.autograd.Function):
                            epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)
             del aol
             h2, h2l, mean2, rstd2 = ops.layernorm_fwd_split(x1, n2w, n2b, eps, mask, m_live)
-            a = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
+            a = torch.empty(m, hidden, dtype=act_dtype, device=x.device) if any(ctx.needs_input_grad) else None
             g = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
             gl = torch.empty_like(g)
             ops.gemm_split((h2, h2l), w1, g, gl, m, hidden, d, alpha=inv_ws, bias=fc1b, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD,
@@ -352,7 +352,10 @@ class TransformerBlockFn(torch.autograd.Function):
                  epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)
         h2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, eps, act_dtype, mask, 0, m_live=m_live)
         hidden = w1.shape[0]
-        a = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
+        # (a no-grad forward - model.eval() under torch.no_grad(), engine/processor.py:217-270 - saves nothing for a backward: the
+        #  16-bit fc1 epilogue then writes ONE output instead of two, 304 MB per layer less at B = 128)
+        need_a = any(ctx.needs_input_grad) or act_dtype not in ops.HALF_DTYPES
+        a = torch.empty(m, hidden, dtype=act_dtype, device=x.device) if need_a else None
         g = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
         # 16-bit modes: `a` receives gelu'(pre-activation) - all the backward needs of it (one multiply in the fc2 dgrad
         # epilogue instead of an erfc + exponential per element); the f32 parity kernels keep the pre-activation

@@ -32,7 +32,8 @@ typedef struct ihipStream_t* editor_stream_t;   /* == hipStream_t */
 /* GEMM epilogues (applied after alpha / bias / rowscale, before beta*C): */
 #define EDITOR_EPI_NONE 0
 #define EDITOR_EPI_RESIDUAL 1 /* C = v + aux        aux: fp32 (M,N) residual stream  (x + drop_path(branch), vit_pytorch.py:217-218) */
-#define EDITOR_EPI_GELU 2     /* aux = v ; C = gelu(v)   aux: pre-activation in the activation dtype (Mlp.fc1 -> act, :140-141) */
+#define EDITOR_EPI_GELU 2     /* aux = v ; C = gelu(v)   aux: pre-activation in the activation dtype (Mlp.fc1 -> act, :140-141);
+                               * 16-bit kernels: aux may be NULL (a no-grad forward saves nothing: one output instead of two) */
 #define EDITOR_EPI_GELU_BWD 3 /* C = v * gelu'(aux)      aux: saved pre-activation (backward of the above) */
 #define EDITOR_EPI_COLSUM 0x100 /* OR-able (editor_gemm_bf16, bf16 C, M >= 2048, N >= 512, A k-major, splitk 1): also write
                                  * the column sums of every 256-row tile of the ROUNDED C to splitk_ws[(M+255)/256][N] - the bias
