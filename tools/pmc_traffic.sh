@@ -5,12 +5,12 @@
 # unit KB, FETCH_SIZE doubled on gfx950 (128-byte requests tallied at 64 B).  Infinity-Cache hits are counted by these
 # memory-side request counters, so the figure is an upper bound on HBM bytes.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 STEPS=2; WARM=1
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$ctr -o pmc -- \
-    python bench.py --steps $STEPS --warmup $WARM --no-graph --no-cpu-baseline --no-replay --no-h2d --no-modes > /tmp/pmc_$ctr.log 2>&1
+    python bench.py --steps $STEPS --warmup $WARM --no-graph --no-cpu-baseline --no-replay --no-h2d --no-modes --no-eval > /tmp/pmc_$ctr.log 2>&1
   tail -1 /tmp/pmc_$ctr.log | cut -c1-300
 done
 mkdir -p gpurun_out
