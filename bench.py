@@ -209,8 +209,8 @@ def hbm_kernels(model, img, b, act_dtype):
     px = mods[0].numel() * 4
     n = nsets_for(nmod * px)
     imgs = [[v.clone() for v in mods] for _ in range(n)]
-    add("freq_counts_kernel (Haar DWT -> mean -> IDWT -> positive count)", nmod * px,
-        lambda i: ops.freq_counts(imgs[i][0], imgs[i][1], imgs[i][2], imgs[i][3] if nmod > 3 else None), n, ("freq_counts_kernel",))
+    add("freq_counts4_kernel (Haar DWT -> mean -> IDWT -> positive count)", nmod * px,
+        lambda i: ops.freq_counts(imgs[i][0], imgs[i][1], imgs[i][2], imgs[i][3] if nmod > 3 else None), n, ("freq_counts",))
     del imgs
     n = nsets_for(2 * nmod * b * t * d * 4)
     feats = [torch.randn(nmod, b, t, d, device=dev) for _ in range(n)]
@@ -827,7 +827,7 @@ def main():
         flops = sum(v[0] for v in kinds.values())
         ms = sum(v[1] for v in kinds.values())
         launches = sum(v[2] for v in kinds.values())
-        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else None        # (--no-replay: not measured, not zero)
         ms_step = 1e3 * elapsed / args.steps
         arch = cfg.MODEL.TRANSFORMER_TYPE.replace("_patch16_224", "").replace("vit_", "ViT-").replace("base", "B").replace("large", "L")
         # `traffic` / `alg_bytes_per_step` are NOT measured in this run: PMC counters need their own rocprofv3 passes
@@ -842,8 +842,8 @@ def main():
                 tsrc = os.path.relpath(tfiles[-1], ROOT) + " (builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.sh; not measured in this run)"
             except Exception:
                 traffic = None
-        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS, 4),
+        roof = {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": None if achieved is None else round(achieved / PEAK_TFLOPS, 4),
                 "traffic": None if traffic is None else traffic.get("gemm_hbm_bytes_per_step"),
                 "traffic_source": tsrc,
                 "traffic_note": None if traffic is None else traffic.get("note"),

@@ -377,6 +377,7 @@ EPI_AUX_GRAD = 0x400          # with EPI_GELU / EPI_GELU_BWD (16-bit): aux = gel
 EPI_FORCE_PP = 0x200          # run the 256x256 ping-pong kernel whatever the shape heuristic says (tests)
 EPI_PIPE128 = 0x800           # prefer the 256x128 three-stage kernel (few token rows; gemm_tile_plan below)
 SHORT_TILES = os.environ.get("EDITOR_SHORT_TILES", "1") != "0"      # gemm_tile_rows below (measurement switch)
+LIVE_FRAC = float(os.environ.get("EDITOR_LIVE_FRAC", "0.5"))         # expected live share of a compacted launch's rows (0: off)
 
 
 def EPI_TILE_ROWS(h):
@@ -469,6 +470,15 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
                 th, epilogue = 256, int(epilogue) | EPI_PIPE128
             elif th != 256:
                 epilogue = int(epilogue) | EPI_TILE_ROWS(th)
+        elif (LIVE_FRAC > 0.0 and m_live is not None and not trans_a and not trans_b and splitk == 1 and beta == 0.0 and m >= 2048
+                and n >= 512 and colsum is None and not (int(epilogue) & (0xF000 | EPI_FORCE_PP))):
+            # compacted HMA head: the launch is sized for the worst case (every token kept) but only *m_live rows are live (a
+            # device scalar; workgroups of dead tiles exit at once) - about half of them (52 - 67 kept tokens of 128, SURVEY.md
+            # Appendix C).  Plan the tiles for THAT many rows: a per-modality block's 768-wide products are ~90 live 256-wide
+            # tiles on 256 CUs
+            _, narrow = gemm_tile_plan(max(256, int(m * LIVE_FRAC)), n)
+            if narrow:
+                epilogue = int(epilogue) | EPI_PIPE128
         if colsum is not None:
             # colsum (n) fp32 <- column sums of the rounded output (bias gradient of the layer this gradient feeds):
             # per-tile-row partials from the GEMM epilogue, folded in a fixed order
