@@ -377,7 +377,9 @@ EPI_AUX_GRAD = 0x400          # with EPI_GELU / EPI_GELU_BWD (16-bit): aux = gel
 EPI_FORCE_PP = 0x200          # run the 256x256 ping-pong kernel whatever the shape heuristic says (tests)
 EPI_PIPE128 = 0x800           # prefer the 256x128 three-stage kernel (few token rows; gemm_tile_plan below)
 SHORT_TILES = os.environ.get("EDITOR_SHORT_TILES", "1") != "0"      # gemm_tile_rows below (measurement switch)
-LIVE_FRAC = float(os.environ.get("EDITOR_LIVE_FRAC", "0.5"))         # expected live share of a compacted launch's rows (0: off)
+# expected live share of a compacted launch's rows for the tile plan below; 0 = off, the default: measured (round 4, same box, twice
+# each) 43.50 / 43.35 ms off against 43.73 / 43.65 ms with 0.5 - the 256 x 128 kernel's lower rate costs more than the idle CUs
+LIVE_FRAC = float(os.environ.get("EDITOR_LIVE_FRAC", "0"))
 
 
 def EPI_TILE_ROWS(h):
