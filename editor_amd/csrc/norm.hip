@@ -112,6 +112,62 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if (lane == 0) { if (mean_out) mean_out[row] = mean; if (rstd_out) rstd_out[row] = rstd; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Residual add + LayerNorm forward in one pass (round 4, bf16 mode):  x_out = x + rowscale[row] * branch,  y = LN(x_out).
+// `branch` is the 16-bit output of the projection / fc2 product written with the PLAIN epilogue: the residual add leaves the
+// GEMM's fp32 epilogue - 512 KiB of HBM-miss traffic per 256 x 256 tile at the ~10 B/clk a CU that is owned by one workgroup can
+// pull - for this streaming kernel (30 waves per CU).  Measured at M = 49 536 (tools/residual_pricing.py): -17 us per
+// projection + LayerNorm pair, -13 .. -16 us per fc2 + LayerNorm pair.  Price: the branch is rounded to 16 bits before the add
+// (cls4t at B = 128: x 1.068, tools/branch16_accuracy.py) - cfg.MODEL.BRANCH16, on in bf16 mode only.  Dense rows (no row mask,
+// no live-row count), D a multiple of 256; same per-row arithmetic as layernorm_fwd_kernel on x_out.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void resid_add_layernorm_fwd_kernel(const float* __restrict__ x, const T* __restrict__ branch,
+    const float* __restrict__ rowscale, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, long M, int D,
+    float* __restrict__ x_out, T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 8;
+    const float rs = rowscale ? rowscale[row] : 1.f;
+    const float* xr = x + row * D;
+    const T* br = branch + row * D;
+    float4 v[kMaxV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+        const int c0 = (i * 64 + lane) * 4;
+        const float4 a = *reinterpret_cast<const float4*>(xr + c0);
+        const float4 b = Vec4<T>::ld(br + c0);
+        v[i] = make_float4(a.x + rs * b.x, a.y + rs * b.y, a.z + rs * b.z, a.w + rs * b.w);
+        *reinterpret_cast<float4*>(x_out + row * D + c0) = v[i];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    T* yr = y + row * D;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+        const int c0 = (i * 64 + lane) * 4;
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c0);
+        const float4 bt = *reinterpret_cast<const float4*>(beta + c0);
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * g.x + bt.x;
+        o.y = (v[i].y - mean) * rstd * g.y + bt.y;
+        o.z = (v[i].z - mean) * rstd * g.z + bt.z;
+        o.w = (v[i].w - mean) * rstd * g.w + bt.w;
+        Vec4<T>::st(yr + c0, o);
+    }
+    if (lane == 0) { if (mean_out) mean_out[row] = mean; if (rstd_out) rstd_out[row] = rstd; }
+}
+
 __device__ __forceinline__ float round_like(float v, float) { return v; }
 __device__ __forceinline__ float round_like(float v, bf16_t) { return bf16_to_f32(f32_to_bf16(v)); }
 __device__ __forceinline__ float round_like(float v, f16_t) { return f16_to_f32(f32_to_f16(v)); }
@@ -668,6 +724,20 @@ extern "C" int editor_layernorm_fwd(const float* x, const float* gamma, const fl
         DISPATCH_T(y_bf16, hipLaunchKernelGGL(layernorm_fwd_kernel<TT>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream,
                    x, gamma, beta, eps, M, D, rowmask, mask_period, (TT*)y, mean, rstd, m_live));
     }
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_resid_add_layernorm_fwd(const float* x, const void* branch, int b16, const float* rowscale, const float* gamma,
+    const float* beta, float eps, long M, int D, float* x_out, void* y, float* mean, float* rstd, hipStream_t stream)
+{
+    if (D % 256 || D > 256 * kMaxV || M <= 0 || (b16 != 1 && b16 != 2) || !x || !branch || !x_out || !y) return (int)hipErrorInvalidValue;
+    if (b16 == 1)
+        hipLaunchKernelGGL(resid_add_layernorm_fwd_kernel<bf16_t>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x,
+                           (const bf16_t*)branch, rowscale, gamma, beta, eps, M, D, x_out, (bf16_t*)y, mean, rstd);
+    else
+        hipLaunchKernelGGL(resid_add_layernorm_fwd_kernel<f16_t>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x,
+                           (const f16_t*)branch, rowscale, gamma, beta, eps, M, D, x_out, (f16_t*)y, mean, rstd);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

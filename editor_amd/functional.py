@@ -279,7 +279,13 @@ class TransformerBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, mask, probs_out,
                 heads, eps, act_dtype, rowscale_attn, rowscale_mlp, cu=None, max_t=None, m_live=None, qk_scale=None,
-                sink=None):
+                sink=None, pend_branch=None, pend_rs=None, defer_out=False, branch16=False):
+        # branch16 (cfg.MODEL.BRANCH16; bf16 backbone blocks): the projection and fc2 products write their 16-bit branch output with
+        # the plain epilogue and the residual add happens inside the LayerNorm that follows (ops.resid_add_layernorm_fwd) - the
+        # next block's LayerNorm-1 for the fc2 branch: `defer_out` makes this node return (x1, fc2 branch) instead of x2, and
+        # (pend_branch, pend_rs) are the previous block's pair for which `x` is x1.  The backward is unchanged: the gradient
+        # that arrives for the x1 output IS dL/dx2 (x2 = x1 + rs * branch), and the branch output's own gradient,
+        # rs * dL/dx2 rounded to 16 bits, is what this node's backward computes first anyway.
         # sink (editor_amd.ddp.BlockSink or None): the 12 parameter gradients of this block are written straight into
         # views of a flat all-reduce bucket and the bucket's collective is launched from the end of the backward
         # dense: x (B,T,D), mask (B,T) token mask.  packed (compacted HMA): x (M,D), cu (B+1) sequence row ranges,
@@ -292,6 +298,9 @@ class TransformerBlockFn(torch.autograd.Function):
         hd = d // heads
         x2d = x.reshape(m, d)
         amask = None if cu is not None else mask           # packed sequences hold only live tokens
+        if (branch16 or defer_out or pend_branch is not None) and (act_dtype not in ops.HALF_DTYPES or cu is not None
+                                                                   or mask is not None or m_live is not None or d % 256):
+            raise RuntimeError("branch16 blocks: dense 16-bit rows only")
         head_done = split_all = False
         if act_dtype in (F16X2, F16X2H):
             # split-precision forward: every product on half PAIRS (three MFMA passes, fp32-class), the exact softmax / GELU
@@ -340,17 +349,26 @@ class TransformerBlockFn(torch.autograd.Function):
         wp, w1, w2 = (act_weight(w, act_dtype) for w in (projw, fc1w, fc2w))
         if not head_done:
             wq = act_weight(qkvw, act_dtype)
-            h1, mean1, rstd1 = ops.layernorm_fwd(x2d, n1w, n1b, eps, act_dtype, mask, 0, m_live=m_live)
+            if pend_branch is not None:          # x2d <- x1_prev + rs_prev * fc2-branch_prev, h1 = LN1(x2d): one pass
+                x2d, h1, mean1, rstd1 = ops.resid_add_layernorm_fwd(x2d, pend_branch, pend_rs, n1w, n1b, eps)
+            else:
+                h1, mean1, rstd1 = ops.layernorm_fwd(x2d, n1w, n1b, eps, act_dtype, mask, 0, m_live=m_live)
             qkv = _linear_fwd(h1, wq, qkvb, act_dtype, m_live)
             if isinstance(probs_out, list):            # bf16 backbone: no probability tensor; the rollout recomputes it
                 ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, None, cu=cu, scale=qk_scale)
                 probs_out.append((qkv, attn_saved))
             else:
                 ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, probs_out, cu=cu, scale=qk_scale)
-        x1 = torch.empty_like(x2d)                  # x1 = x + rs * (ao Wp^T + b): residual add in the GEMM epilogue
-        ops.gemm(ao, wp, x1, m, d, d, d, d, d, 0, 0, bias=projb, rowscale=rowscale_attn,
-                 epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)
-        h2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, eps, act_dtype, mask, 0, m_live=m_live)
+        if branch16:                                # 16-bit branch, plain epilogue; x1 = x + rs * branch inside LayerNorm-2's pass
+            br1 = torch.empty(m, d, dtype=act_dtype, device=x.device)
+            ops.gemm(ao, wp, br1, m, d, d, d, d, d, 0, 0, bias=projb)
+            x1, h2, mean2, rstd2 = ops.resid_add_layernorm_fwd(x2d, br1, rowscale_attn, n2w, n2b, eps)
+            del br1
+        else:
+            x1 = torch.empty_like(x2d)              # x1 = x + rs * (ao Wp^T + b): residual add in the GEMM epilogue
+            ops.gemm(ao, wp, x1, m, d, d, d, d, d, 0, 0, bias=projb, rowscale=rowscale_attn,
+                     epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)
+            h2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, eps, act_dtype, mask, 0, m_live=m_live)
         hidden = w1.shape[0]
         # (a no-grad forward - model.eval() under torch.no_grad(), engine/processor.py:217-270 - saves nothing for a backward: the
         #  16-bit fc1 epilogue then writes ONE output instead of two, 304 MB per layer less at B = 128)
@@ -362,9 +380,14 @@ class TransformerBlockFn(torch.autograd.Function):
         light = ACT_LIGHT and act_dtype in ops.HALF_DTYPES
         ag = ops.EPI_AUX_GRAD if (act_dtype in ops.HALF_DTYPES and not light) else 0     # light: `a` keeps the pre-activation
         ops.gemm(h2, w1, g, m, hidden, d, d, d, hidden, 0, 0, bias=fc1b, epilogue=ops.EPI_GELU | ag, aux=a, m_live=m_live)
-        x2 = torch.empty_like(x2d)
-        ops.gemm(g, w2, x2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b, rowscale=rowscale_mlp,
-                 epilogue=ops.EPI_RESIDUAL, aux=x1, m_live=m_live)
+        br2 = None
+        if defer_out:                               # (x1, fc2 branch): the consumer's LayerNorm adds them
+            br2 = torch.empty(m, d, dtype=act_dtype, device=x.device)
+            ops.gemm(g, w2, br2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b)
+        else:
+            x2 = torch.empty_like(x2d)
+            ops.gemm(g, w2, x2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b, rowscale=rowscale_mlp,
+                     epilogue=ops.EPI_RESIDUAL, aux=x1, m_live=m_live)
         if light:
             h1 = h2 = g = None                      # recomputed by the backward (n1b / n2b / eps ride along)
         ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
@@ -373,10 +396,13 @@ class TransformerBlockFn(torch.autograd.Function):
         ctx.gs = grad_scale(act_dtype)               # (the model's loss scale at forward time: the backward uses THIS one)
         ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None,
                     tuple(x.shape), qk_scale, sink)
+        if defer_out:
+            ctx.mark_non_differentiable(br2)
+            return x1.view(x.shape), br2
         return x2.view(x.shape)
 
     @staticmethod
-    def backward(ctx, dx2):
+    def backward(ctx, dx2, *_unused):
         (x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w, qkvw, projw, fc1w, fc2w, mask,
          attn_saved, rs_attn, rs_mlp, cu, m_live) = ctx.saved_tensors
         b, t, d, heads, act_dtype, hb_qkv, hb_proj, hb_fc1, hb_fc2, xshape, qk_scale, sink = ctx.meta
@@ -458,7 +484,7 @@ class TransformerBlockFn(torch.autograd.Function):
             # the bucket's all-reduce start now, under the rest of the backward
             grads = tuple(None if v is not None else g_ for g_, v in zip(grads, sv))
             sink.done()
-        return (dx.view(xshape),) + grads + (None,) * 13
+        return (dx.view(xshape),) + grads + (None,) * 17
 
 
 def _scaled_cast_colsum(dx, rowscale, dtype, m_live, want_colsum, gs=1.0, cs_out=None, rq=None):

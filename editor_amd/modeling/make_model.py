@@ -307,6 +307,15 @@ class EDITOR(nn.Module):
         self.act_light = bool(getattr(cfg.MODEL, "ACT_LIGHT", False))   # 24 instead of 36 saved bytes per token-row-element
         fn.set_model_options(self.grad_scale_f16, self.act_light)
         self.hma_compact = bool(getattr(cfg.MODEL, "HMA_COMPACT", True))
+        # cfg.MODEL.BRANCH16 (default: on in bf16 mode, off elsewhere): the backbone blocks' projection / fc2 products write their
+        # branch output in 16 bits with the plain epilogue and the residual add happens inside the LayerNorm that follows
+        # (functional.TransformerBlockFn branch16 / defer_out; -0.35 ms per step, GEMM family 0.353 -> ~0.375 of peak).  It rounds
+        # every branch to bf16 before the add: cls4t at B = 128 6.5e-3 -> 7.0e-3 (x 1.068, tools/branch16_accuracy.py) - inside the
+        # 1.1 x bound the round-3 review set for adopting it, and only in the mode whose features are 8-bit-mantissa class anyway;
+        # f16 (8.4e-4 -> 9.0e-4 against the north star's 1e-3), f16x2 and f32 keep the fp32 epilogue.
+        b16_default = self.act_dtype == torch.bfloat16 and not self.split_fwd
+        self.branch16 = bool(getattr(cfg.MODEL, "BRANCH16", b16_default)) and self.act_dtype in (torch.bfloat16, torch.float16) \
+            and not self.split_fwd and not self.bb_attn_f32 and dim % 256 == 0
         self.rollout_probs = bool(getattr(cfg.MODEL, "ROLLOUT_PROBS", False))
         self.teacher_index = None            # optional (B,N) bool: force the SFTS selection (bf16 protocol)
         self.grad_buckets = None             # editor_amd.ddp.GradBuckets once enable_grad_buckets() was called
@@ -386,14 +395,23 @@ class EDITOR(nn.Module):
                 seed0 = (int(torch.initial_seed()) * 1000003) & 0x3FFFFFFFFFFFFFFF
                 self._drop_state = torch.full((1,), seed0, dtype=torch.int64, device=dev)
             scales = ops.droppath_scales_dev(self._drop_rates_dev, btot, t, self._drop_state)
+        pend_branch = pend_rs = None                 # BRANCH16: the previous block's (fc2 branch, drop-path scales); x is then its x1
         for i, blk in enumerate(base.blocks):
             rs_a = rs_m = None
             if scales is not None and base.drop_rates[i] > 0.0:
                 rs_a, rs_m = scales[i, 0], scales[i, 1]
-            x = fn.TransformerBlockFn.apply(x, *_block_args(blk.norm1, blk.attn, blk.norm2, blk.mlp), None,
-                                            probs if recompute else probs[i], base.heads, 1e-6,
-                                            self.fn_dtype_last if i == len(base.blocks) - 1 else self.fn_dtype, rs_a, rs_m,
-                                            None, None, None, base.qk_scale, self._sink("backbone.%d" % i))
+            last = i == len(base.blocks) - 1
+            defer = self.branch16 and not last        # (the last block adds its own fc2 branch: the final norm takes plain rows)
+            out = fn.TransformerBlockFn.apply(x, *_block_args(blk.norm1, blk.attn, blk.norm2, blk.mlp), None,
+                                              probs if recompute else probs[i], base.heads, 1e-6,
+                                              self.fn_dtype_last if last else self.fn_dtype, rs_a, rs_m,
+                                              None, None, None, base.qk_scale, self._sink("backbone.%d" % i),
+                                              pend_branch, pend_rs, defer, self.branch16)
+            if defer:
+                x, pend_branch = out
+                pend_rs = rs_m
+            else:
+                x, pend_branch, pend_rs = out, None, None
         x = fn.LayerNormFn.apply(x, base.norm.weight, base.norm.bias, 1e-6, None)
         return x, probs
 

@@ -183,6 +183,18 @@ def layernorm_fwd(x2d, gamma, beta, eps, out_dtype, rowmask=None, mask_period=0,
     return y, mean, rstd
 
 
+def resid_add_layernorm_fwd(x2d, branch, rowscale, gamma, beta, eps):
+    """x_out = x + rowscale[:, None] * branch (branch: 16-bit, plain-epilogue output of the projection / fc2 product), y = LN(x_out)
+    in branch's dtype -> (x_out fp32, y, mean, rstd).  Dense rows, D a multiple of 256 (cfg.MODEL.BRANCH16)."""
+    m, d = x2d.shape
+    x_out = torch.empty_like(x2d)
+    y = torch.empty(m, d, dtype=branch.dtype, device=x2d.device)
+    mean = torch.empty(m, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(m, dtype=torch.float32, device=x2d.device)
+    call("editor_resid_add_layernorm_fwd", x2d, branch, _is_bf16(branch), rowscale, gamma, beta, float(eps), m, d, x_out, y, mean, rstd)
+    return x_out, y, mean, rstd
+
+
 def layernorm_bwd(dy, x2d, gamma, mean, rstd, rowmask=None, mask_period=0, dx_in=None, want_param_grads=True,
                   m_live=None, dy_scale=1.0, dgb_out=None, rq=None):
     """dgb_out: optional (2, D) fp32 view that receives [dgamma; dbeta] (adjacent slots of a gradient bucket).

@@ -90,6 +90,13 @@ int editor_mask_or(const uint8_t* a, const uint8_t* b, const uint8_t* c, const u
 int editor_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, long M, int D,
                          const uint8_t* rowmask, int mask_period, void* y, int y_bf16, float* mean, float* rstd,
                          const int* m_live, editor_stream_t stream);
+/* Residual add + LayerNorm in one pass (bf16 mode, cfg.MODEL.BRANCH16): x_out[m,:] = x[m,:] + rowscale[m] * branch[m,:] with
+ * `branch` the 16-bit (b16 = 1 bf16 / 2 f16) output of the projection / fc2 product written with the plain epilogue
+ * (vit_pytorch.py:217-218: x + drop_path(branch)), y = LayerNorm(x_out) in the same 16-bit type, mean / rstd of x_out.  Dense
+ * rows, D a multiple of 256 (<= 1024).  rowscale may be NULL. */
+int editor_resid_add_layernorm_fwd(const float* x, const void* branch, int b16, const float* rowscale, const float* gamma,
+                                   const float* beta, float eps, long M, int D, float* x_out, void* y, float* mean,
+                                   float* rstd, editor_stream_t stream);
 /* backward: dx_out = (dx_in ? dx_in : 0) + dLN/dx ; dgamma/dbeta: ONE (2,D) fp32 buffer (dbeta == dgamma + D; NULL to
  * skip).  workspace: ws_rows*2*D floats. */
 int editor_layernorm_bwd(const void* dy, int dy_bf16, float dy_scale /* dy is multiplied by it on load */,

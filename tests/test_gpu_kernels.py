@@ -649,3 +649,26 @@ def test_grouped_weight_gradients_match_separate_products(dtype):
     ops.gemm_wgrad_group(jobs, m, alpha=1.0, m_live=torch.tensor([live], dtype=torch.int32, device="cuda"))
     for dy, x, dw in jobs:
         assert rel_err(dw.cpu(), (dy[:live].float().t() @ x[:live].float()).cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,d", [(1031, 768), (516, 1024), (77, 256)])
+def test_resid_add_layernorm_fwd(ops, m, d, dtype):
+    """Round 4, cfg.MODEL.BRANCH16: x_out = x + rowscale * branch (16-bit branch), y = LN(x_out) in one pass == the residual add in
+    fp32 followed by the stand-alone LayerNorm kernel, BIT FOR BIT (same per-row arithmetic on the same fp32 rows), and close to
+    torch's fp32 layer_norm."""
+    x = torch.randn(m, d, generator=_g(1)).cuda() * 3
+    br = (torch.randn(m, d, generator=_g(2)) * 0.7).to(dtype).cuda()
+    rs = ((torch.rand(m, generator=_g(3)) > 0.2).float() / 0.8).cuda()
+    g = (torch.rand(d, generator=_g(4)) + 0.5).cuda()
+    b = (torch.randn(d, generator=_g(5)) * 0.1).cuda()
+    for scale in (rs, None):
+        xo, y, mean, rstd = ops.resid_add_layernorm_fwd(x, br, scale, g, b, 1e-6)
+        want_x = x + (br.float() * scale[:, None] if scale is not None else br.float())
+        assert torch.equal(xo, want_x)
+        y2, mean2, rstd2 = ops.layernorm_fwd(want_x, g, b, 1e-6, dtype)
+        assert torch.equal(y.view(torch.int16), y2.view(torch.int16)) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+        ref = F.layer_norm(want_x, (d,), g, b, 1e-6)
+        assert rel_err(y.float().cpu(), ref.cpu()) < (5e-3 if dtype == torch.bfloat16 else 6e-4)
+    with pytest.raises(RuntimeError):
+        ops.resid_add_layernorm_fwd(x[:, :384].contiguous(), br[:, :384].contiguous(), None, g[:384].contiguous(), b[:384].contiguous(), 1e-6)

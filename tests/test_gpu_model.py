@@ -471,3 +471,31 @@ def test_activation_light_blocks_match_default(dtype):
     worst = max(rel_err(grads[1][k].cpu(), grads[0][k].cpu()) for k in grads[0] if grads[0][k].abs().max() > 0)
     print(dtype, "activation-light vs default: worst gradient rel err", worst)
     assert worst < (2e-2 if dtype == "bf16" else 3e-3)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_branch16_blocks_against_the_fp32_epilogue(dtype):
+    """cfg.MODEL.BRANCH16 (round 4; default on in bf16 mode): the backbone's projection / fc2 branches leave their GEMMs in 16 bits
+    and are added to the residual stream inside the LayerNorm that follows (across blocks for fc2).  Same training step with it on
+    and off, drop-path ON (the per-sample scales ride with the deferred branch): outputs and gradients agree to what rounding
+    24 branch tensors to 16 bits costs, every parameter that has a gradient without it has one with it, and with it on the step
+    is bit-reproducible."""
+    res = {}
+    for b16 in (False, True, True):
+        torch.manual_seed(5)
+        m, cfg, c, cams = _model("RGBNT201", 41, dtype, drop_path=0.1, branch16=b16)
+        assert m.branch16 == b16
+        m.train()
+        img, label, cam, view = _cuda_batch(*synth.make_batch(42, 16, 256, 128, cams, instances=4))
+        out = m(img, label=label, cam_label=cam, view_label=view, writer=_Writer(), epoch=1)
+        total = out[-1] + sum((o * synth.uniform(5, "proj/%d" % i, tuple(o.shape)).cuda()).mean() for i, o in enumerate(out[:-1]))
+        total.backward()
+        res.setdefault(b16, []).append(([o.detach().clone() for o in out],
+                                       {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+    (o0, g0), (o1, g1), (o2, g2) = res[False][0], res[True][0], res[True][1]
+    assert all(torch.equal(a, b) for a, b in zip(o1, o2)) and all(torch.equal(g1[k], g2[k]) for k in g1)
+    assert set(g0) == set(g1)
+    oerr = max(rel_err(a.float().cpu(), b.float().cpu()) for a, b in zip(o1, o0))
+    worst = max(rel_err(g1[k].cpu(), g0[k].cpu()) for k in g0 if g0[k].abs().max() > 0)
+    print(dtype, "branch16 vs fp32 residual epilogue: worst output rel err %.2e, worst gradient rel err %.2e" % (oerr, worst))
+    assert oerr < (8e-3 if dtype == "bf16" else 1.2e-3) and worst < (4e-2 if dtype == "bf16" else 6e-3)
