@@ -16,6 +16,7 @@ MI355X-first differences in HOW (not WHAT) it computes:
   * top-k tie order of torch's CPU kernel is reproduced on device (libstdc++ heap/introselect).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -307,13 +308,14 @@ class EDITOR(nn.Module):
         self.act_light = bool(getattr(cfg.MODEL, "ACT_LIGHT", False))   # 24 instead of 36 saved bytes per token-row-element
         fn.set_model_options(self.grad_scale_f16, self.act_light)
         self.hma_compact = bool(getattr(cfg.MODEL, "HMA_COMPACT", True))
-        # cfg.MODEL.BRANCH16 (default: on in bf16 mode, off elsewhere): the backbone blocks' projection / fc2 products write their
-        # branch output in 16 bits with the plain epilogue and the residual add happens inside the LayerNorm that follows
-        # (functional.TransformerBlockFn branch16 / defer_out; -0.35 ms per step, GEMM family 0.353 -> ~0.375 of peak).  It rounds
-        # every branch to bf16 before the add: cls4t at B = 128 6.5e-3 -> 7.0e-3 (x 1.068, tools/branch16_accuracy.py) - inside the
-        # 1.1 x bound the round-3 review set for adopting it, and only in the mode whose features are 8-bit-mantissa class anyway;
-        # f16 (8.4e-4 -> 9.0e-4 against the north star's 1e-3), f16x2 and f32 keep the fp32 epilogue.
-        b16_default = self.act_dtype == torch.bfloat16 and not self.split_fwd
+        # cfg.MODEL.BRANCH16 (default OFF; EDITOR_BRANCH16=1 switches it on for A/B runs): the backbone blocks' projection / fc2
+        # products write their branch output in 16 bits with the plain epilogue and the residual add happens inside the LayerNorm
+        # that follows (functional.TransformerBlockFn branch16 / defer_out).  Measured in the step: the GEMM
+        # family gets 1.0 ms shorter (0.357 -> 0.369 of peak: the fp32 residual epilogues leave it) and the LayerNorm family 1.0
+        # ms longer - in situ the stand-alone LayerNorm reads rows the epilogue has just left in the Infinity Cache, the fused one
+        # reads the residual from HBM - so the STEP does not move (42.57 / 42.35 vs 42.57 / 42.47 ms), while every branch is
+        # rounded to 16 bits before the add (cls4t x 1.068).  Hence an option, not the default.
+        b16_default = os.environ.get("EDITOR_BRANCH16") == "1" and self.act_dtype == torch.bfloat16 and not self.split_fwd
         self.branch16 = bool(getattr(cfg.MODEL, "BRANCH16", b16_default)) and self.act_dtype in (torch.bfloat16, torch.float16) \
             and not self.split_fwd and not self.bb_attn_f32 and dim % 256 == 0
         self.rollout_probs = bool(getattr(cfg.MODEL, "ROLLOUT_PROBS", False))

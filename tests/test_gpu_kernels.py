@@ -670,5 +670,6 @@ def test_resid_add_layernorm_fwd(ops, m, d, dtype):
         assert torch.equal(y.view(torch.int16), y2.view(torch.int16)) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
         ref = F.layer_norm(want_x, (d,), g, b, 1e-6)
         assert rel_err(y.float().cpu(), ref.cpu()) < (5e-3 if dtype == torch.bfloat16 else 6e-4)
-    with pytest.raises(RuntimeError):
-        ops.resid_add_layernorm_fwd(x[:, :384].contiguous(), br[:, :384].contiguous(), None, g[:384].contiguous(), b[:384].contiguous(), 1e-6)
+    with pytest.raises(RuntimeError):                      # D = 384: not a multiple of 256 - an error, not a silent fallback
+        ops.resid_add_layernorm_fwd(torch.zeros(8, 384, device="cuda"), torch.zeros(8, 384, dtype=dtype, device="cuda"), None,
+                                    torch.ones(384, device="cuda"), torch.zeros(384, device="cuda"), 1e-6)
