@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "attn_common.h"
+#include <string.h>
 
 namespace {
 
@@ -753,6 +754,101 @@ __global__ __launch_bounds__(256) void attn_rollout_step_kernel(const bf16_t* __
     }
 }
 
+// The whole rollout (all L layers) as ONE launch (round 4): a workgroup keeps its (sample, head)'s row vector r in LDS and walks
+// the layers last -> first; layer l-1's Q image and log-sum-exps travel (LDS-DMA / registers) while layer l is being multiplied,
+// the wave's first key fragments of the next layer are requested one layer ahead.  Same arithmetic per element and the same
+// summation order as L launches of attn_rollout_step_kernel (bit-identical scores); 12 launches and their tails -> 1.
+constexpr int kMaxRollLayers = 32;
+struct RolloutArgs { const bf16_t* qkv[kMaxRollLayers]; const float* lse[kMaxRollLayers]; int L; };
+
+template <int NT, bool F16>
+__global__ __launch_bounds__(256) void attn_rollout_multi_kernel(RolloutArgs ra, int T, int heads, float scale, long Mtot,
+                                                                 float* __restrict__ scores)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Tp = NT * 16;
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * Tp * ROWB);      // [2][Tp]
+    float* w_s = lse_s + 2 * Tp;                                         // [2][Tp]
+    const int D = heads * HD;
+    const int b = blockIdx.x / heads, hh = blockIdx.x % heads;
+    const long ld = 3L * D;
+    const long row0 = (long)b * T;
+    const int nt = min(NT, ((T + 31) >> 5) << 1);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const float sc = scale * kLog2e;
+    const int L = ra.L;
+
+    const bf16_t* qb = ra.qkv[L - 1] + row0 * ld + hh * HD;
+    load_image(smem, qb, ld, T, nt * 16);
+    for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
+        lse_s[t] = t < T ? ra.lse[L - 1][(long)hh * Mtot + row0 + t] : INFINITY;
+        w_s[t] = t == 0 ? 1.f : 0.f;                                     // r = e_cls^T
+        w_s[Tp + t] = 0.f;                                               // (pad entries of the other buffer: never written later)
+    }
+    short8_t kn[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) kn[s] = frag_own(qb + D, ld, w * 16, T, s, lane);
+    for (int l = L - 1, cur = 0; l >= 0; --l, cur ^= 1) {
+        images_ready();                                                  // layer l's image (and everything written to LDS) is visible
+        const bf16_t* qcur = ra.qkv[l] + row0 * ld + hh * HD;
+        const bf16_t* qnx = l > 0 ? ra.qkv[l - 1] + row0 * ld + hh * HD : nullptr;
+        float lse_nx[(Tp + 191) / 192];                                  // next layer's log-sum-exps ride in registers
+        if (qnx) {
+            load_image(smem + (cur ^ 1) * (Tp * ROWB), qnx, ld, T, nt * 16);
+#pragma unroll
+            for (int i = 0; i < (Tp + 191) / 192; ++i) {
+                const int t = threadIdx.x + i * blockDim.x;
+                lse_nx[i] = (t < T) ? ra.lse[l - 1][(long)hh * Mtot + row0 + t] : INFINITY;
+            }
+        }
+        const char* qimg_c = smem + cur * (Tp * ROWB);
+        const float* lsec = lse_s + cur * Tp;
+        const float* wc = w_s + cur * Tp;
+        float* wn = w_s + (cur ^ 1) * Tp;
+        for (int k0 = w * 16; k0 < T; k0 += nw * 16) {
+            const int key = k0 + li;
+            short8_t kf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) kf[s] = kn[s];
+            // the next fragments: this layer's next key tile, or - on the wave's last tile - the next layer's first
+            const bool more = k0 + nw * 16 < T;
+            if (more || qnx) {
+                const bf16_t* src = more ? qcur : qnx;
+                const int r0 = more ? k0 + nw * 16 : w * 16;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) kn[s] = frag_own(src + D, ld, r0, T, s, lane);
+            }
+            float acc = 0.f;
+#pragma unroll 2
+            for (int u = 0; u < nt; ++u) {
+                float4_t s_ = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    s_ = mfma16<F16>(frag_k(qimg_c, u * 16, s, lane), kf[s], s_);
+                const float4 l4 = *reinterpret_cast<const float4*>(lsec + 16 * u + 4 * lg);
+                const float4 w4 = *reinterpret_cast<const float4*>(wc + 16 * u + 4 * lg);
+                acc = fmaf(__builtin_amdgcn_exp2f(s_[0] * sc - l4.x), w4.x, acc);
+                acc = fmaf(__builtin_amdgcn_exp2f(s_[1] * sc - l4.y), w4.y, acc);
+                acc = fmaf(__builtin_amdgcn_exp2f(s_[2] * sc - l4.z), w4.z, acc);
+                acc = fmaf(__builtin_amdgcn_exp2f(s_[3] * sc - l4.w), w4.w, acc);
+            }
+            acc = group_sum(acc);
+            if (lg == 0) {
+                if (l == 0) { if (key >= 1 && key < T) scores[(long)blockIdx.x * (T - 1) + key - 1] = acc; }
+                else wn[key] = key < T ? acc : 0.f;                      // (key < Tp: k0 + 15 < nt * 16)
+            }
+        }
+        if (qnx) {
+#pragma unroll
+            for (int i = 0; i < (Tp + 191) / 192; ++i) {
+                const int t = threadIdx.x + i * blockDim.x;
+                if (t < Tp) lse_s[(cur ^ 1) * Tp + t] = lse_nx[i];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Long sequences (T > 608: the joint HMA block of the 4-modal 512-token configuration, up to 4 x 513 = 2052 tokens).
 // The key range no longer fits the CU's LDS, so a workgroup owns 64 "own" rows (one 16-row tile per wave) and streams the
@@ -1150,7 +1246,47 @@ int rollout_step_h16(const uint16_t* qkv, const float* lse, const float* r_in, i
     return 0;
 }
 
+template <bool F16>
+int rollout_multi_h16(int L, const uint16_t* const* qkv, const float* const* lse, int B, int T, int heads, int hd, float scale,
+                      float* scores, hipStream_t stream)
+{
+    if (hd != HD || T < 2 || B < 1 || L < 1 || L > kMaxRollLayers || !qkv || !lse || !scores) return (int)hipErrorInvalidValue;
+    RolloutArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.L = L;
+    for (int l = 0; l < L; ++l) {
+        if (!qkv[l] || !lse[l]) return (int)hipErrorInvalidValue;
+        ra.qkv[l] = reinterpret_cast<const bf16_t*>(qkv[l]); ra.lse[l] = lse[l];
+    }
+    const int threads = pick_threads(T);
+    const long Mtot = (long)B * T;
+#define ROLLM_CASE(NTV) case NTV: {                                                                                  \
+        auto k = attn_rollout_multi_kernel<NTV, F16>;                                                                    \
+        const size_t lds = (size_t)2 * NTV * 16 * ROWB + (size_t)4 * NTV * 16 * sizeof(float);                          \
+        int rc = set_lds(k, lds); if (rc) return rc;                                                                     \
+        hipLaunchKernelGGL(k, dim3(B * heads), dim3(threads), lds, stream, ra, T, heads, scale, Mtot, scores);           \
+        break; }
+    switch (pick_nt(T)) {
+        ROLLM_CASE(10) ROLLM_CASE(14) ROLLM_CASE(26) ROLLM_CASE(38)
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef ROLLM_CASE
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
+
+extern "C" int editor_attn_rollout_multi_bf16(int L, const uint16_t* const* qkv, const float* const* lse, int B, int T, int heads,
+                                              int hd, float scale, float* scores, hipStream_t stream)
+{
+    return rollout_multi_h16<false>(L, qkv, lse, B, T, heads, hd, scale, scores, stream);
+}
+extern "C" int editor_attn_rollout_multi_f16(int L, const uint16_t* const* qkv, const float* const* lse, int B, int T, int heads,
+                                             int hd, float scale, float* scores, hipStream_t stream)
+{
+    return rollout_multi_h16<true>(L, qkv, lse, B, T, heads, hd, scale, scores, stream);
+}
 
 extern "C" int editor_attention_fwd_bf16(const uint16_t* qkv, int B, int T, int heads, int hd, float scale,
                                          const uint8_t* mask, uint16_t* out, float* probs, int ldp, float* lse,

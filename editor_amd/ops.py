@@ -55,12 +55,23 @@ def attn_rollout(probs):
     return scores
 
 
+ROLLOUT_MULTI = os.environ.get("EDITOR_ROLLOUT_MULTI", "1") != "0"    # measurement switch: 0 = one launch per layer
+
+
 def attn_rollout_qk(layers, b, t, heads, hd, scale=None):
     """Rollout scores (B, H, T-1) from the per-layer (qkv, lse) pairs of the bf16 backbone, first layer first:
     r = e_cls^T A_{L-1}; r <- r A_l for l = L-2 .. 0, each A_l recomputed on the fly (no probability tensor)."""
     dev = layers[0][0].device
-    bufs = [torch.empty(b * heads, t, dtype=torch.float32, device=dev) for _ in range(2)]
     scores = torch.empty(b, heads, t - 1, dtype=torch.float32, device=dev)
+    if ROLLOUT_MULTI and len(layers) <= 32:
+        # one launch for all layers (editor_attn_rollout_multi_*): r stays in LDS, the next layer's operands travel under this one's
+        n = len(layers)
+        qs = (ctypes.c_void_p * n)(*[q.data_ptr() for q, _ in layers])
+        ls = (ctypes.c_void_p * n)(*[l_.data_ptr() for _, l_ in layers])
+        with torch.cuda.device(dev):
+            call(_h16(layers[0][0], "attn_rollout_multi"), n, qs, ls, b, t, heads, hd, float(scale or hd ** -0.5), scores)
+        return scores
+    bufs = [torch.empty(b * heads, t, dtype=torch.float32, device=dev) for _ in range(2)]
     r_in = None
     for i, (qkv, lse) in enumerate(reversed(layers)):
         last = i == len(layers) - 1

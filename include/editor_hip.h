@@ -258,6 +258,13 @@ int editor_attention_fwd_f32(const float* qkv, int B, int T, int heads, int hd, 
 int editor_attention_bwd_f32(const float* qkv, const float* dout, const float* probs, int B, int T, int heads, int hd,
                              float scale, float* dqkv, float* workspace, editor_stream_t stream);
 
+/* The whole rollout in ONE launch (round 4): qkv / lse are HOST arrays of L device pointers, first layer first (layer l's packed
+ * qkv (B*T, 3*heads*64) and forward lse (heads*B*T)); scores (B*heads, T-1) <- the CLS->patch row of A_{L-1} ... A_0 per head.
+ * Same arithmetic and summation order as L calls of editor_attn_rollout_step_* (bit-identical); L <= 32. */
+int editor_attn_rollout_multi_bf16(int L, const uint16_t* const* qkv, const float* const* lse, int B, int T, int heads, int hd,
+                                   float scale, float* scores, editor_stream_t stream);
+int editor_attn_rollout_multi_f16(int L, const uint16_t* const* qkv, const float* const* lse, int B, int T, int heads, int hd,
+                                  float scale, float* scores, editor_stream_t stream);
 /* One step of the attention rollout (SFTS.py:150-153) WITHOUT materialised probabilities: r_out[bh][k] =
  * sum_q r_in[bh][q] * P_l[q,k], P_l recomputed from layer l's packed qkv (B*T, 3*heads*64) and the forward's lse
  * (heads*B*T).  r_in NULL = one-hot CLS row (first step, last layer).  final_step: r_out is (B*heads, T-1) and receives
