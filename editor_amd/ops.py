@@ -55,7 +55,11 @@ def attn_rollout(probs):
     return scores
 
 
-ROLLOUT_MULTI = os.environ.get("EDITOR_ROLLOUT_MULTI", "1") != "0"    # measurement switch: 0 = one launch per layer
+# all layers of the rollout in ONE launch (editor_attn_rollout_multi_*) instead of one per layer: bit-identical, 11 launches fewer,
+# and NOT faster - measured (round 4, same box, twice each) 43.96 / 43.99 ms per step with the per-layer launches against 44.05 /
+# 44.02 with the single one (a workgroup then walks twelve dependent layers with 43 KiB of LDS, four resident per CU instead of
+# seven).  Off by default; EDITOR_ROLLOUT_MULTI=1 switches it on.
+ROLLOUT_MULTI = os.environ.get("EDITOR_ROLLOUT_MULTI", "0") == "1"
 
 
 def attn_rollout_qk(layers, b, t, heads, hd, scale=None):
