@@ -875,6 +875,10 @@ def main():
                 roof["sclk_mhz_min_max_0p5ms"] = None if mhz[1] is None else [round(mhz[1][0], 0), round(mhz[1][1], 0)]
         if not args.no_replay:
             roof["hbm_kernels"], roof["hbm_kernels_in_situ_source"] = hbm_kernels(model, img, b, model.act_dtype)
+            roof["hbm_kernels_note"] = ("us / frac: this run, HIP events, every kernel rotating over `sets` operand sets > 512 MB (HBM, not the "
+                                        "256 MB Infinity Cache); in_situ_*: the same kernel's average duration inside the step, from the committed "
+                                        "rocprofv3 profile - there its operands were written by the previous kernel and are partly cache-resident "
+                                        "(a fraction above 1 is that, not a faster HBM)")
         out = {
             "metric": "tri-modal images/sec fwd+bwd @ B=128 ViT-B",
             "value": round(world * b * args.steps / elapsed, 2),
