@@ -350,7 +350,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // DKV pass (own = keys; LDS holds the Q and dO images + lse/delta of every query)
 // ---------------------------------------------------------------------------------------------------------
 template <int NT, bool F16, bool FULL>
-__global__ __launch_bounds__(256) void attn_kv_pass_kernel(AttnArgs a)
+// (amdgpu_waves_per_eu: with a lower bound of >= 2 waves per SIMD the register budget is <= 256 and LLVM selects the VGPR form of the
+//  MFMAs; without it the results land in AGPRs and every score / dP tile costs four v_accvgpr_read_b32 in a VALU-bound kernel)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void attn_kv_pass_kernel(AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Tp = NT * 16;
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(NT / 2 * 64) __attribute__((amdgpu_waves_per_eu(3, 
 // r_in == NULL: one-hot CLS row (the first step, l = L-1).  final: write r_out[1:] to a (BH, T-1) score tensor.
 // ---------------------------------------------------------------------------------------------------------
 template <int NT, bool F16>
-__global__ __launch_bounds__(256) void attn_rollout_step_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_rollout_step_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
     const float* __restrict__ r_in, int T, int heads, float scale, long Mtot, float* __restrict__ r_out, int final_step)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -762,7 +764,7 @@ constexpr int kMaxRollLayers = 32;
 struct RolloutArgs { const bf16_t* qkv[kMaxRollLayers]; const float* lse[kMaxRollLayers]; int L; };
 
 template <int NT, bool F16>
-__global__ __launch_bounds__(256) void attn_rollout_multi_kernel(RolloutArgs ra, int T, int heads, float scale, long Mtot,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_rollout_multi_kernel(RolloutArgs ra, int T, int heads, float scale, long Mtot,
                                                                  float* __restrict__ scores)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -860,7 +862,7 @@ __global__ __launch_bounds__(256) void attn_rollout_multi_kernel(RolloutArgs ra,
 constexpr int LCH = 256;
 
 template <bool BWD, bool F16>
-__global__ __launch_bounds__(256) void attn_q_long_kernel(AttnArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_q_long_kernel(AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* kimg = smem;
@@ -975,7 +977,7 @@ __global__ __launch_bounds__(256) void attn_q_long_kernel(AttnArgs a)
 }
 
 template <bool F16>
-__global__ __launch_bounds__(256) void attn_kv_long_kernel(AttnArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void attn_kv_long_kernel(AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* qimg = smem;
@@ -1149,9 +1151,11 @@ int launch_all(const AttnArgs& a_in, int B, int mode, hipStream_t stream)
         EDITOR_LAUNCH_CHECK();
         const size_t lds2 = img + (size_t)2 * NT * 16 * sizeof(float);          // images | lse, delta | staging
         if (full) {
-            auto k2 = attn_kv_pass_kernel<NT, F16, true>;
-            if ((rc = set_lds(k2, lds2))) return rc;
-            hipLaunchKernelGGL(k2, grid, dim3(threads), lds2, stream, a);
+            if constexpr (NT <= 14) {                    // (`full` implies it; the unrolled form of longer sequences is not built)
+                auto k2 = attn_kv_pass_kernel<NT, F16, true>;
+                if ((rc = set_lds(k2, lds2))) return rc;
+                hipLaunchKernelGGL(k2, grid, dim3(threads), lds2, stream, a);
+            }
         } else {
             auto k2 = attn_kv_pass_kernel<NT, F16, false>;
             if ((rc = set_lds(k2, lds2))) return rc;

@@ -33,7 +33,7 @@ constexpr int SCH = 128;                  // key chunk of the streamed form
 constexpr float kPScale = 4096.f;         // 2^12
 
 template <bool MULTI>
-__global__ __launch_bounds__(256) void attn_fwd_split_kernel(SplitAttnArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_fwd_split_kernel(SplitAttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int cap = a.cap;
@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256) void attn_fwd_split_kernel(SplitAttnArgs a)
 // exponential - the streamed form above recomputes the scores in its second sweep and pays the running-max rescales of the
 // first (measured at T = 129, B = 384: 309 us per layer against 79 us for the 16-bit kernel; this form: see DESIGN.md).
 template <int NT>
-__global__ __launch_bounds__(256) void attn_fwd_split_reg_kernel(SplitAttnArgs a)
+// (waves_per_eu >= 2: VGPR-form MFMAs, no v_accvgpr_read_b32 per score element - see attn_kv_pass_kernel)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 10 ? 3 : 2, 8))) void attn_fwd_split_reg_kernel(SplitAttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Tp = NT * 16;
@@ -332,6 +333,79 @@ __global__ __launch_bounds__(256) void attn_fwd_split_reg_kernel(SplitAttnArgs a
     }
 }
 
+// Rollout step of the split-precision mode (SFTS.py:150-153, row-vector form; round 4): r_out[k] = sum_q r_in[q] P_l[q,k] with
+// P_l RECOMPUTED from layer l's q / k half pairs and the forward's row log-sum-exp, P[q,k] = exp2(s[q,k] - lse[q]), s the same
+// three-pass fp32-class score the forward formed (Q_lo K_hi + Q_hi K_lo + Q_hi K_hi) - instead of read from the materialised
+// (L,3B,h,T,T) fp32 probabilities (3.8 GB written by the forward and read back at B = 128).  Skeleton of the 16-bit
+// attn_rollout_step_kernel (attention_bf16.hip): own = keys, the Q pair images + lse + r_in in LDS.
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_rollout_step_split_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
+    const float* __restrict__ lse, const float* __restrict__ r_in, int T, int heads, float scale, long Mtot, float* __restrict__ r_out,
+    int final_step)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Tp = NT * 16;
+    char* qhi = smem;
+    char* qlo = smem + Tp * ROWB;
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * Tp * ROWB);
+    float* w_s = lse_s + Tp;
+    const int D = heads * HD;
+    const int b = blockIdx.x / heads, hh = blockIdx.x % heads;
+    const long ld = 3L * D;
+    const long row0 = (long)b * T;
+    const int nt = min(NT, ((T + 31) >> 5) << 1);
+    const bf16_t* bh = qkv_hi + row0 * ld + hh * HD;
+    const bf16_t* bl = qkv_lo + row0 * ld + hh * HD;
+    load_image(qhi, bh, ld, T, nt * 16);
+    load_image(qlo, bl, ld, T, nt * 16);
+    for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
+        lse_s[t] = t < T ? lse[(long)hh * Mtot + row0 + t] : INFINITY;          // +inf (pad rows, dead queries) -> probability 0
+        w_s[t] = t < T ? (r_in ? r_in[(long)blockIdx.x * T + t] : (t == 0 ? 1.f : 0.f)) : 0.f;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    short8_t knh[2], knl[2];                                       // own key fragments: first tile's travel with the images
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { knh[s] = frag_own(bh + D, ld, w * 16, T, s, lane); knl[s] = frag_own(bl + D, ld, w * 16, T, s, lane); }
+    images_ready();
+    const int li = lane & 15, lg = lane >> 4;
+    const float sc = scale * kLog2e;
+    for (int k0 = w * 16; k0 < T; k0 += nw * 16) {
+        const int key = k0 + li;
+        short8_t kh[2], kl[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { kh[s] = knh[s]; kl[s] = knl[s]; }
+        if (k0 + nw * 16 < T) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                knh[s] = frag_own(bh + D, ld, k0 + nw * 16, T, s, lane); knl[s] = frag_own(bl + D, ld, k0 + nw * 16, T, s, lane);
+            }
+        }
+        float acc = 0.f;
+#pragma unroll 2
+        for (int u = 0; u < nt; ++u) {
+            float4_t s_ = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {                          // lane (i, g): queries 16u + 4g + r  x  key k0 + i
+                const short8_t fh = frag_k(qhi, u * 16, s, lane), fl = frag_k(qlo, u * 16, s, lane);
+                s_ = mfma16<true>(fl, kh[s], s_);
+                s_ = mfma16<true>(fh, kl[s], s_);
+                s_ = mfma16<true>(fh, kh[s], s_);
+            }
+            const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * u + 4 * lg);
+            const float4 w4 = *reinterpret_cast<const float4*>(w_s + 16 * u + 4 * lg);
+            acc = fmaf(__builtin_amdgcn_exp2f(s_[0] * sc - l4.x), w4.x, acc);
+            acc = fmaf(__builtin_amdgcn_exp2f(s_[1] * sc - l4.y), w4.y, acc);
+            acc = fmaf(__builtin_amdgcn_exp2f(s_[2] * sc - l4.z), w4.z, acc);
+            acc = fmaf(__builtin_amdgcn_exp2f(s_[3] * sc - l4.w), w4.w, acc);
+        }
+        acc = group_sum(acc);
+        if (lg == 0 && key < T) {
+            if (final_step) { if (key >= 1) r_out[(long)blockIdx.x * (T - 1) + key - 1] = acc; }
+            else r_out[(long)blockIdx.x * T + key] = acc;
+        }
+    }
+}
+
 template <auto KERN>
 int set_lds_dev(size_t bytes)
 {
@@ -377,6 +451,29 @@ extern "C" int editor_attention_fwd_f16x2(const uint16_t* qkv_hi, const uint16_t
         if (int rc = set_lds_dev<attn_fwd_split_kernel<true>>(lds)) return rc;
         hipLaunchKernelGGL(attn_fwd_split_kernel<true>, dim3(B * heads, (T + 63) / 64), dim3(256), lds, stream, a);
     }
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_attn_rollout_step_f16x2(const uint16_t* qkv_hi, const uint16_t* qkv_lo, const float* lse, const float* r_in,
+    int B, int T, int heads, int hd, float scale, float* r_out, int final_step, hipStream_t stream)
+{
+    if (hd != HD || T < 2 || B < 1 || !qkv_hi || !qkv_lo || !lse || !r_out) return (int)hipErrorInvalidValue;
+    const int tiles = (T + 15) / 16;
+    const int threads = (tiles % 3 == 0) ? 192 : 256;
+    const dim3 grid(B * heads);
+    const long Mtot = (long)B * T;
+#define ROLL_CASE(NTV) {                                                                                                \
+        const size_t lds = (size_t)2 * NTV * 16 * ROWB + (size_t)2 * NTV * 16 * sizeof(float);                             \
+        if (int rc = set_lds_dev<attn_rollout_step_split_kernel<NTV>>(lds)) return rc;                                    \
+        hipLaunchKernelGGL(attn_rollout_step_split_kernel<NTV>, grid, dim3(threads), lds, stream, qkv_hi, qkv_lo, lse, r_in, T, \
+                           heads, scale, Mtot, r_out, final_step); }
+    if (T <= 160) ROLL_CASE(10)
+    else if (T <= 224) ROLL_CASE(14)
+    else if (T <= 416) ROLL_CASE(26)
+    else if (T <= 608) ROLL_CASE(38)
+    else return (int)hipErrorInvalidValue;                            // the backbone's sequences are <= 608 tokens
+#undef ROLL_CASE
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

@@ -90,7 +90,7 @@ __device__ __forceinline__ void store_tile(const TileRegs& t, int trans, float (
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void gemm_f32_kernel(GemmArgs g)
 {
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDT];

@@ -318,6 +318,8 @@ class TransformerBlockFn(torch.autograd.Function):
             (ao, aol), attn_saved = ops.attention_fwd_split((qkv, qkvl), b, t, heads, hd, amask,
                                                             None if isinstance(probs_out, list) else probs_out, cu=cu,
                                                             scale=qk_scale)
+            if isinstance(probs_out, list):            # no probability tensor: the rollout recomputes it from the q / k pairs
+                probs_out.append((qkv, qkvl, attn_saved))
             del qkvl
             head_done, split_all = head_only, not head_only
         if head_done:

@@ -319,6 +319,8 @@ class EDITOR(nn.Module):
         self.branch16 = bool(getattr(cfg.MODEL, "BRANCH16", b16_default)) and self.act_dtype in (torch.bfloat16, torch.float16) \
             and not self.split_fwd and not self.bb_attn_f32 and dim % 256 == 0
         self.rollout_probs = bool(getattr(cfg.MODEL, "ROLLOUT_PROBS", False))
+        self.split_rollout_recompute = bool(getattr(cfg.MODEL, "SPLIT_ROLLOUT_RECOMPUTE",
+                                                    os.environ.get("EDITOR_SPLIT_ROLLOUT") == "1"))
         self.teacher_index = None            # optional (B,N) bool: force the SFTS selection (bf16 protocol)
         self.grad_buckets = None             # editor_amd.ddp.GradBuckets once enable_grad_buckets() was called
         self._drop_rates_dev = None
@@ -384,8 +386,13 @@ class EDITOR(nn.Module):
         # f32 parity mode: the (L,3B,h,T,T) softmax outputs are materialised as the reference does.  bf16 mode: every
         # block hands back its (qkv, row log-sum-exp) instead and the rollout recomputes the probabilities from them
         # (cfg.MODEL.ROLLOUT_PROBS = True keeps the materialised form: rows padded to a multiple of 4 floats).
-        # (split-precision mode: the fp32 probabilities of the split attention kernel are materialised, as in f32 mode)
-        recompute = self.act_dtype != torch.float32 and not self.rollout_probs and not self.split_fwd and not self.bb_attn_f32
+        # (split-precision mode: the fp32 probabilities of the split attention kernel are materialised, as in f32 mode.  Round 4
+        # built the recomputing form for it too - editor_attn_rollout_step_f16x2, scores from the q / k half PAIRS in three passes -
+        # and measured it in the step: 61.9 / 65.1 ms against 61.1 - 62.0 / 64.7 - 65.0, i.e. nothing (a step then reads 304 MB of
+        # operand pairs where the probabilities were 314 MB), and its scores are 8x less accurate (6e-7 against 8e-8: one lse
+        # rounding per row).  cfg.MODEL.SPLIT_ROLLOUT_RECOMPUTE / EDITOR_SPLIT_ROLLOUT=1 selects it: 1.1 GB less at B = 128.)
+        recompute = self.act_dtype != torch.float32 and not self.rollout_probs and not self.bb_attn_f32 and \
+            (not self.split_fwd or self.split_rollout_recompute)
         ldp = t if (self.act_dtype == torch.float32 or self.bb_attn_f32) else (t + 3) // 4 * 4
         probs = [] if recompute else torch.empty(base.depth, btot, base.heads, t, ldp, dtype=torch.float32,
                                                  device=dev)

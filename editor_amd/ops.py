@@ -67,7 +67,7 @@ def attn_rollout_qk(layers, b, t, heads, hd, scale=None):
     r = e_cls^T A_{L-1}; r <- r A_l for l = L-2 .. 0, each A_l recomputed on the fly (no probability tensor)."""
     dev = layers[0][0].device
     scores = torch.empty(b, heads, t - 1, dtype=torch.float32, device=dev)
-    if ROLLOUT_MULTI and len(layers) <= 32:
+    if ROLLOUT_MULTI and len(layers) <= 32 and all(len(l_) == 2 for l_ in layers):
         # one launch for all layers (editor_attn_rollout_multi_*): r stays in LDS, the next layer's operands travel under this one's
         n = len(layers)
         qs = (ctypes.c_void_p * n)(*[q.data_ptr() for q, _ in layers])
@@ -77,11 +77,17 @@ def attn_rollout_qk(layers, b, t, heads, hd, scale=None):
         return scores
     bufs = [torch.empty(b * heads, t, dtype=torch.float32, device=dev) for _ in range(2)]
     r_in = None
-    for i, (qkv, lse) in enumerate(reversed(layers)):
+    for i, layer in enumerate(reversed(layers)):
         last = i == len(layers) - 1
         out = scores if last else bufs[i & 1]
-        call(_h16(qkv, "attn_rollout_step"), qkv, lse, r_in, b, t, heads, hd, float(scale or hd ** -0.5), out,
-             1 if last else 0)
+        if len(layer) == 3:         # split-precision layer: (qkv_hi, qkv_lo, lse) - scores in three passes, fp32-class
+            qkv, qkv_lo, lse = layer
+            call("editor_attn_rollout_step_f16x2", qkv, qkv_lo, lse, r_in, b, t, heads, hd, float(scale or hd ** -0.5), out,
+                 1 if last else 0)
+        else:
+            qkv, lse = layer
+            call(_h16(qkv, "attn_rollout_step"), qkv, lse, r_in, b, t, heads, hd, float(scale or hd ** -0.5), out,
+                 1 if last else 0)
         r_in = out
     return scores
 

@@ -297,6 +297,12 @@ int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const u
 int editor_attention_fwd_f16x2(const uint16_t* qkv_hi, const uint16_t* qkv_lo, int B, int T, int heads, int hd, float scale,
                                const uint8_t* mask, uint16_t* out_hi, uint16_t* out_lo, float* probs, int ldp, float* lse,
                                const int* cu, long Mtot, editor_stream_t stream);
+/* One rollout step (SFTS.py:150-153) of the split-precision mode WITHOUT materialised probabilities (round 4): as
+ * editor_attn_rollout_step_f16, with the scores formed from layer l's q / k half PAIRS in three MFMA passes (fp32-class, the
+ * forward's own S) and P = exp2(S - lse) with the lse editor_attention_fwd_f16x2 wrote - the (L,3B,h,T,T) fp32 probability tensor
+ * (vit_pytorch.py:638-644) is then never written.  Dense, unmasked sequences, T <= 608. */
+int editor_attn_rollout_step_f16x2(const uint16_t* qkv_hi, const uint16_t* qkv_lo, const float* lse, const float* r_in, int B,
+                                   int T, int heads, int hd, float scale, float* r_out, int final_step, editor_stream_t stream);
 int editor_attention_fwd_f16(const uint16_t* qkv, int B, int T, int heads, int hd, float scale, const uint8_t* mask,
                              uint16_t* out, float* probs, int ldp, float* lse, const int* cu, long Mtot,
                              editor_stream_t stream);

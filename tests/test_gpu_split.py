@@ -149,6 +149,40 @@ def test_attention_f16x2_dense_vs_float64(t):
     assert rel_err(o16.double().cpu(), ref) < 2e-3
 
 
+@pytest.mark.parametrize("t", [129, 193, 513])
+def test_rollout_f16x2_recomputed_from_pairs(t):
+    """Round 4: the split-precision rollout recomputes every layer's probabilities from the q / k half pairs and the forward's lse
+    (editor_attn_rollout_step_f16x2) instead of reading the materialised fp32 probabilities: both against the float64 rollout
+    (SFTS.py:150-153: CLS row of A_{L-1} ... A_0 without the CLS column) - fp32-class, and no worse than the materialised form."""
+    from editor_amd import ops
+    b, heads, hd, layers = 3, 12, 64, 4
+    g = torch.Generator().manual_seed(100 + t)
+    ldp = (t + 3) // 4 * 4
+    probs = torch.zeros(layers, b, heads, t, ldp, device="cuda")
+    triples, refs = [], []
+    for l in range(layers):
+        qkv = torch.randn(b * t, 3 * heads * hd, generator=g) * 0.8
+        pair = _pair(qkv)
+        _, lse = ops.attention_fwd_split(pair, b, t, heads, hd, None, probs[l])
+        triples.append((pair[0], pair[1], lse))
+        refs.append(torch.stack(_attn_ref(qkv, b, t, heads)[1]))           # (b, heads, t, t) float64
+    r = refs[-1][:, :, 0:1, :]                                              # CLS row of the last layer
+    for l in range(layers - 2, -1, -1):
+        r = r @ refs[l]
+    ref = r[:, :, 0, 1:]
+    got = ops.attn_rollout_qk(triples, b, t, heads, hd)
+    mat = ops.attn_rollout(probs)
+    assert got.shape == (b, heads, t - 1)
+    e_got, e_mat = rel_err(got.double().cpu(), ref), rel_err(mat.double().cpu(), ref)
+    print("rollout f16x2 T=%d: recomputed %.2e materialised %.2e" % (t, e_got, e_mat))
+    assert e_got < 2e-6 and e_mat < 5e-7        # measured 6.4e-7 / 7.9e-8 at T = 129: one lse rounding per row vs exp2(s - max) / sum
+    # a single step, non-final form: r_out (B*heads, T) = CLS row of the last layer's map
+    one = torch.empty(b * heads, t, device="cuda")
+    ops.call("editor_attn_rollout_step_f16x2", triples[-1][0], triples[-1][1], triples[-1][2], None, b, t, heads, hd, hd ** -0.5,
+             one, 0)
+    assert rel_err(one.view(b, heads, t).double().cpu(), refs[-1][:, :, 0, :]) < 2e-6
+
+
 def test_attention_f16x2_masked_and_varlen():
     from editor_amd import ops
     b, t, heads, hd = 4, 129, 12, 64
