@@ -32,28 +32,32 @@ namespace {
 // (block size, occupancy and 20 % less arithmetic all left their time unchanged; without the global loads / stores of the
 // own side they ran 15-25 % faster).  Here the tile is parked in 2.5 KiB of the wave's own LDS (rows padded to 160 bytes:
 // the 8-byte column writes of 8 rows hit disjoint banks) and leaves as 16 bytes per lane, 8 lanes per full 128-byte row.
-constexpr int STG_ROW = 160, STG_BYTES = 16 * STG_ROW;
+constexpr int STG_ROW = ROWB + 32, STG_BYTES = 16 * STG_ROW;      // (HD = 64: rows of 160 bytes)
+constexpr int STG_LPR = CPR <= 4 ? 4 : (CPR <= 8 ? 8 : 16);      // lanes per staged row on the way out (16 bytes each)
 template <bool F16>
-__device__ __forceinline__ void store_tile(char* stg, const float4_t (&o)[4], bf16_t* dst, long ldo, int nrows, int lane)
+__device__ __forceinline__ void store_tile(char* stg, const float4_t (&o)[ND], bf16_t* dst, long ldo, int nrows, int lane)
 {
     const int li = lane & 15, lg = lane >> 4;
     if (!stg) {                                      // no LDS left for staging (608-token images), or forward (see launch_all)
         if (li < nrows) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < ND; ++dt)
                 *reinterpret_cast<uint2*>(dst + (long)li * ldo + dt * 16 + 4 * lg) = pack4<F16>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
         }
         return;
     }
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < ND; ++dt)
         *reinterpret_cast<uint2*>(stg + li * STG_ROW + dt * 32 + lg * 8) = pack4<F16>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
     // (same wave wrote and reads: the compiler's lgkmcnt wait orders the two; no barrier)
+    constexpr int RPP = 64 / STG_LPR;                // rows per pass (HD = 64: 8 rows of 8 lanes, two passes)
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int row = pass * 8 + (lane >> 3), ch = lane & 7;
-        const uint4 v = *reinterpret_cast<const uint4*>(stg + row * STG_ROW + ch * 16);
-        if (row < nrows) *reinterpret_cast<uint4*>(dst + (long)row * ldo + ch * 8) = v;
+    for (int pass = 0; pass < 16 / RPP; ++pass) {
+        const int row = pass * RPP + lane / STG_LPR, ch = lane % STG_LPR;
+        if (CPR == STG_LPR || ch < CPR) {
+            const uint4 v = *reinterpret_cast<const uint4*>(stg + row * STG_ROW + ch * 16);
+            if (row < nrows) *reinterpret_cast<uint4*>(dst + (long)row * ldo + ch * 8) = v;
+        }
     }
 }
 
@@ -91,7 +95,7 @@ __device__ __forceinline__ uint32_t nibble_of(const KeyBits& kb, int t)
 // is valid iff it lies inside the sequence - then validity is one integer compare per key against a per-lane limit
 // instead of a per-lane bitmap (whose 64-bit shifts and SGPR traffic were ~1/3 of the forward's VALU + SALU work).
 template <int NT, bool BWD, bool FULL, bool F16, bool MASKED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_q_pass_kernel(AttnArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 4 : 3, 8))) void attn_q_pass_kernel(AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Tp = NT * 16;
@@ -109,9 +113,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     // the wave's first own-side (query) fragments are requested together with the images, the next tile's at the top of each
     // tile: their HBM latency used to be paid in front of every 16-query tile, after the images had already been waited for
-    short8_t qnext[2];
+    short8_t qnext[KS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) qnext[s] = frag_own(qbase, ld, w * 16, T, s, lane);
+    for (int s = 0; s < KS; ++s) qnext[s] = frag_own(qbase, ld, w * 16, T, s, lane);
     images_ready();
 
     const int li = lane & 15, lg = lane >> 4;
@@ -144,12 +148,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     for (int q0 = w * 16; q0 < T; q0 += nw * 16) {
         const int q = q0 + li;
         const bool qok = q < T && (!mk || mk[q]);
-        short8_t qf[2];
+        short8_t qf[KS];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) qf[s] = qnext[s];
+        for (int s = 0; s < KS; ++s) qf[s] = qnext[s];
         if (q0 + nw * 16 < T) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) qnext[s] = frag_own(qbase, ld, q0 + nw * 16, T, s, lane);
+            for (int s = 0; s < KS; ++s) qnext[s] = frag_own(qbase, ld, q0 + nw * 16, T, s, lane);
         }
         float lse;                                        // log2-sum-exp2 of the scaled scores of row q
         if constexpr (!BWD && NT <= 14) {
@@ -163,13 +167,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 // the scheduling barrier keeps the compiler from hoisting ALL reads up front (163 VGPRs, half the occupancy)
 #pragma unroll
                 for (int t = 0; t < NT; t += 2) {
-                    const short8_t a0 = frag_k(kimg, t * 16, 0, lane), a1 = frag_k(kimg, t * 16, 1, lane);
-                    const short8_t b0 = frag_k(kimg, t * 16 + 16, 0, lane), b1 = frag_k(kimg, t * 16 + 16, 1, lane);
                     float4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    acc0 = mfma16<F16>(a0, qf[0], acc0);
-                    acc1 = mfma16<F16>(b0, qf[0], acc1);
-                    acc0 = mfma16<F16>(a1, qf[1], acc0);
-                    acc1 = mfma16<F16>(b1, qf[1], acc1);
+                    if constexpr (KS == 2) {
+                        const short8_t a0 = frag_k(kimg, t * 16, 0, lane), a1 = frag_k(kimg, t * 16, 1, lane);
+                        const short8_t b0 = frag_k(kimg, t * 16 + 16, 0, lane), b1 = frag_k(kimg, t * 16 + 16, 1, lane);
+                        acc0 = mfma16<F16>(a0, qf[0], acc0);
+                        acc1 = mfma16<F16>(b0, qf[0], acc1);
+                        acc0 = mfma16<F16>(a1, qf[1], acc0);
+                        acc1 = mfma16<F16>(b1, qf[1], acc1);
+                    } else {                                  // other head widths: KS k-steps of 32
+                        short8_t ka[KS], kb2[KS];
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) { ka[s] = frag_k(kimg, t * 16, s, lane); kb2[s] = frag_k(kimg, t * 16 + 16, s, lane); }
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) {
+                            acc0 = mfma16<F16>(ka[s], qf[s], acc0);
+                            acc1 = mfma16<F16>(kb2[s], qf[s], acc1);
+                        }
+                    }
                     // FULL launches are unmasked and populate all NT tiles (T > 16 (NT - 2)): only the last two tiles can
                     // hold keys beyond the sequence end; the others take no compare / select at all
                     const uint32_t vb0 = (t < NT - 2) ? 0xfu : vbits(t), vb1 = (t + 1 < NT - 2) ? 0xfu : vbits(t + 1);
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 if (t < nt) {
                     float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int s = 0; s < 2; ++s)
+                    for (int s = 0; s < KS; ++s)
                         acc = mfma16<F16>(frag_k(kimg, t * 16, s, lane), qf[s], acc);
                     const uint32_t vb = vbits(t);
 #pragma unroll
@@ -214,9 +229,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             lse = live ? M + __builtin_amdgcn_logf(L) : INFINITY;
             if (a.lse && lg == 0 && q < T) a.lse[row_idx0 + q] = lse;
             float* pr = (a.probs && q < T) ? a.probs + (prow0 + q) * a.ldp : nullptr;
-            float4_t o[4];
+            float4_t o[ND];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+            for (int dt = 0; dt < ND; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s2 = 0; s2 < NT / 2; ++s2)
                 if (FULL || 2 * s2 < nt) {
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     }
                     const short8_t pf = join(pk[0], pk[1]);
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
+                    for (int dt = 0; dt < ND; ++dt)
                         o[dt] = mfma16<F16>(frag_t(vimg, s2, dt, lane), pf, o[dt]);
                     if (FULL) __builtin_amdgcn_sched_barrier(0);
                 }
@@ -244,7 +259,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             for (int t = 0; t < nt; ++t) {
                 float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < KS; ++s)
                     acc = mfma16<F16>(frag_k(kimg, t * 16, s, lane), qf[s], acc);
                 float sv[4], tm = -INFINITY;
                 const uint32_t vb = vbits(t);
@@ -265,12 +280,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
 
         float dl = 0.f;
-        short8_t dof[2];
+        short8_t dof[KS];
         if (BWD) {   // delta[q] = sum_d dO[q,d] * O[q,d]
             const bf16_t* dobase = a.dout + row0 * D + hh * HD;
             const bf16_t* obase = a.out_fwd + row0 * D + hh * HD;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < KS; ++s) {
                 dof[s] = frag_own(dobase, D, q0, T, s, lane);
                 const short8_t of = frag_own(obase, D, q0, T, s, lane);
 #pragma unroll
@@ -283,9 +298,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         float* pr = (!BWD && a.probs && q < T) ? a.probs + (prow0 + q) * a.ldp : nullptr;
 
         // ---- sweep 2: P^T tiles from lse; FWD: O^T += V^T P^T ; BWD: dS^T, dQ^T += K^T dS^T ----------------------
-        float4_t o[4];
+        float4_t o[ND];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < ND; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
         // one pair of key tiles; CHECK = false for pairs that cannot hold a key beyond the sequence end (unmasked sequences:
         // every pair but the last) - no compare / select per key there
         auto pair = [&](int s2, auto chk) {
@@ -296,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 const int t = 2 * s2 + half;
                 float4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                for (int s = 0; s < KS; ++s) {
                     acc = mfma16<F16>(frag_k(kimg, t * 16, s, lane), qf[s], acc);
                     if (BWD) dp = mfma16<F16>(frag_k(vimg, t * 16, s, lane), dof[s], dp);
                 }
@@ -318,7 +333,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const short8_t pf = join(pk[0], pk[1]);
             const char* timg = BWD ? kimg : vimg;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < ND; ++dt)
                 o[dt] = mfma16<F16>(frag_t(timg, s2, dt, lane), pf, o[dt]);
         };
         const int npair = nt / 2;
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
         if (BWD) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] *= a.scale;
+            for (int dt = 0; dt < ND; ++dt) o[dt] *= a.scale;
             store_tile<F16>(stg, o, a.dqkv + (row0 + q0) * ld + hh * HD, ld, T - q0, lane);
         } else {
             store_tile<F16>(stg, o, a.out + (row0 + q0) * D + hh * HD, D, T - q0, lane);
@@ -352,7 +367,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 template <int NT, bool F16, bool FULL>
 // (amdgpu_waves_per_eu: with a lower bound of >= 2 waves per SIMD the register budget is <= 256 and LLVM selects the VGPR form of the
 //  MFMAs; without it the results land in AGPRs and every score / dP tile costs four v_accvgpr_read_b32 in a VALU-bound kernel)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void attn_kv_pass_kernel(AttnArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 3 : 2, 8))) void attn_kv_pass_kernel(AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Tp = NT * 16;
@@ -386,33 +401,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         const int key = k0 + li;
         const bool kok = key < T && (!mk || mk[key]);
         // (requesting these one tile ahead, as the query pass does with its own fragments, was not faster: 143 us against 124-135)
-        short8_t kf[2], vf[2];
+        short8_t kf[KS], vf[KS];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < KS; ++s) {
             kf[s] = frag_own(qbase + D, ld, k0, T, s, lane);
             vf[s] = frag_own(qbase + 2 * D, ld, k0, T, s, lane);
         }
-        float4_t dv[4], dk[4];
+        float4_t dv[ND], dk[ND];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { dv[dt] = float4_t{0.f, 0.f, 0.f, 0.f}; dk[dt] = dv[dt]; }
+        for (int dt = 0; dt < ND; ++dt) { dv[dt] = float4_t{0.f, 0.f, 0.f, 0.f}; dk[dt] = dv[dt]; }
         // k-major fragments of one pair of query tiles (8 x ds_read_b128)
-        auto qload = [&](int u2, short8_t (&fq)[2][2], short8_t (&fd)[2][2]) {
+        auto qload = [&](int u2, short8_t (&fq)[2][KS], short8_t (&fd)[2][KS]) {
 #pragma unroll
             for (int half = 0; half < 2; ++half)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                for (int s = 0; s < KS; ++s) {
                     fq[half][s] = frag_k(qimg, (2 * u2 + half) * 16, s, lane);
                     fd[half][s] = frag_k(doimg, (2 * u2 + half) * 16, s, lane);
                 }
         };
-        auto qcompute = [&](int u2, short8_t (&fq)[2][2], short8_t (&fd)[2][2]) {
+        auto qcompute = [&](int u2, short8_t (&fq)[2][KS], short8_t (&fd)[2][KS]) {
             uint2 pk[2], dsk[2];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int u = 2 * u2 + half;
                 float4_t s_ = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                for (int s = 0; s < KS; ++s) {
                     s_ = mfma16<F16>(fq[half][s], kf[s], s_);
                     dp = mfma16<F16>(fd[half][s], vf[s], dp);
                 }
@@ -436,7 +451,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             }
             const short8_t pf = join(pk[0], pk[1]), df = join(dsk[0], dsk[1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < ND; ++dt) {
                 dv[dt] = mfma16<F16>(frag_t(doimg, u2, dt, lane), pf, dv[dt]);
                 dk[dt] = mfma16<F16>(frag_t(qimg, u2, dt, lane), df, dk[dt]);
             }
@@ -444,7 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         if constexpr (FULL && ATTN_UNROLL_BWD) {
             // dense backbone call: compile-time trip count and the fragments double-buffered in registers - the reads of
             // pair u2+1 are in flight under the MFMAs / exponentials of pair u2 (the rolled loop: read -> wait -> MFMA)
-            short8_t fq[2][2][2], fd[2][2][2];
+            short8_t fq[2][2][KS], fd[2][2][KS];
             qload(0, fq[0], fd[0]);
 #pragma unroll
             for (int u2 = 0; u2 < NT / 2; ++u2) {
@@ -458,7 +473,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             for (int u2 = 0; u2 < nt / 2; ++u2) {
                 // the eight k-major fragments of this pair of query tiles are requested together, ahead of the eight MFMAs
                 // (left to itself the compiler reads one fragment ahead: read -> wait -> MFMA, LDS latency each time)
-                short8_t fq[2][2], fd[2][2];
+                short8_t fq[2][KS], fd[2][KS];
                 qload(u2, fq, fd);
                 __builtin_amdgcn_sched_barrier(0);
                 qcompute(u2, fq, fd);
@@ -468,7 +483,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             char* stg = a.stage_out ? smem + 2 * Tp * ROWB + 2 * Tp * sizeof(float) + w * STG_BYTES : nullptr;
             bf16_t* kdst = a.dqkv + (row0 + k0) * ld + D + hh * HD;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dk[dt] *= a.scale;
+            for (int dt = 0; dt < ND; ++dt) dk[dt] *= a.scale;
             store_tile<F16>(stg, dk, kdst, ld, T - k0, lane);
             store_tile<F16>(stg, dv, kdst + D, ld, T - k0, lane);
         }
@@ -499,6 +514,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 // the kernel is bound by exposed LDS / MFMA / exp latency, not by the arithmetic it saves.  The two-pass waves never
 // meet a barrier after the image load.  Kept as the worked-out answer to "fuse it with <= 80 KB of LDS" (VERDICT r2 item 3).
 // ---------------------------------------------------------------------------------------------------------
+#if ATTN_HD == 64                              // (the fused form exists for the backbone's 64-wide heads only)
 constexpr int FB_DS_ROW = 72;                  // bytes per key row of the dS chunk: 32 queries x 2 B + 8 (rows shift by 18 banks)
 constexpr int FB_DQ_ROW = 144;                 // bytes per query row of the dQ staging tile: 64 x 2 B + 16
 template <int NT> constexpr size_t fused_bwd_lds()
@@ -539,7 +555,7 @@ __global__ __launch_bounds__(NT / 2 * 64) __attribute__((amdgpu_waves_per_eu(3, 
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) vf[j][s] = frag_own(qbase + 2 * D, ld, k0 + 16 * j, T, s, lane);
+        for (int s = 0; s < KS; ++s) vf[j][s] = frag_own(qbase + 2 * D, ld, k0 + 16 * j, T, s, lane);
     // lse and delta of every query (the dQ pass's expression and summation order)
     {
         const bf16_t* obase = a.out_fwd + row0 * D + hh * HD;
@@ -548,7 +564,7 @@ __global__ __launch_bounds__(NT / 2 * 64) __attribute__((amdgpu_waves_per_eu(3, 
             const int q = q0 + li;
             float dl = 0.f;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < KS; ++s) {
                 const short8_t dof = frag_own(dobase, D, q0, T, s, lane);
                 const short8_t of = frag_own(obase, D, q0, T, s, lane);
 #pragma unroll
@@ -570,7 +586,7 @@ __global__ __launch_bounds__(NT / 2 * 64) __attribute__((amdgpu_waves_per_eu(3, 
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { dv[j][dt] = float4_t{0.f, 0.f, 0.f, 0.f}; dk[j][dt] = dv[j][dt]; }
+        for (int dt = 0; dt < ND; ++dt) { dv[j][dt] = float4_t{0.f, 0.f, 0.f, 0.f}; dk[j][dt] = dv[j][dt]; }
     // (K image rows beyond the end are copies of the last row, see load_image: an invalid key's P and dS are forced to zero -
     //  the wave-uniform `edge` keeps the compare / select off the tiles that cannot hold one)
     typedef __attribute__((address_space(3))) short4_t* lds_p;
@@ -585,7 +601,7 @@ __global__ __launch_bounds__(NT / 2 * 64) __attribute__((amdgpu_waves_per_eu(3, 
         for (int half = 0; half < 2; ++half) {
             short8_t fq[2], fd[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < KS; ++s) {
                 fq[s] = frag_k(qimg, (2 * u2 + half) * 16, s, lane);
                 fd[s] = frag_k(doimg, (2 * u2 + half) * 16, s, lane);
             }
@@ -600,7 +616,7 @@ __global__ __launch_bounds__(NT / 2 * 64) __attribute__((amdgpu_waves_per_eu(3, 
                     const bool kok = key < T;
                     float4_t s_ = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
+                    for (int s = 0; s < KS; ++s) {
                         s_ = mfma16<F16>(fq[s], frag_k(kimg, k0 + 16 * j, s, lane), s_);
                         dp = mfma16<F16>(fd[s], vf[j][s], dp);
                     }
@@ -632,7 +648,7 @@ __global__ __launch_bounds__(NT / 2 * 64) __attribute__((amdgpu_waves_per_eu(3, 
         for (int j = 0; j < 2; ++j)
             if (j < ntl) { pf[j] = join(pk[j][0], pk[j][1]); df[j] = join(dsk[j][0], dsk[j][1]); }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < ND; ++dt) {
             const short8_t tdo = frag_t(doimg, u2, dt, lane), tq = frag_t(qimg, u2, dt, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -681,11 +697,13 @@ __global__ __launch_bounds__(NT / 2 * 64) __attribute__((amdgpu_waves_per_eu(3, 
         if (j < ntl) {
             bf16_t* kdst = a.dqkv + (row0 + k0 + 16 * j) * ld + D + hh * HD;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dk[j][dt] *= a.scale;
+            for (int dt = 0; dt < ND; ++dt) dk[j][dt] *= a.scale;
             store_tile<F16>(stg, dk[j], kdst, ld, T - (k0 + 16 * j), lane);
             store_tile<F16>(stg, dv[j], kdst + D, ld, T - (k0 + 16 * j), lane);
         }
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // Rollout step (SFTS.py:150-153, row-vector form):  r_out[k] = sum_q r_in[q] * P_l[q,k]  for one layer l, with the
@@ -719,27 +737,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     // image and every later tile's one tile ahead, under the arithmetic of the current one (round 4: they used to be requested
     // at the top of each trip - two to three exposed HBM latencies per wave on top of the image's)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    short8_t kn[2];
+    short8_t kn[KS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) kn[s] = frag_own(qbase + D, ld, w * 16, T, s, lane);
+    for (int s = 0; s < KS; ++s) kn[s] = frag_own(qbase + D, ld, w * 16, T, s, lane);
     images_ready();
     const int li = lane & 15, lg = lane >> 4;
     const float sc = scale * kLog2e;
     for (int k0 = w * 16; k0 < T; k0 += nw * 16) {
         const int key = k0 + li;
-        short8_t kf[2];
+        short8_t kf[KS];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) kf[s] = kn[s];
+        for (int s = 0; s < KS; ++s) kf[s] = kn[s];
         if (k0 + nw * 16 < T) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) kn[s] = frag_own(qbase + D, ld, k0 + nw * 16, T, s, lane);
+            for (int s = 0; s < KS; ++s) kn[s] = frag_own(qbase + D, ld, k0 + nw * 16, T, s, lane);
         }
         float acc = 0.f;
 #pragma unroll 2
         for (int u = 0; u < nt; ++u) {
             float4_t s_ = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < KS; ++s)
                 s_ = mfma16<F16>(frag_k(qimg, u * 16, s, lane), kf[s], s_);
             const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * u + 4 * lg);
             const float4 w4 = *reinterpret_cast<const float4*>(w_s + 16 * u + 4 * lg);
@@ -788,9 +806,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         w_s[t] = t == 0 ? 1.f : 0.f;                                     // r = e_cls^T
         w_s[Tp + t] = 0.f;                                               // (pad entries of the other buffer: never written later)
     }
-    short8_t kn[2];
+    short8_t kn[KS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) kn[s] = frag_own(qb + D, ld, w * 16, T, s, lane);
+    for (int s = 0; s < KS; ++s) kn[s] = frag_own(qb + D, ld, w * 16, T, s, lane);
     for (int l = L - 1, cur = 0; l >= 0; --l, cur ^= 1) {
         images_ready();                                                  // layer l's image (and everything written to LDS) is visible
         const bf16_t* qcur = ra.qkv[l] + row0 * ld + hh * HD;
@@ -810,23 +828,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         float* wn = w_s + (cur ^ 1) * Tp;
         for (int k0 = w * 16; k0 < T; k0 += nw * 16) {
             const int key = k0 + li;
-            short8_t kf[2];
+            short8_t kf[KS];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) kf[s] = kn[s];
+            for (int s = 0; s < KS; ++s) kf[s] = kn[s];
             // the next fragments: this layer's next key tile, or - on the wave's last tile - the next layer's first
             const bool more = k0 + nw * 16 < T;
             if (more || qnx) {
                 const bf16_t* src = more ? qcur : qnx;
                 const int r0 = more ? k0 + nw * 16 : w * 16;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) kn[s] = frag_own(src + D, ld, r0, T, s, lane);
+                for (int s = 0; s < KS; ++s) kn[s] = frag_own(src + D, ld, r0, T, s, lane);
             }
             float acc = 0.f;
 #pragma unroll 2
             for (int u = 0; u < nt; ++u) {
                 float4_t s_ = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < KS; ++s)
                     s_ = mfma16<F16>(frag_k(qimg_c, u * 16, s, lane), kf[s], s_);
                 const float4 l4 = *reinterpret_cast<const float4*>(lsec + 16 * u + 4 * lg);
                 const float4 w4 = *reinterpret_cast<const float4*>(wc + 16 * u + 4 * lg);
@@ -881,9 +899,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int q0 = qb0 + w * 16, q = q0 + li;
     const bool qin = q < T;
     const bool qok = qin && (!mk || mk[q]);
-    short8_t qf[2];
+    short8_t qf[KS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) qf[s] = frag_own(qbase, ld, q0, T, s, lane);
+    for (int s = 0; s < KS; ++s) qf[s] = frag_own(qbase, ld, q0, T, s, lane);
     const float sc = a.scale * kLog2e;
     const long row_idx0 = (long)hh * a.Mtot + row0;
     float lse;
@@ -898,7 +916,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             for (int t = 0; t < ntc; ++t) {
                 float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 2; ++s) acc = mfma16<F16>(frag_k(kimg, t * 16, s, lane), qf[s], acc);
+                for (int s = 0; s < KS; ++s) acc = mfma16<F16>(frag_k(kimg, t * 16, s, lane), qf[s], acc);
                 float sv[4], tm = -INFINITY;
                 const int key0 = c0 + 16 * t + 4 * lg;
 #pragma unroll
@@ -918,12 +936,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         lse = qin ? a.lse[row_idx0 + q] : INFINITY;
     }
     float dl = 0.f;
-    short8_t dof[2];
+    short8_t dof[KS];
     if (BWD) {
         const bf16_t* dobase = a.dout + row0 * D + hh * HD;
         const bf16_t* obase = a.out_fwd + row0 * D + hh * HD;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < KS; ++s) {
             dof[s] = frag_own(dobase, D, q0, T, s, lane);
             const short8_t of = frag_own(obase, D, q0, T, s, lane);
 #pragma unroll
@@ -932,9 +950,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         dl = group_sum(dl);
         if (lg == 0 && qin) a.delta[row_idx0 + q] = dl;
     }
-    float4_t o[4];
+    float4_t o[ND];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < ND; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < T; c0 += LCH) {
         const int len = min(LCH, T - c0), ntc = ((len + 31) >> 5) << 1;
         __syncthreads();
@@ -949,7 +967,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 const int t = 2 * s2 + half;
                 float4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                for (int s = 0; s < KS; ++s) {
                     acc = mfma16<F16>(frag_k(kimg, t * 16, s, lane), qf[s], acc);
                     if (BWD) dp = mfma16<F16>(frag_k(vimg, t * 16, s, lane), dof[s], dp);
                 }
@@ -965,13 +983,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const short8_t pf = join(pk[0], pk[1]);
             const char* timg = BWD ? kimg : vimg;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16<F16>(frag_t(timg, s2, dt, lane), pf, o[dt]);
+            for (int dt = 0; dt < ND; ++dt) o[dt] = mfma16<F16>(frag_t(timg, s2, dt, lane), pf, o[dt]);
         }
     }
     if (qin) {
         bf16_t* orow = BWD ? a.dqkv + (row0 + q) * ld + hh * HD + 4 * lg : a.out + (row0 + q) * D + hh * HD + 4 * lg;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < ND; ++dt)
             *reinterpret_cast<uint2*>(orow + dt * 16) = pack4<F16>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
     }
 }
@@ -999,15 +1017,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     const bool kin = key < T;
     const bool kok = kin && (!mk || mk[key]);
     const float sc = a.scale * kLog2e;
-    short8_t kf[2], vf[2];
+    short8_t kf[KS], vf[KS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < KS; ++s) {
         kf[s] = frag_own(qbase + D, ld, k0, T, s, lane);
         vf[s] = frag_own(qbase + 2 * D, ld, k0, T, s, lane);
     }
-    float4_t dv[4], dk[4];
+    float4_t dv[ND], dk[ND];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dv[dt] = float4_t{0.f, 0.f, 0.f, 0.f}; dk[dt] = dv[dt]; }
+    for (int dt = 0; dt < ND; ++dt) { dv[dt] = float4_t{0.f, 0.f, 0.f, 0.f}; dk[dt] = dv[dt]; }
     for (int c0 = 0; c0 < T; c0 += LCH) {
         const int len = min(LCH, T - c0), ntc = ((len + 31) >> 5) << 1;
         __syncthreads();
@@ -1023,11 +1041,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll 1
         for (int u2 = 0; u2 < ntc / 2; ++u2) {
             uint2 pk[2], dsk[2];
-            short8_t fq[2][2], fd[2][2];
+            short8_t fq[2][KS], fd[2][KS];
 #pragma unroll
             for (int half = 0; half < 2; ++half)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                for (int s = 0; s < KS; ++s) {
                     fq[half][s] = frag_k(qimg, (2 * u2 + half) * 16, s, lane);
                     fd[half][s] = frag_k(doimg, (2 * u2 + half) * 16, s, lane);
                 }
@@ -1037,7 +1055,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 const int u = 2 * u2 + half;
                 float4_t s_ = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                for (int s = 0; s < KS; ++s) {
                     s_ = mfma16<F16>(fq[half][s], kf[s], s_);
                     dp = mfma16<F16>(fd[half][s], vf[s], dp);
                 }
@@ -1056,7 +1074,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             }
             const short8_t pf = join(pk[0], pk[1]), df = join(dsk[0], dsk[1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < ND; ++dt) {
                 dv[dt] = mfma16<F16>(frag_t(doimg, u2, dt, lane), pf, dv[dt]);
                 dk[dt] = mfma16<F16>(frag_t(qimg, u2, dt, lane), df, dk[dt]);
             }
@@ -1065,7 +1083,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     if (kin) {
         bf16_t* krow = a.dqkv + (row0 + key) * ld + D + hh * HD + 4 * lg;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < ND; ++dt) {
             *reinterpret_cast<uint2*>(krow + dt * 16) = pack4<F16>(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
             *reinterpret_cast<uint2*>(krow + D + dt * 16) = pack4<F16>(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
         }
@@ -1087,7 +1105,8 @@ int set_lds(K kern, size_t bytes)
     return 0;
 }
 
-inline int pick_nt(int T) { return T <= 160 ? 10 : (T <= 224 ? 14 : (T <= 416 ? 26 : (T <= 608 ? 38 : 0))); }
+// (two images of NT * 16 rows + row statistics must fit 160 KiB: 608 rows of 64-wide heads, 416 rows of 96-wide ones)
+inline int pick_nt(int T) { return T <= 160 ? 10 : (T <= 224 ? 14 : (T <= 416 ? 26 : ((T <= 608 && HD <= 64) ? 38 : 0))); }
 inline int pick_threads(int T) { const int tiles = (T + 15) / 16; return (tiles % 3 == 0) ? 192 : 256; }
 
 template <int NT, bool F16>
@@ -1124,6 +1143,7 @@ int launch_all(const AttnArgs& a_in, int B, int mode, hipStream_t stream)
         EDITOR_LAUNCH_CHECK();
     } else {
         const bool full = !a.cu && !a.mask && (((a.T + 31) >> 5) << 1) >= NT && NT <= 14;
+#if ATTN_HD == 64
         if constexpr (NT <= 10) {
             // dense backbone sequences, opt-in (EDITOR_ATTN_FUSED_BWD=1): S / P / dP / dS once, dQ and dK / dV from the same
             // workgroup; bit-identical to the two-pass form and, as measured, slower
@@ -1135,6 +1155,7 @@ int launch_all(const AttnArgs& a_in, int B, int mode, hipStream_t stream)
                 return 0;
             }
         }
+#endif
         if (a.mask) {
             auto k1 = attn_q_pass_kernel<NT, true, false, F16, true>;
             if ((rc = set_lds(k1, img))) return rc;
@@ -1281,57 +1302,91 @@ int rollout_multi_h16(int L, const uint16_t* const* qkv, const float* const* lse
 
 }  // namespace
 
-extern "C" int editor_attn_rollout_multi_bf16(int L, const uint16_t* const* qkv, const float* const* lse, int B, int T, int heads,
-                                              int hd, float scale, float* scores, hipStream_t stream)
+// ---- entry points.  This file is compiled once per head width (editor_amd/build.py: -DATTN_HD=32 / 64 / 96); the 64-wide build
+// carries the C-ABI names of include/editor_hip.h and forwards the other widths to the suffixed builds of the same source.
+#if ATTN_HD == 64
+#define ATTN_ENTRY(name) name
+#define ATTN_DECL_WIDTHS(name, ...) extern "C" int name##_hd32(__VA_ARGS__); extern "C" int name##_hd96(__VA_ARGS__);
+#define ATTN_OTHER_WIDTHS(name, ...) do { if (hd == 32) return name##_hd32(__VA_ARGS__); if (hd == 96) return name##_hd96(__VA_ARGS__); } while (0)
+#elif ATTN_HD == 32
+#define ATTN_ENTRY(name) name##_hd32
+#define ATTN_DECL_WIDTHS(name, ...)
+#define ATTN_OTHER_WIDTHS(name, ...) do { } while (0)
+#else
+#define ATTN_ENTRY(name) name##_hd96
+#define ATTN_DECL_WIDTHS(name, ...)
+#define ATTN_OTHER_WIDTHS(name, ...) do { } while (0)
+#endif
+
+#define ROLLM_ARGS int L, const uint16_t* const* qkv, const float* const* lse, int B, int T, int heads, int hd, float scale, \
+                   float* scores, hipStream_t stream
+ATTN_DECL_WIDTHS(editor_attn_rollout_multi_bf16, ROLLM_ARGS)
+ATTN_DECL_WIDTHS(editor_attn_rollout_multi_f16, ROLLM_ARGS)
+extern "C" int ATTN_ENTRY(editor_attn_rollout_multi_bf16)(ROLLM_ARGS)
 {
+    ATTN_OTHER_WIDTHS(editor_attn_rollout_multi_bf16, L, qkv, lse, B, T, heads, hd, scale, scores, stream);
     return rollout_multi_h16<false>(L, qkv, lse, B, T, heads, hd, scale, scores, stream);
 }
-extern "C" int editor_attn_rollout_multi_f16(int L, const uint16_t* const* qkv, const float* const* lse, int B, int T, int heads,
-                                             int hd, float scale, float* scores, hipStream_t stream)
+extern "C" int ATTN_ENTRY(editor_attn_rollout_multi_f16)(ROLLM_ARGS)
 {
+    ATTN_OTHER_WIDTHS(editor_attn_rollout_multi_f16, L, qkv, lse, B, T, heads, hd, scale, scores, stream);
     return rollout_multi_h16<true>(L, qkv, lse, B, T, heads, hd, scale, scores, stream);
 }
+#undef ROLLM_ARGS
 
-extern "C" int editor_attention_fwd_bf16(const uint16_t* qkv, int B, int T, int heads, int hd, float scale,
-                                         const uint8_t* mask, uint16_t* out, float* probs, int ldp, float* lse,
-                                         const int* cu, long Mtot, hipStream_t stream)
+#define FWD_ARGS const uint16_t* qkv, int B, int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* out, \
+                 float* probs, int ldp, float* lse, const int* cu, long Mtot, hipStream_t stream
+ATTN_DECL_WIDTHS(editor_attention_fwd_bf16, FWD_ARGS)
+ATTN_DECL_WIDTHS(editor_attention_fwd_f16, FWD_ARGS)
+extern "C" int ATTN_ENTRY(editor_attention_fwd_bf16)(FWD_ARGS)
 {
+    ATTN_OTHER_WIDTHS(editor_attention_fwd_bf16, qkv, B, T, heads, hd, scale, mask, out, probs, ldp, lse, cu, Mtot, stream);
     return attention_fwd_h16<false>(qkv, B, T, heads, hd, scale, mask, out, probs, ldp, lse, cu, Mtot, stream);
 }
-extern "C" int editor_attention_fwd_f16(const uint16_t* qkv, int B, int T, int heads, int hd, float scale,
-                                        const uint8_t* mask, uint16_t* out, float* probs, int ldp, float* lse,
-                                        const int* cu, long Mtot, hipStream_t stream)
+extern "C" int ATTN_ENTRY(editor_attention_fwd_f16)(FWD_ARGS)
 {
+    ATTN_OTHER_WIDTHS(editor_attention_fwd_f16, qkv, B, T, heads, hd, scale, mask, out, probs, ldp, lse, cu, Mtot, stream);
     return attention_fwd_h16<true>(qkv, B, T, heads, hd, scale, mask, out, probs, ldp, lse, cu, Mtot, stream);
 }
+#undef FWD_ARGS
 
-extern "C" int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse,
-    int B, int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace, const int* cu,
-    long Mtot, hipStream_t stream)
+#define BWD_ARGS const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, int B, int T, int heads, int hd, \
+                 float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace, const int* cu, long Mtot, hipStream_t stream
+ATTN_DECL_WIDTHS(editor_attention_bwd_bf16, BWD_ARGS)
+ATTN_DECL_WIDTHS(editor_attention_bwd_f16, BWD_ARGS)
+extern "C" int ATTN_ENTRY(editor_attention_bwd_bf16)(BWD_ARGS)
 {
+    ATTN_OTHER_WIDTHS(editor_attention_bwd_bf16, qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, stream);
     return attention_bwd_h16<false>(qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, stream);
 }
-extern "C" int editor_attention_bwd_f16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse,
-    int B, int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace, const int* cu,
-    long Mtot, hipStream_t stream)
+extern "C" int ATTN_ENTRY(editor_attention_bwd_f16)(BWD_ARGS)
 {
+    ATTN_OTHER_WIDTHS(editor_attention_bwd_f16, qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, stream);
     return attention_bwd_h16<true>(qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, stream);
 }
+#undef BWD_ARGS
 
+#if ATTN_HD == 64
 extern "C" int editor_attention_bwd_mode(int fused)
 {
     const int prev = g_fused_bwd;
     if (fused >= 0) g_fused_bwd = fused ? 1 : 0;
     return prev;
 }
+#endif
 
-extern "C" int editor_attn_rollout_step_bf16(const uint16_t* qkv, const float* lse, const float* r_in, int B, int T, int heads,
-                                             int hd, float scale, float* r_out, int final_step, hipStream_t stream)
+#define ROLL_ARGS const uint16_t* qkv, const float* lse, const float* r_in, int B, int T, int heads, int hd, float scale, \
+                  float* r_out, int final_step, hipStream_t stream
+ATTN_DECL_WIDTHS(editor_attn_rollout_step_bf16, ROLL_ARGS)
+ATTN_DECL_WIDTHS(editor_attn_rollout_step_f16, ROLL_ARGS)
+extern "C" int ATTN_ENTRY(editor_attn_rollout_step_bf16)(ROLL_ARGS)
 {
+    ATTN_OTHER_WIDTHS(editor_attn_rollout_step_bf16, qkv, lse, r_in, B, T, heads, hd, scale, r_out, final_step, stream);
     return rollout_step_h16<false>(qkv, lse, r_in, B, T, heads, hd, scale, r_out, final_step, stream);
 }
-extern "C" int editor_attn_rollout_step_f16(const uint16_t* qkv, const float* lse, const float* r_in, int B, int T, int heads,
-                                            int hd, float scale, float* r_out, int final_step, hipStream_t stream)
+extern "C" int ATTN_ENTRY(editor_attn_rollout_step_f16)(ROLL_ARGS)
 {
+    ATTN_OTHER_WIDTHS(editor_attn_rollout_step_f16, qkv, lse, r_in, B, T, heads, hd, scale, r_out, final_step, stream);
     return rollout_step_h16<true>(qkv, lse, r_in, B, T, heads, hd, scale, r_out, final_step, stream);
 }
+#undef ROLL_ARGS

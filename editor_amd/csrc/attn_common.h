@@ -1,4 +1,4 @@
-// Shared device helpers of the fused attention kernels (attention_bf16.hip, attention_split.hip): LDS images of 64-wide head
+// Shared device helpers of the fused attention kernels (attention_bf16.hip, attention_split.hip): LDS images of HD-wide head
 // slices, MFMA fragment loads in the k-major and transposed (ds_read_b64_tr_b16) forms, accumulator packing.  gfx950 only.
 #pragma once
 #include "common.h"
@@ -21,12 +21,24 @@ __device__ __forceinline__ float4_t mfma16(short8_t a, short8_t b, float4_t c)
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-constexpr int HD = 64;                 // head dim (ViT-B/L, DeiT-S backbones)
+// Head width.  The kernels are written for 64-wide heads (ViT-B/L, DeiT-B: every shipped configuration); the same source is
+// compiled again with -DATTN_HD=32 and -DATTN_HD=96 for the factory's other widths (DeiT-small's HMA heads, ViT-small's backbone:
+// vit_pytorch.py:704-727) - KS k-steps of 32 and ND output tiles of 16 columns across the head instead of 2 and 4, image rows of
+// CPR 16-byte chunks.  With ATTN_HD == 64 every expression below reduces to the original one.
+#ifndef ATTN_HD
+#define ATTN_HD 64
+#endif
+static_assert(ATTN_HD == 32 || ATTN_HD == 64 || ATTN_HD == 96, "head widths built: 32, 64, 96");
+constexpr int HD = ATTN_HD;            // head dim
+constexpr int KS = HD / 32;            // 32-deep MFMA k-steps across the head dim
+constexpr int ND = HD / 16;            // 16-column output tiles across the head dim
+constexpr int CPR = HD / 8;            // 16-byte chunks per LDS image row
 constexpr int ROWB = HD * 2;           // bytes per LDS image row
+constexpr int SWZ = (CPR % 8 == 0) ? 7 : 3;   // XOR swizzle mask of the chunk index (stays inside an aligned group of SWZ + 1 chunks)
 constexpr float kLog2e = 1.4426950408889634f;
 
-// LDS image of (rows x 64) bf16: 16-byte chunk c of row r lives at r*128 + ((c ^ (r&7)) << 4)
-__device__ __forceinline__ int img_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
+// LDS image of (rows x HD) bf16: 16-byte chunk c of row r lives at r*ROWB + ((c ^ (r & SWZ)) << 4)  (HD = 64: r*128, r & 7)
+__device__ __forceinline__ int img_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & SWZ)) << 4); }
 
 // cooperative load of rows [0,T) of one head slice (64 columns starting at `base` of a row-major matrix with leading
 // dimension ld) into an LDS image of Tp rows (Tp a multiple of 8), as LDS-DMA (global_load_lds_dwordx4): no staging
@@ -39,13 +51,26 @@ __device__ __forceinline__ void load_image(char* img, const bf16_t* __restrict__
 {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-    const int r8 = lane >> 3, p = lane & 7;
-    for (int piece = w; piece < (Tp >> 3); piece += nw) {          // 8 rows x 128 B = 1 KiB per piece
-        const int row = piece * 8 + r8;
-        const int c = p ^ (row & 7);
-        const bf16_t* src = base + (long)min(row, T - 1) * ld + c * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(img + piece * 1024), 16, 0, 0);
+    if constexpr (HD == 64) {
+        const int r8 = lane >> 3, p = lane & 7;
+        for (int piece = w; piece < (Tp >> 3); piece += nw) {          // 8 rows x 128 B = 1 KiB per piece
+            const int row = piece * 8 + r8;
+            const int c = p ^ (row & 7);
+            const bf16_t* src = base + (long)min(row, T - 1) * ld + c * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(img + piece * 1024), 16, 0, 0);
+        }
+    } else {
+        // other head widths: a 1 KiB piece is 64 consecutive chunk SLOTS of the flat image (16 rows of 4, or 5 1/3 rows of 12);
+        // slot p of row r receives source chunk p ^ (r & SWZ).  Tp is a multiple of 16, so Tp * CPR / 64 is whole.
+        for (int piece = w; piece < Tp * CPR / 64; piece += nw) {
+            const int ci = piece * 64 + lane;
+            const int row = ci / CPR, p = ci - row * CPR;
+            const int c = p ^ (row & SWZ);
+            const bf16_t* src = base + (long)min(row, T - 1) * ld + c * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(img + piece * 1024), 16, 0, 0);
+        }
     }
 }
 // the DMA counts on vmcnt: drain it before the barrier that publishes the images

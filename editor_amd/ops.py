@@ -649,6 +649,11 @@ def gemm_wgrad_group(jobs, m, alpha=1.0, m_live=None):
          ia(ns), ia(ks), m, float(alpha), sk, ws, m_live)
 
 
+# head widths the fused 16-bit attention / rollout kernels are built for (csrc/attention_bf16.hip compiled per width, round 4:
+# 64 = ViT-B/L, DeiT-B; 96 = ViT-small's backbone; 32 = DeiT-small's HMA heads)
+ATTN_HEAD_WIDTHS = (32, 64, 96)
+
+
 def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True, cu=None, scale=None):
     """Attention / AttentionMask core on packed qkv (rows, 3*heads*hd) -> (rows, heads*hd).
     Dense: rows = b*t.  Variable length (compacted HMA): cu (b+1 int32) = packed row range of every sequence,
@@ -666,14 +671,14 @@ def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True, cu
             probs = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
         call("editor_attention_fwd_f32", qkv, b, t, heads, hd, scale, mask, out, probs)
         return out, probs
-    if hd != 64:
-        # head widths other than 64 (ViT-small: 96, DeiT-small's HMA: 32; no shipped config): the 16-bit kernels are written
-        # for 64-wide heads, so this product runs on the exact-f32 attention kernels between two casts - correct, not fast.
+    if hd not in ATTN_HEAD_WIDTHS:
+        # head widths the fused 16-bit kernels are not built for (they exist for 32, 64 and 96: every factory of the reference,
+        # vit_pytorch.py:693-727): this product runs on the exact-f32 attention kernels between two casts - correct, not fast.
         # `saved` is then the fp32 probability tensor (4-D), which attention_bwd recognises.
         if cu is not None:
-            raise RuntimeError("variable-length attention needs 64-wide heads (use the dense-masked HMA form)")
+            raise RuntimeError("variable-length attention needs 32 / 64 / 96-wide heads (use the dense-masked HMA form)")
         if probs is not None and probs.shape[-1] != t:
-            raise RuntimeError("attention_fwd: probability rows of a non-64-wide head must be unpadded (ldp == T)")
+            raise RuntimeError("attention_fwd: probability rows of such a head must be unpadded (ldp == T)")
         out32, probs = attention_fwd(qkv.float(), b, t, heads, hd, mask, probs, cu=None, scale=scale)
         return out32.to(qkv.dtype), probs
     out = _packed_alloc(rows, d, qkv.dtype, qkv.device, cu)
@@ -699,7 +704,9 @@ def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None, c
         dqkv = torch.empty_like(qkv)
         ws = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
         call("editor_attention_bwd_f32", qkv, dout, saved, b, t, heads, hd, scale, dqkv, ws)
-    elif hd != 64:                                      # (see attention_fwd: exact-f32 kernels between two casts)
+    elif hd not in ATTN_HEAD_WIDTHS or (saved is not None and saved.dim() == 4):
+        # (see attention_fwd: exact-f32 kernels between two casts; a 4-D `saved` is the fp32 probability tensor such a forward -
+        #  or the split-precision forward of a non-64-wide head, attention_fwd_split - handed back)
         dqkv = attention_bwd(qkv.float(), dout.float(), b, t, heads, hd, mask, saved, None, None, scale).to(qkv.dtype)
     else:
         if not _ATTN_MODE_ENV[0]:                       # EDITOR_ATTN_FUSED_BWD=1: the fused backward (A/B measurements), once

@@ -274,7 +274,9 @@ int editor_attn_rollout_step_bf16(const uint16_t* qkv, const float* lse, const f
 int editor_attn_rollout_step_f16(const uint16_t* qkv, const float* lse, const float* r_in, int B, int T, int heads, int hd,
                                  float scale, float* r_out, int final_step, editor_stream_t stream);
 
-/* Fused 16-bit form (hd must be 64).  T <= 608: one workgroup per (sample, head) with the whole key range in LDS.
+/* Fused 16-bit form.  hd = 64 (every shipped configuration), 32 or 96 (the factory's other head widths, vit_pytorch.py:704-727:
+ * the same kernels built per width; whole-sequence form up to 416 tokens at hd = 96); any other hd is hipErrorInvalidValue.
+ * T <= 608: one workgroup per (sample, head) with the whole key range in LDS.
  * T > 608 (joint HMA block of the 4-modal 512-token configuration): 64 own rows per workgroup, the other side streamed
  * through LDS in 256-row chunks; probs must be NULL there.  probs optional (NULL skips the write).  lse (heads*Mtot fp32, log2 units
  * of the scaled scores, +inf for masked queries) is written by the forward (NULL to skip) and consumed by the backward,

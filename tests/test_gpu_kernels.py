@@ -494,6 +494,98 @@ def test_attention_varlen_matches_dense_reference(ops):
     assert float(dqkv[total:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hd,heads", [(32, 12), (96, 8)])
+@pytest.mark.parametrize("t,use_mask", [(129, False), (129, True), (193, False), (387, True), (50, False), (700, False)])
+def test_attention_other_head_widths(ops, dtype, hd, heads, t, use_mask):
+    """Round 4: the fused 16-bit kernels built for the factory's other head widths (vit_small_patch16_224: 8 heads of 96,
+    vit_pytorch.py:704-713; DeiT-small's 12 HMA heads of 32, :716-727) - forward, probabilities, lse and the two-pass backward
+    against the fp32 softmax attention, in the whole-sequence form (T <= 416 at 96 columns) and the chunked one (T = 700)."""
+    b = 3
+    d = heads * hd
+    assert hd in ops.ATTN_HEAD_WIDTHS
+    qkv = (torch.randn(b * t, 3 * d, generator=_g(1)) * 1.5).to(dtype).float()
+    mask = None
+    if use_mask:
+        mask = (torch.rand(b, t, generator=_g(2)) > 0.5).to(torch.uint8)
+        mask[:, 0] = 1
+    qr = qkv.clone().requires_grad_(True)
+    o_ref, p_ref = _attn_ref(qr, b, t, heads, hd, mask)
+    do = torch.randn(b * t, d, generator=_g(3)).to(dtype).float()
+    o_ref.backward(do)
+    ldp = (t + 3) // 4 * 4
+    probs = torch.zeros(b, heads, t, ldp, device="cuda") if t <= 416 else None      # (no probability output in the chunked form)
+    mk = None if mask is None else mask.cuda()
+    o, lse = ops.attention_fwd(qkv.to(dtype).cuda(), b, t, heads, hd, mk, probs)
+    assert lse.dim() == 1 and lse.numel() == heads * b * t                            # the fused path, not the fp32 detour
+    assert rel_err(o.float().cpu(), o_ref.detach()) < 1.5e-2
+    if probs is not None:
+        assert rel_err(probs[..., :t].cpu(), p_ref.detach()) < 1e-2
+    dqkv = ops.attention_bwd(qkv.to(dtype).cuda(), do.to(dtype).cuda(), b, t, heads, hd, mk, lse, o)
+    assert rel_err(dqkv.float().cpu(), qr.grad) < 2.5e-2
+    # same operands through the exact-f32 kernels: the 16-bit result differs from it by 16-bit rounding only
+    if t <= 416:
+        o32, _ = ops.attention_fwd(qkv.cuda(), b, t, heads, hd, mk, None)
+        assert rel_err(o.float().cpu(), o32.cpu()) < 1.5e-2
+
+
+@pytest.mark.parametrize("hd,heads", [(32, 12), (96, 8)])
+def test_attention_varlen_other_head_widths(ops, hd, heads):
+    """Compacted (variable-length) attention at 32- and 96-wide heads == per-sequence dense softmax attention."""
+    d = heads * hd
+    lens = [129, 60, 1, 77, 128]
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    total = int(cu[-1])
+    rows = (total + 63) // 64 * 64
+    g = _g(5)
+    qkv = (torch.randn(rows, 3 * d, generator=g) * 1.2).bfloat16()
+    qkv[total:] = 0
+    do = torch.randn(rows, d, generator=g).bfloat16()
+    do[total:] = 0
+    qr = qkv.float().requires_grad_(True)
+    outs = []
+    for i, n in enumerate(lens):
+        s0 = int(cu[i])
+        o, _ = _attn_ref(qr[s0:s0 + n], 1, n, heads, hd, None)
+        outs.append(o)
+    ref = torch.cat(outs + [torch.zeros(rows - total, d)])
+    ref.backward(do.float())
+    o, lse = ops.attention_fwd(qkv.cuda(), len(lens), max(lens), heads, hd, None, None, cu=cu.cuda())
+    assert rel_err(o.float().cpu(), ref.detach()) < 1.5e-2
+    assert float(o[total:].abs().max()) == 0.0
+    dqkv = ops.attention_bwd(qkv.cuda(), do.cuda(), len(lens), max(lens), heads, hd, None, lse, o, cu=cu.cuda())
+    assert rel_err(dqkv.float().cpu(), qr.grad) < 2.5e-2
+    assert float(dqkv[total:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("hd,heads", [(32, 12), (96, 8)])
+@pytest.mark.parametrize("t", [129, 193])
+def test_rollout_recomputed_other_head_widths(ops, hd, heads, t):
+    """Rollout steps that recompute P from (qkv, lse) at 32- / 96-wide heads == the rollout over the materialised probabilities;
+    the one-launch form == the per-layer steps, bit for bit."""
+    import editor_amd.ops as ops_mod
+    b, layers = 4, 4
+    g = torch.Generator().manual_seed(3)
+    ldp = (t + 3) // 4 * 4
+    probs = torch.empty(layers, b, heads, t, ldp, device="cuda")
+    pairs = []
+    for l in range(layers):
+        qkv = (torch.randn(b * t, 3 * heads * hd, generator=g) * 0.7).bfloat16().cuda()
+        _, lse = ops.attention_fwd(qkv, b, t, heads, hd, None, probs[l])
+        pairs.append((qkv, lse))
+    ref = ops.attn_rollout(probs)
+    got = ops.attn_rollout_qk(pairs, b, t, heads, hd)
+    assert got.shape == ref.shape == (b, heads, t - 1)
+    assert rel_err(got.cpu(), ref.cpu()) < 2e-5
+    old = ops_mod.ROLLOUT_MULTI
+    try:
+        ops_mod.ROLLOUT_MULTI = True
+        multi = ops.attn_rollout_qk(pairs, b, t, heads, hd)
+    finally:
+        ops_mod.ROLLOUT_MULTI = old
+    assert torch.equal(got, multi)
+
+
 def test_compact_plan_and_rows(ops):
     g = _g(11)
     b, n, d, nmod = 7, 128, 256, 3

@@ -26,3 +26,21 @@ for mode, name in ((0, "two-pass"), (1, "fused")):
     ops.attention_bwd_mode(mode)
     print("bwd %-8s        %.1f us" % (name, bench(lambda: ops.attention_bwd(qkv, do, b, t, heads, hd, None, lse, o))))
 ops.attention_bwd_mode(0)
+# round 4: the fused kernels at the factory's other head widths (same 768 = heads x hd columns, B = 384 sequences of 129 tokens)
+# against the exact-f32 kernels between two casts they used to take (ops.attention_fwd's fallback for other widths)
+for heads2, hd2 in ((8, 96), (24, 32)):
+    q3 = (torch.randn(b * t, 3 * heads2 * hd2, device='cuda') * 0.5).bfloat16()
+    o3, lse3 = ops.attention_fwd(q3, b, t, heads2, hd2, None, None)
+    do3 = torch.randn_like(o3)
+    f16 = bench(lambda: ops.attention_fwd(q3, b, t, heads2, hd2, None, None))
+    b16 = bench(lambda: ops.attention_bwd(q3, do3, b, t, heads2, hd2, None, lse3, o3))
+    r16 = bench(lambda: ops.attn_rollout_qk([(q3, lse3)], b, t, heads2, hd2))
+    q32 = q3.float()
+    def detour_fwd():
+        o_, p_ = ops.attention_fwd(q3.float(), b, t, heads2, hd2, None, None)
+        return o_.to(q3.dtype), p_
+    _, p32 = detour_fwd()
+    def detour_bwd():
+        return ops.attention_bwd(q3.float(), do3.float(), b, t, heads2, hd2, None, p32, None).to(q3.dtype)
+    print("hd=%d (%d heads): fwd %.1f us, bwd %.1f us, rollout step %.1f us   |  exact-f32 detour: fwd %.1f us, bwd %.1f us"
+          % (hd2, heads2, f16, b16, r16, bench(detour_fwd, 5), bench(detour_bwd, 5)))
