@@ -20,7 +20,7 @@ LIB_TRACE = os.path.join(HERE, "libeditor_gemm_trace.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-munsafe-fp-atomics"]
-DEBUG_ONLY = {"probe.hip"}
+DEBUG_ONLY = {"probe.hip", "gemm_w4.hip"}          # libeditor_probe.so: tests / tools only
 
 
 def _stale(target, deps):
@@ -63,10 +63,13 @@ def build(force=False, verbose=False, trace=False):
         objs.append(obj)
         if force or _stale(obj, [attn_src] + hdrs):
             jobs.append((attn_src, obj, ["-DATTN_HD=%d" % hd]))
-    probe_src = os.path.join(CSRC, "probe.hip")
-    probe_obj = probe_src[:-4] + ".o"
-    if force or _stale(probe_obj, [probe_src] + hdrs):
-        jobs.append((probe_src, probe_obj, []))
+    probe_objs = []
+    for name in sorted(DEBUG_ONLY):
+        probe_src = os.path.join(CSRC, name)
+        probe_obj = probe_src[:-4] + ".o"
+        probe_objs.append(probe_obj)
+        if force or _stale(probe_obj, [probe_src] + hdrs):
+            jobs.append((probe_src, probe_obj, []))
     trace_obj = os.path.join(CSRC, "gemm_bf16.trace.o")
     gemm_src = os.path.join(CSRC, "gemm_bf16.hip")
     if trace and (force or _stale(trace_obj, [gemm_src] + hdrs)):
@@ -74,8 +77,8 @@ def build(force=False, verbose=False, trace=False):
     _compile(jobs, verbose)
     if force or _stale(LIB, objs):
         _link(LIB, objs)
-    if force or _stale(LIB_PROBE, [probe_obj]):
-        _link(LIB_PROBE, [probe_obj])
+    if force or _stale(LIB_PROBE, probe_objs):
+        _link(LIB_PROBE, probe_objs)
     if trace and (force or _stale(LIB_TRACE, [trace_obj])):
         _link(LIB_TRACE, [trace_obj])
     return LIB

@@ -77,6 +77,8 @@ struct GemmB16Args {
     int linear_ids;                          // ping-pong kernel: `bid` already is the position in the grouped tile order (the
                                              // grouped weight-gradient launch does its own XCD mapping)
     int prefer_pipe;                         // EDITOR_EPI_PIPE128
+    int ablate;                              // debug build only (EDITOR_GEMM_ABLATE, tools/gemm_bound_probe.py): 1 = no LDS-DMA inside the
+                                             // K loop, 2 = no MFMAs, 4 = no fragment reads - what each costs, by deletion
 };
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: remember it per device index, so a
@@ -992,7 +994,12 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
     using c1 = std::integral_constant<int, 1>;
 #define PP_WAIT_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PP_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PP_MMA(fbv, MI, NJ, LIVE) do { __builtin_amdgcn_s_setprio(1); mma_q(fbv, MI{}, NJ{}, LIVE{}); __builtin_amdgcn_s_setprio(0); } while (0)
+#ifdef EDITOR_DEBUG_TRACE
+#define PP_ABL(bit) (g.ablate & (bit))
+#else
+#define PP_ABL(bit) false
+#endif
+#define PP_MMA(fbv, MI, NJ, LIVE) do { if (!PP_ABL(2)) { __builtin_amdgcn_s_setprio(1); mma_q(fbv, MI{}, NJ{}, LIVE{}); __builtin_amdgcn_s_setprio(0); } } while (0)
 
     // one K-tile (four phases) out of buffer BUF.  Units: A0,B0 are read in P1, B1 in P2, A1 in P3; each is refilled
     // for K-tile t+2 in the phase after (A1: two phases after, at P1 of t+1).
@@ -1003,28 +1010,28 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
         using B = decltype(BUF);
         using L1 = std::integral_constant<int, decltype(FG)::value - 4>;
         // P1
-        read_b(fb0, std::integral_constant<int, UB0>{}, B{});
+        if (!PP_ABL(4)) read_b(fb0, std::integral_constant<int, UB0>{}, B{});
         __builtin_amdgcn_sched_barrier(0);
-        read_a(std::integral_constant<int, UA0>{}, B{}, c4{});
-        if (t + 1 < nk) stage_a(t + 1, 1);
+        if (!PP_ABL(4)) read_a(std::integral_constant<int, UA0>{}, B{}, c4{});
+        if (t + 1 < nk && !PP_ABL(1)) stage_a(t + 1, 1);
         PP_WAIT_LGKM0(); PP_BAR();
         PP_MMA(fb0, c0, c0, c4);
         PP_BAR();
         // P2
-        read_b(fb1, std::integral_constant<int, UB1>{}, B{});
-        if (t + 2 < nk) stage_a(t + 2, 0);
+        if (!PP_ABL(4)) read_b(fb1, std::integral_constant<int, UB1>{}, B{});
+        if (t + 2 < nk && !PP_ABL(1)) stage_a(t + 2, 0);
         PP_WAIT_LGKM0(); PP_BAR();
         PP_MMA(fb1, c0, c1, c4);
         PP_BAR();
         // P3
-        read_a(std::integral_constant<int, UA1>{}, B{}, L1{});
-        if (t + 2 < nk) stage_b(t + 2, 0);
+        if (!PP_ABL(4)) read_a(std::integral_constant<int, UA1>{}, B{}, L1{});
+        if (t + 2 < nk && !PP_ABL(1)) stage_b(t + 2, 0);
         PP_WAIT_LGKM0(); PP_BAR();
         PP_MMA(fb1, c1, c1, L1);
         PP_BAR();
         // P4
         if (t + 2 < nk) {
-            stage_b(t + 2, 1);
+            if (!PP_ABL(1)) stage_b(t + 2, 1);
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            // through A1(t+1); three units stay in flight
         } else if (t + 1 < nk) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1393,6 +1400,7 @@ int launch_pp_t(GemmB16Args g, hipStream_t stream)
     // Debug build only (libeditor_debug.so, tools/gemm_bench.py): experiment switches and the per-workgroup phase
     // timeline.  The product library has no environment lookups, allocations or synchronisation in its entry points.
     if (const char* e = getenv("EDITOR_GEMM_PP_STAGED")) g.pp_staged = atoi(e);
+    if (const char* e = getenv("EDITOR_GEMM_ABLATE")) g.ablate = atoi(e);
     if (getenv("EDITOR_GEMM_TRACE")) {
         const int nwg = g.tiles_m * g.tiles_n * g.splitk;
         static unsigned long long* buf = nullptr;

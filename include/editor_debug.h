@@ -33,6 +33,10 @@ int editor_probe_mfma_peak(float* out, int grid, int iters, int zero, editor_str
 int editor_probe_resid_add_layernorm(const float* x, const uint16_t* branch, const float* rowscale, const float* gamma,
                                      const float* beta, float eps, long M, int D, float* x_out, uint16_t* y, float* mean,
                                      float* rstd, editor_stream_t stream);
+/* bring-up of the four-wave 256 x 256 GEMM tile (csrc/gemm_w4.hip: one wave per SIMD, 128 x 128 per wave, accumulators in the
+ * accumulator file, one workgroup barrier per K-tile): C (M,N) 16-bit = A (M,K) B (N,K)^T, N % 256 == 0, K % 64 == 0 */
+int editor_probe_gemm_w4(const uint16_t* A, const uint16_t* B, uint16_t* C, int f16, int M, int N, int K, long lda, long ldb,
+                         long ldc, int ablate /* 1 no LDS-DMA in the loop, 2 no MFMAs, 4 no fragment reads */, editor_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -586,6 +586,30 @@ def test_rollout_recomputed_other_head_widths(ops, hd, heads, t):
     assert torch.equal(got, multi)
 
 
+@pytest.mark.parametrize("m,n,k", [(512, 256, 64), (777, 768, 768), (2049, 512, 1536)])
+def test_four_wave_gemm_tile_equals_ping_pong(ops, m, n, k):
+    """Round 4 bring-up (csrc/gemm_w4.hip, probe library): the 256 x 256 tile on four wavefronts - one per SIMD, 128 x 128 each,
+    accumulators in the accumulator file, LDS-DMA pieces and fragment reads between the wave's own MFMAs, two workgroup barriers
+    per K-tile - is BIT-IDENTICAL to the eight-wave ping-pong kernel (same fragment maps, same summation order).  Measured equal,
+    not faster (profiles/r04_gemm_w4_probe.txt), so the product path keeps the ping-pong kernel; this pins the alternative."""
+    import ctypes
+    from editor_amd import _lib
+    fn = _lib.probe_lib().editor_probe_gemm_w4
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_long] * 3 + [ctypes.c_int, ctypes.c_void_p]
+    for dtype, f16 in ((torch.bfloat16, 0), (torch.float16, 1)):
+        x = torch.randn(m, k, generator=_g(21)).to(dtype).cuda()
+        w = (torch.randn(n, k, generator=_g(22)) * 0.05).to(dtype).cuda()
+        y0 = torch.empty(m, n, dtype=dtype, device="cuda")
+        y1 = torch.full((m, n), 3.0, dtype=dtype, device="cuda")
+        ops.gemm(x, w, y0, m, n, k, k, k, n, 0, 0, epilogue=ops.EPI_FORCE_PP)
+        rc = fn(x.data_ptr(), w.data_ptr(), y1.data_ptr(), f16, m, n, k, k, k, n, 0, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y1)
+        assert rel_err(y1.float().cpu(), x.float().cpu() @ w.float().cpu().t()) < 1e-2
+
+
 def test_compact_plan_and_rows(ops):
     g = _g(11)
     b, n, d, nmod = 7, 128, 256, 3
