@@ -46,6 +46,10 @@ typedef struct ihipStream_t* editor_stream_t;   /* == hipStream_t */
 #define EDITOR_EPI_PIPE128 0x800 /* OR-able: prefer the 256x128 three-stage kernel over the 256x256 ping-pong kernel (few token rows:
                                   * twice the tiles fill more of the 256 CUs; the caller's tile-count heuristic decides,
                                   * editor_amd.ops.gemm).  Ignored with EDITOR_EPI_COLSUM / _FORCE_PP / _TILE_ROWS. */
+#define EDITOR_EPI_REVERSE_ROWS 0x10000 /* OR-able (256x256 ping-pong kernel; ignored by the others): output tile rows are taken
+                                  * last-first - for the consumer of a tensor larger than the Infinity Cache that the previous
+                                  * launch has just written (fc2 after fc1's GELU output, fc1's dgrad after fc2's).  Same
+                                  * results bit for bit (every tile is computed as before). */
 #define EDITOR_EPI_TILE_ROWS(h) ((((h) / 16) & 15) << 12) /* OR-able, h = 208 | 256 (ping-pong kernel, both operands k-major,
                                    * split-K 1, beta 0): rows per output tile.  M = 49 536 token rows x 768 columns are 582 full
                                    * tiles = 2.27 rounds of the 256 CUs; 208-row tiles make it 2.8 rounds of smaller tiles.
