@@ -55,14 +55,15 @@ def build(force=False, verbose=False, trace=False):
     srcs = sorted(s for s in glob.glob(os.path.join(CSRC, "*.hip")) if os.path.basename(s) not in DEBUG_ONLY)
     objs = [s[:-4] + ".o" for s in srcs]
     jobs = [(s, o, []) for s, o in zip(srcs, objs) if force or _stale(o, [s] + hdrs)]
-    # the fused 16-bit attention kernels once more per extra head width (csrc/attn_common.h: ATTN_HD; the plain object is the
+    # the fused 16-bit and split-precision attention kernels once more per extra head width (csrc/attn_common.h: ATTN_HD; the plain object is the
     # 64-wide build with the C-ABI names, which forwards hd = 32 / 96 to these)
-    attn_src = os.path.join(CSRC, "attention_bf16.hip")
-    for hd in (32, 96):
-        obj = os.path.join(CSRC, "attention_bf16.hd%d.o" % hd)
-        objs.append(obj)
-        if force or _stale(obj, [attn_src] + hdrs):
-            jobs.append((attn_src, obj, ["-DATTN_HD=%d" % hd]))
+    for stem in ("attention_bf16", "attention_split"):
+        attn_src = os.path.join(CSRC, stem + ".hip")
+        for hd in (32, 96):
+            obj = os.path.join(CSRC, "%s.hd%d.o" % (stem, hd))
+            objs.append(obj)
+            if force or _stale(obj, [attn_src] + hdrs):
+                jobs.append((attn_src, obj, ["-DATTN_HD=%d" % hd]))
     probe_objs = []
     for name in sorted(DEBUG_ONLY):
         probe_src = os.path.join(CSRC, name)

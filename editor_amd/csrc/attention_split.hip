@@ -33,7 +33,7 @@ constexpr int SCH = 128;                  // key chunk of the streamed form
 constexpr float kPScale = 4096.f;         // 2^12
 
 template <bool MULTI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_fwd_split_kernel(SplitAttnArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 4 : 3, 8))) void attn_fwd_split_kernel(SplitAttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int cap = a.cap;
@@ -56,10 +56,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const long prow0 = ((long)b * a.heads + hh) * a.T;
 
     // S^T tile (keys 16t .. 16t+15 of the resident images x this wave's 16 queries): lane (i, g) gets keys 16t + 4g + r
-    auto scores = [&](int t, const short8_t (&qfh)[2], const short8_t (&qfl)[2]) {
+    auto scores = [&](int t, const short8_t (&qfh)[KS], const short8_t (&qfl)[KS]) {
         float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < KS; ++s) {
             const short8_t kh = frag_k(khi, t * 16, s, lane), kl = frag_k(klo, t * 16, s, lane);
             acc = mfma16<true>(kl, qfh[s], acc);
             acc = mfma16<true>(kh, qfl[s], acc);
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     auto key_ok = [&](int key) { return key < T && (!mk || mk[key]); };
 
     // sweep 1 over the resident keys [c0, c0 + 16 ntc): running max / sum of this lane's keys
-    auto sweep1 = [&](int c0, int ntc, const short8_t (&qfh)[2], const short8_t (&qfl)[2], float& m, float& l) {
+    auto sweep1 = [&](int c0, int ntc, const short8_t (&qfh)[KS], const short8_t (&qfl)[KS], float& m, float& l) {
 #pragma unroll 2
         for (int t = 0; t < ntc; ++t) {
             const float4_t acc = scores(t, qfh, qfl);
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
     };
     // sweep 2: P = exp2(s - M) / L for the resident keys; O'^T += V^T P'^T with P' = 2^12 P as a half pair
-    auto sweep2 = [&](int c0, int ntc, const short8_t (&qfh)[2], const short8_t (&qfl)[2], float Ms, float inv, float* pr,
-                      float4_t (&o)[4]) {
+    auto sweep2 = [&](int c0, int ntc, const short8_t (&qfh)[KS], const short8_t (&qfl)[KS], float Ms, float inv, float* pr,
+                      float4_t (&o)[ND]) {
         const float invs = inv * kPScale;
 #pragma unroll 1
         for (int s2 = 0; s2 < ntc / 2; ++s2) {
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             }
             const short8_t pfh = join(ph[0], ph[1]), pfl = join(pl[0], pl[1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < ND; ++dt) {
                 const short8_t vh = frag_t(vhi, s2, dt, lane), vl = frag_t(vlo, s2, dt, lane);
                 o[dt] = mfma16<true>(vl, pfh, o[dt]);
                 o[dt] = mfma16<true>(vh, pfl, o[dt]);
@@ -126,11 +126,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         inv = live ? 1.f / L : 0.f;
         if (a.lse && lg == 0 && q < T) a.lse[row_idx0 + q] = live ? M + __builtin_amdgcn_logf(L) : INFINITY;
     };
-    auto store_out = [&](int q0, float4_t (&o)[4]) {
+    auto store_out = [&](int q0, float4_t (&o)[ND]) {
         if (q0 + li >= T) return;
         const long off = (row0 + q0 + li) * D + hh * HD + 4 * lg;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < ND; ++dt) {
             const float v0 = o[dt][0] * (1.f / kPScale), v1 = o[dt][1] * (1.f / kPScale), v2 = o[dt][2] * (1.f / kPScale),
                         v3 = o[dt][3] * (1.f / kPScale);
             const uint2 h = pack4<true>(v0, v1, v2, v3);
@@ -150,16 +150,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         for (int q0 = w * 16; q0 < T; q0 += nw * 16) {
             const int q = q0 + li;
             const bool qok = q < T && (!mk || mk[q]);
-            short8_t qfh[2], qfl[2];
+            short8_t qfh[KS], qfl[KS];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) { qfh[s] = frag_own(qh, ld, q0, T, s, lane); qfl[s] = frag_own(ql, ld, q0, T, s, lane); }
+            for (int s = 0; s < KS; ++s) { qfh[s] = frag_own(qh, ld, q0, T, s, lane); qfl[s] = frag_own(ql, ld, q0, T, s, lane); }
             float m = -INFINITY, l = 0.f, Ms, inv;
             sweep1(0, nt, qfh, qfl, m, l);
             finish_stats(m, l, qok, q, Ms, inv);
             float* pr = (a.probs && q < T) ? a.probs + (prow0 + q) * a.ldp : nullptr;
-            float4_t o[4];
+            float4_t o[ND];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+            for (int dt = 0; dt < ND; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
             sweep2(0, nt, qfh, qfl, Ms, inv, pr, o);
             store_out(q0, o);
         }
@@ -169,9 +169,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         const int q0 = qb0 + w * 16, q = q0 + li;
         const bool active = q0 < T;                                   // (wave-uniform; idle waves still load and synchronise)
         const bool qok = q < T && (!mk || mk[q]);
-        short8_t qfh[2], qfl[2];
+        short8_t qfh[KS], qfl[KS];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) { qfh[s] = frag_own(qh, ld, q0, T, s, lane); qfl[s] = frag_own(ql, ld, q0, T, s, lane); }
+        for (int s = 0; s < KS; ++s) { qfh[s] = frag_own(qh, ld, q0, T, s, lane); qfl[s] = frag_own(ql, ld, q0, T, s, lane); }
         float m = -INFINITY, l = 0.f, Ms = 0.f, inv = 0.f;
         for (int c0 = 0; c0 < T; c0 += SCH) {
             const int len = min(SCH, T - c0), ntc = ((len + 31) >> 5) << 1;
@@ -183,9 +183,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
         if (active) finish_stats(m, l, qok, q, Ms, inv);
         float* pr = (a.probs && q < T) ? a.probs + (prow0 + q) * a.ldp : nullptr;
-        float4_t o[4];
+        float4_t o[ND];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < ND; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
         for (int c0 = 0; c0 < T; c0 += SCH) {
             const int len = min(SCH, T - c0), ntc = ((len + 31) >> 5) << 1;
             __syncthreads();
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // first (measured at T = 129, B = 384: 309 us per layer against 79 us for the 16-bit kernel; this form: see DESIGN.md).
 template <int NT>
 // (waves_per_eu >= 2: VGPR-form MFMAs, no v_accvgpr_read_b32 per score element - see attn_kv_pass_kernel)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 10 ? 3 : 2, 8))) void attn_fwd_split_reg_kernel(SplitAttnArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NT <= 10 && HD <= 64) ? 3 : 2, 8))) void attn_fwd_split_reg_kernel(SplitAttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Tp = NT * 16;
@@ -229,9 +229,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 10 ? 
     load_image(klo, ql + D, ld, T, nt * 16);
     load_image(vhi, qh + 2 * D, ld, T, nt * 16);
     load_image(vlo, ql + 2 * D, ld, T, nt * 16);
-    short8_t qnh[2], qnl[2];                                       // the wave's first query fragments travel with the images
+    short8_t qnh[KS], qnl[KS];                                       // the wave's first query fragments travel with the images
 #pragma unroll
-    for (int s = 0; s < 2; ++s) { qnh[s] = frag_own(qh, ld, w * 16, T, s, lane); qnl[s] = frag_own(ql, ld, w * 16, T, s, lane); }
+    for (int s = 0; s < KS; ++s) { qnh[s] = frag_own(qh, ld, w * 16, T, s, lane); qnl[s] = frag_own(ql, ld, w * 16, T, s, lane); }
     images_ready();
     const float sc = a.scale * kLog2e;
     const long row_idx0 = (long)hh * a.Mtot + row0;
@@ -241,12 +241,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 10 ? 
     for (int q0 = w * 16; q0 < T; q0 += nw * 16) {
         const int q = q0 + li;
         const bool qok = q < T && (!mk || mk[q]);
-        short8_t qfh[2], qfl[2];
+        short8_t qfh[KS], qfl[KS];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) { qfh[s] = qnh[s]; qfl[s] = qnl[s]; }
+        for (int s = 0; s < KS; ++s) { qfh[s] = qnh[s]; qfl[s] = qnl[s]; }
         if (q0 + nw * 16 < T) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) { qnh[s] = frag_own(qh, ld, q0 + nw * 16, T, s, lane); qnl[s] = frag_own(ql, ld, q0 + nw * 16, T, s, lane); }
+            for (int s = 0; s < KS; ++s) { qnh[s] = frag_own(qh, ld, q0 + nw * 16, T, s, lane); qnl[s] = frag_own(ql, ld, q0 + nw * 16, T, s, lane); }
         }
         float4_t sreg[NT];
         float m = -INFINITY;
@@ -254,15 +254,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 10 ? 
         for (int t = 0; t < NT; t += 2) {
             if (t >= nt) { sreg[t] = sreg[t + 1] = float4_t{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; continue; }
             // two key tiles at a time: eight fragment reads in flight, then twelve MFMAs on two independent accumulators
-            short8_t kh0[2], kl0[2], kh1[2], kl1[2];
+            short8_t kh0[KS], kl0[KS], kh1[KS], kl1[KS];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < KS; ++s) {
                 kh0[s] = frag_k(khi, t * 16, s, lane); kl0[s] = frag_k(klo, t * 16, s, lane);
                 kh1[s] = frag_k(khi, t * 16 + 16, s, lane); kl1[s] = frag_k(klo, t * 16 + 16, s, lane);
             }
             float4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < KS; ++s) {
                 a0 = mfma16<true>(kl0[s], qfh[s], a0); a1 = mfma16<true>(kl1[s], qfh[s], a1);
                 a0 = mfma16<true>(kh0[s], qfl[s], a0); a1 = mfma16<true>(kh1[s], qfl[s], a1);
                 a0 = mfma16<true>(kh0[s], qfh[s], a0); a1 = mfma16<true>(kh1[s], qfh[s], a1);
@@ -289,9 +289,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 10 ? 
         const float inv = live ? 1.f / L : 0.f, invs = inv * kPScale;
         if (a.lse && lg == 0 && q < T) a.lse[row_idx0 + q] = live ? M + __builtin_amdgcn_logf(L) : INFINITY;
         float* pr = (a.probs && q < T) ? a.probs + (prow0 + q) * a.ldp : nullptr;
-        float4_t o[4];
+        float4_t o[ND];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < ND; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s2 = 0; s2 < NT / 2; ++s2) {
             if (2 * s2 >= nt) continue;
@@ -307,11 +307,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 10 ? 
                 pl[half] = pack4<true>(p0 - h0.x, p1 - h0.y, p2 - h1.x, p3 - h1.y);
             }
             const short8_t pfh = join(ph[0], ph[1]), pfl = join(pl[0], pl[1]);
-            short8_t vh[4], vl[4];
+            short8_t vh[ND], vl[ND];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) { vh[dt] = frag_t(vhi, s2, dt, lane); vl[dt] = frag_t(vlo, s2, dt, lane); }
+            for (int dt = 0; dt < ND; ++dt) { vh[dt] = frag_t(vhi, s2, dt, lane); vl[dt] = frag_t(vlo, s2, dt, lane); }
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < ND; ++dt) {
                 o[dt] = mfma16<true>(vl[dt], pfh, o[dt]);
                 o[dt] = mfma16<true>(vh[dt], pfl, o[dt]);
                 o[dt] = mfma16<true>(vh[dt], pfh, o[dt]);
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 10 ? 
         if (q < T) {
             const long off = (row0 + q) * D + hh * HD + 4 * lg;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < ND; ++dt) {
                 const float v0 = o[dt][0] * (1.f / kPScale), v1 = o[dt][1] * (1.f / kPScale), v2 = o[dt][2] * (1.f / kPScale),
                             v3 = o[dt][3] * (1.f / kPScale);
                 const uint2 h = pack4<true>(v0, v1, v2, v3);
@@ -363,20 +363,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         w_s[t] = t < T ? (r_in ? r_in[(long)blockIdx.x * T + t] : (t == 0 ? 1.f : 0.f)) : 0.f;
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    short8_t knh[2], knl[2];                                       // own key fragments: first tile's travel with the images
+    short8_t knh[KS], knl[KS];                                       // own key fragments: first tile's travel with the images
 #pragma unroll
-    for (int s = 0; s < 2; ++s) { knh[s] = frag_own(bh + D, ld, w * 16, T, s, lane); knl[s] = frag_own(bl + D, ld, w * 16, T, s, lane); }
+    for (int s = 0; s < KS; ++s) { knh[s] = frag_own(bh + D, ld, w * 16, T, s, lane); knl[s] = frag_own(bl + D, ld, w * 16, T, s, lane); }
     images_ready();
     const int li = lane & 15, lg = lane >> 4;
     const float sc = scale * kLog2e;
     for (int k0 = w * 16; k0 < T; k0 += nw * 16) {
         const int key = k0 + li;
-        short8_t kh[2], kl[2];
+        short8_t kh[KS], kl[KS];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) { kh[s] = knh[s]; kl[s] = knl[s]; }
+        for (int s = 0; s < KS; ++s) { kh[s] = knh[s]; kl[s] = knl[s]; }
         if (k0 + nw * 16 < T) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < KS; ++s) {
                 knh[s] = frag_own(bh + D, ld, k0 + nw * 16, T, s, lane); knl[s] = frag_own(bl + D, ld, k0 + nw * 16, T, s, lane);
             }
         }
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         for (int u = 0; u < nt; ++u) {
             float4_t s_ = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {                          // lane (i, g): queries 16u + 4g + r  x  key k0 + i
+            for (int s = 0; s < KS; ++s) {                          // lane (i, g): queries 16u + 4g + r  x  key k0 + i
                 const short8_t fh = frag_k(qhi, u * 16, s, lane), fl = frag_k(qlo, u * 16, s, lane);
                 s_ = mfma16<true>(fl, kh[s], s_);
                 s_ = mfma16<true>(fh, kl[s], s_);
@@ -418,10 +418,29 @@ int set_lds_dev(size_t bytes)
 
 }  // namespace
 
-extern "C" int editor_attention_fwd_f16x2(const uint16_t* qkv_hi, const uint16_t* qkv_lo, int B, int T, int heads, int hd,
-    float scale, const uint8_t* mask, uint16_t* out_hi, uint16_t* out_lo, float* probs, int ldp, float* lse, const int* cu,
-    long Mtot, hipStream_t stream)
+// ---- entry points (this file is compiled once per head width, as attention_bf16.hip: editor_amd/build.py -DATTN_HD=32 / 64 / 96) ----
+#if ATTN_HD == 64
+#define SPLIT_ENTRY(name) name
+#define SPLIT_DECL_WIDTHS(name, ...) extern "C" int name##_hd32(__VA_ARGS__); extern "C" int name##_hd96(__VA_ARGS__);
+#define SPLIT_OTHER_WIDTHS(name, ...) do { if (hd == 32) return name##_hd32(__VA_ARGS__); if (hd == 96) return name##_hd96(__VA_ARGS__); } while (0)
+#elif ATTN_HD == 32
+#define SPLIT_ENTRY(name) name##_hd32
+#define SPLIT_DECL_WIDTHS(name, ...)
+#define SPLIT_OTHER_WIDTHS(name, ...) do { } while (0)
+#else
+#define SPLIT_ENTRY(name) name##_hd96
+#define SPLIT_DECL_WIDTHS(name, ...)
+#define SPLIT_OTHER_WIDTHS(name, ...) do { } while (0)
+#endif
+constexpr size_t kLdsMax = 160 * 1024;
+
+#define FWD2_ARGS const uint16_t* qkv_hi, const uint16_t* qkv_lo, int B, int T, int heads, int hd, float scale, const uint8_t* mask, \
+                  uint16_t* out_hi, uint16_t* out_lo, float* probs, int ldp, float* lse, const int* cu, long Mtot, hipStream_t stream
+SPLIT_DECL_WIDTHS(editor_attention_fwd_f16x2, FWD2_ARGS)
+extern "C" int SPLIT_ENTRY(editor_attention_fwd_f16x2)(FWD2_ARGS)
 {
+    SPLIT_OTHER_WIDTHS(editor_attention_fwd_f16x2, qkv_hi, qkv_lo, B, T, heads, hd, scale, mask, out_hi, out_lo, probs, ldp, lse, cu, Mtot,
+                       stream);
     if (hd != HD || T < 1 || B < 1 || !qkv_hi || !qkv_lo || !out_hi || !out_lo) return (int)hipErrorInvalidValue;
     if (probs && (ldp < T || (ldp & 3) || (reinterpret_cast<uintptr_t>(probs) & 15) || cu)) return (int)hipErrorInvalidValue;
     if (cu && mask) return (int)hipErrorInvalidValue;
@@ -430,18 +449,17 @@ extern "C" int editor_attention_fwd_f16x2(const uint16_t* qkv_hi, const uint16_t
     SplitAttnArgs a{qkv_hi, qkv_lo, out_hi, out_lo, probs, lse, mask, T, heads, scale, ldp, cu, Mtot, rows};
     const int tiles = (T + 15) / 16;
     const int threads = (tiles % 3 == 0) ? 192 : 256;
-    if (rows <= 160 || rows <= 224) {
+    // (four images - K and V pairs - of the whole sequence must fit the CU's 160 KiB: 288 rows of 64-wide heads, 208 of 96-wide ones)
+    if (rows <= 160 && (size_t)4 * 160 * ROWB <= kLdsMax) {
         // scores in registers (one pass): NT = 10 (T <= 160) or 14 (T <= 224) key tiles
-        const bool small = rows <= 160;
-        const size_t lds = (size_t)4 * (small ? 160 : 224) * ROWB;
-        if (small) {
-            if (int rc = set_lds_dev<attn_fwd_split_reg_kernel<10>>(lds)) return rc;
-            hipLaunchKernelGGL(attn_fwd_split_reg_kernel<10>, dim3(B * heads), dim3(threads), lds, stream, a);
-        } else {
-            if (int rc = set_lds_dev<attn_fwd_split_reg_kernel<14>>(lds)) return rc;
-            hipLaunchKernelGGL(attn_fwd_split_reg_kernel<14>, dim3(B * heads), dim3(threads), lds, stream, a);
-        }
-    } else if (rows <= 288) {
+        const size_t lds = (size_t)4 * 160 * ROWB;
+        if (int rc = set_lds_dev<attn_fwd_split_reg_kernel<10>>(lds)) return rc;
+        hipLaunchKernelGGL(attn_fwd_split_reg_kernel<10>, dim3(B * heads), dim3(threads), lds, stream, a);
+    } else if (rows <= 224 && (size_t)4 * 224 * ROWB <= kLdsMax) {
+        const size_t lds = (size_t)4 * 224 * ROWB;
+        if (int rc = set_lds_dev<attn_fwd_split_reg_kernel<14>>(lds)) return rc;
+        hipLaunchKernelGGL(attn_fwd_split_reg_kernel<14>, dim3(B * heads), dim3(threads), lds, stream, a);
+    } else if (rows <= 288 && (size_t)4 * rows * ROWB <= kLdsMax) {
         const size_t lds = (size_t)4 * rows * ROWB;
         if (int rc = set_lds_dev<attn_fwd_split_kernel<false>>(lds)) return rc;
         hipLaunchKernelGGL(attn_fwd_split_kernel<false>, dim3(B * heads), dim3(threads), lds, stream, a);
@@ -454,10 +472,14 @@ extern "C" int editor_attention_fwd_f16x2(const uint16_t* qkv_hi, const uint16_t
     EDITOR_LAUNCH_CHECK();
     return 0;
 }
+#undef FWD2_ARGS
 
-extern "C" int editor_attn_rollout_step_f16x2(const uint16_t* qkv_hi, const uint16_t* qkv_lo, const float* lse, const float* r_in,
-    int B, int T, int heads, int hd, float scale, float* r_out, int final_step, hipStream_t stream)
+#define ROLL2_ARGS const uint16_t* qkv_hi, const uint16_t* qkv_lo, const float* lse, const float* r_in, int B, int T, int heads, int hd, \
+                   float scale, float* r_out, int final_step, hipStream_t stream
+SPLIT_DECL_WIDTHS(editor_attn_rollout_step_f16x2, ROLL2_ARGS)
+extern "C" int SPLIT_ENTRY(editor_attn_rollout_step_f16x2)(ROLL2_ARGS)
 {
+    SPLIT_OTHER_WIDTHS(editor_attn_rollout_step_f16x2, qkv_hi, qkv_lo, lse, r_in, B, T, heads, hd, scale, r_out, final_step, stream);
     if (hd != HD || T < 2 || B < 1 || !qkv_hi || !qkv_lo || !lse || !r_out) return (int)hipErrorInvalidValue;
     const int tiles = (T + 15) / 16;
     const int threads = (tiles % 3 == 0) ? 192 : 256;
@@ -465,6 +487,7 @@ extern "C" int editor_attn_rollout_step_f16x2(const uint16_t* qkv_hi, const uint
     const long Mtot = (long)B * T;
 #define ROLL_CASE(NTV) {                                                                                                \
         const size_t lds = (size_t)2 * NTV * 16 * ROWB + (size_t)2 * NTV * 16 * sizeof(float);                             \
+        if (lds > kLdsMax) return (int)hipErrorInvalidValue;                                                               \
         if (int rc = set_lds_dev<attn_rollout_step_split_kernel<NTV>>(lds)) return rc;                                    \
         hipLaunchKernelGGL(attn_rollout_step_split_kernel<NTV>, grid, dim3(threads), lds, stream, qkv_hi, qkv_lo, lse, r_in, T, \
                            heads, scale, Mtot, r_out, final_step); }
@@ -472,8 +495,9 @@ extern "C" int editor_attn_rollout_step_f16x2(const uint16_t* qkv_hi, const uint
     else if (T <= 224) ROLL_CASE(14)
     else if (T <= 416) ROLL_CASE(26)
     else if (T <= 608) ROLL_CASE(38)
-    else return (int)hipErrorInvalidValue;                            // the backbone's sequences are <= 608 tokens
+    else return (int)hipErrorInvalidValue;                            // the backbone's sequences are <= 608 tokens (416 at 96 columns)
 #undef ROLL_CASE
     EDITOR_LAUNCH_CHECK();
     return 0;
 }
+#undef ROLL2_ARGS

@@ -297,16 +297,12 @@ class EDITOR(nn.Module):
         self.fn_dtype_last = fn.F16X2H if self.split_selection_only else self.fn_dtype     # last backbone block
         self.fn_dtype_hma = self.act_dtype if self.split_selection_only else self.fn_dtype  # HMA head
         base = self.BACKBONE.base
-        # the fused 16-bit attention / rollout kernels are built for 32-, 64- and 96-wide heads (round 4: ViT-small's 96 and the
-        # 32-wide HMA heads of DeiT-small used to take the detour below).  Any other width - and the split-precision forward of a
-        # non-64-wide head, whose kernels exist for 64 only - keeps its 16-bit GEMMs and runs the attention product itself on the
-        # exact-f32 kernels between two casts (ops.attention_fwd): the probabilities are then materialised for the rollout as in
-        # the f32 mode, and the HMA head takes its dense-masked form
-        self.bb_attn_f32 = self.act_dtype != torch.float32 and (dim // base.heads not in ops.ATTN_HEAD_WIDTHS or
-                                                                (self.split_fwd and dim // base.heads != 64))
-        self.hma_attn_f32 = self.act_dtype != torch.float32 and (dim // self.hma_heads not in ops.ATTN_HEAD_WIDTHS or
-                                                                 (self.split_fwd and not self.split_selection_only
-                                                                  and dim // self.hma_heads != 64))
+        # the fused 16-bit and split-precision attention / rollout kernels are built for 32-, 64- and 96-wide heads (round 4:
+        # ViT-small's 96 and the 32-wide HMA heads of DeiT-small used to take the detour below).  Any other width keeps its 16-bit
+        # GEMMs and runs the attention product itself on the exact-f32 kernels between two casts (ops.attention_fwd): the
+        # probabilities are then materialised for the rollout as in the f32 mode, and the HMA head takes its dense-masked form
+        self.bb_attn_f32 = self.act_dtype != torch.float32 and dim // base.heads not in ops.ATTN_HEAD_WIDTHS
+        self.hma_attn_f32 = self.act_dtype != torch.float32 and dim // self.hma_heads not in ops.ATTN_HEAD_WIDTHS
         # per-model options of the autograd nodes (installed at the top of every forward, captured by the nodes' ctx)
         self.grad_scale_f16 = float(cfg.MODEL.GRAD_SCALE) if hasattr(cfg.MODEL, "GRAD_SCALE") else None
         self.act_light = bool(getattr(cfg.MODEL, "ACT_LIGHT", False))   # 24 instead of 36 saved bytes per token-row-element

@@ -596,9 +596,9 @@ def attention_fwd_split(qkv, b, t, heads, hd, mask=None, probs=None, cu=None, sc
     d = heads * hd
     rows = hi.shape[0]
     scale = float(scale or hd ** -0.5)
-    if hd != 64:                                         # (see attention_fwd) the pair is summed back into fp32 - exact - first
+    if hd not in ATTN_HEAD_WIDTHS:                       # (see attention_fwd) the pair is summed back into fp32 - exact - first
         if cu is not None:
-            raise RuntimeError("variable-length attention needs 64-wide heads (use the dense-masked HMA form)")
+            raise RuntimeError("variable-length attention needs 32 / 64 / 96-wide heads (use the dense-masked HMA form)")
         out32, probs = attention_fwd(hi.float() + lo.float(), b, t, heads, hd, mask, probs, cu=None, scale=scale)
         return split_f32(out32), probs
     out_hi = _packed_alloc(rows, d, torch.float16, hi.device, cu)

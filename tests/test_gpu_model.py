@@ -140,9 +140,9 @@ def test_small_factory_architectures_f32_vs_oracle(arch, heads, qk, oracle):
 @pytest.mark.parametrize("arch,heads,qk", [("vit_small_patch16_224", 8, 768 ** -0.5), ("deit_small_patch16_224", 6, None)])
 def test_small_factory_architectures_16bit_modes(arch, heads, qk, dtype, oracle):
     """The same two backbones in the 16-bit modes: GEMMs, LayerNorms and every other kernel as usual; the attention products
-    of their 96- / 32-wide heads run on the fused 16-bit kernels built for those widths (round 4; bf16 / f16: compacted HMA
-    head and probability-free rollout as for ViT-B) - in f16x2 on the exact-f32 kernels between two casts (the split-precision
-    attention kernels exist for 64-wide heads), rollout on materialised probabilities.  Checked like the ViT-B modes: features with
+    of their 96- / 32-wide heads run on the fused 16-bit / split-precision kernels built for those widths (round 4: compacted HMA
+    head and probability-free rollout as for ViT-B; until then the exact-f32 kernels between two casts).  Checked like the ViT-B
+    modes: features with
     the oracle's selection teacher-forced (bf16 1e-2, f16 1e-3), f16x2 free-running with bit-identical selection; one
     training step against the oracle's gradients."""
     seed, batch = 5, 8

@@ -183,6 +183,49 @@ def test_rollout_f16x2_recomputed_from_pairs(t):
     assert rel_err(one.view(b, heads, t).double().cpu(), refs[-1][:, :, 0, :]) < 2e-6
 
 
+@pytest.mark.parametrize("hd,heads", [(32, 12), (96, 8)])
+@pytest.mark.parametrize("t", [129, 193, 387])
+def test_attention_f16x2_other_head_widths(hd, heads, t):
+    """Round 4: the split-precision attention and rollout kernels at the factory's other head widths (32: DeiT-small's HMA heads,
+    96: ViT-small's backbone) - fp32-class against float64, as at 64 columns; T = 193 / 387 take the chunked form at 96 columns
+    (four images of the whole sequence do not fit the LDS there)."""
+    from editor_amd import ops
+    b = 3
+    d = heads * hd
+    g = torch.Generator().manual_seed(7 * t + hd)
+    qkv = torch.randn(b * t, 3 * d, generator=g) * 0.8
+    x = qkv.double()
+    outs, probs_ref = [], []
+    for i in range(b):
+        q, k, v = (x[i * t:(i + 1) * t, j * d:(j + 1) * d].view(t, heads, hd).transpose(0, 1) for j in range(3))
+        p = torch.softmax(q @ k.transpose(1, 2) * hd ** -0.5, dim=-1)
+        probs_ref.append(p)
+        outs.append((p @ v).transpose(0, 1).reshape(t, d))
+    ref = torch.cat(outs)
+    pair = _pair(qkv)
+    ldp = (t + 3) // 4 * 4
+    probs = torch.zeros(b, heads, t, ldp, device="cuda")
+    (oh, ol), lse = ops.attention_fwd_split(pair, b, t, heads, hd, None, probs)
+    assert lse.dim() == 1                                     # the split kernel, not the exact-f32 detour
+    e_out, e_p = rel_err(_join(oh, ol), ref), rel_err(probs[..., :t].double().cpu(), torch.stack(probs_ref))
+    print("attention f16x2 hd=%d T=%d: out %.2e probs %.2e" % (hd, t, e_out, e_p))
+    assert e_out < 1e-6 and e_p < 1e-6
+    # the 16-bit backward runs on the hi halves with this lse (the f16x2 mode's backward)
+    do = torch.randn(b * t, d, generator=g).half().cuda()
+    dqkv = ops.attention_bwd(pair[0], do, b, t, heads, hd, None, lse, oh)
+    qr = qkv.clone().requires_grad_(True)
+    o32 = []
+    for i in range(b):
+        q, k, v = (qr[i * t:(i + 1) * t, j * d:(j + 1) * d].view(t, heads, hd).transpose(0, 1) for j in range(3))
+        o32.append((torch.softmax(q @ k.transpose(1, 2) * hd ** -0.5, dim=-1) @ v).transpose(0, 1).reshape(t, d))
+    torch.cat(o32).backward(do.float().cpu())
+    assert rel_err(dqkv.float().cpu(), qr.grad) < 5e-3
+    if t <= 416:
+        r = probs_ref_roll = torch.stack(probs_ref)[:, :, 0:1, :]
+        got = ops.attn_rollout_qk([(pair[0], pair[1], lse)], b, t, heads, hd)
+        assert rel_err(got.double().cpu(), r[:, :, 0, 1:]) < 2e-6
+
+
 def test_attention_f16x2_masked_and_varlen():
     from editor_amd import ops
     b, t, heads, hd = 4, 129, 12, 64
