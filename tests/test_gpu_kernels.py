@@ -610,6 +610,35 @@ def test_four_wave_gemm_tile_equals_ping_pong(ops, m, n, k):
         assert rel_err(y1.float().cpu(), x.float().cpu() @ w.float().cpu().t()) < 1e-2
 
 
+def test_gemm_reverse_row_order_is_bit_identical(ops):
+    """EDITOR_EPI_REVERSE_ROWS (round 4, an option): the ping-pong kernel takes its tile rows last-first - every tile computed as
+    before, so outputs and the column sums of the epilogue are bit-identical (plain, GELU two-output, fp32-residual epilogues,
+    full and 208-row tiles)."""
+    m, k = 3 * 16 * 129, 768
+    g = _g(31)
+    x = torch.randn(m, k, generator=g).bfloat16().cuda()
+    for n in (768, 2304):
+        w = (torch.randn(n, k, generator=g) * 0.05).bfloat16().cuda()
+        bias = torch.randn(n, generator=g).cuda()
+        res = torch.randn(m, n, generator=g).cuda()
+        rs = torch.rand(m, generator=g).cuda()
+        for extra in (ops.EPI_FORCE_PP, ops.EPI_TILE_ROWS(208)):
+            outs = []
+            for rev in (0, ops.EPI_REVERSE_ROWS):
+                y = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+                cs = torch.empty(n, device="cuda")
+                ops.gemm(x, w, y, m, n, k, k, k, n, 0, 0, bias=bias, epilogue=extra | rev,
+                         colsum=cs if ops.gemm_colsum_ok(m, n, k, y.dtype, 0, 1, None) else None)
+                y2 = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+                aux = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+                ops.gemm(x, w, y2, m, n, k, k, k, n, 0, 0, bias=bias, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD | extra | rev, aux=aux)
+                yf = torch.empty(m, n, device="cuda")
+                ops.gemm(x, w, yf, m, n, k, k, k, n, 0, 0, bias=bias, rowscale=rs, epilogue=ops.EPI_RESIDUAL | extra | rev, aux=res)
+                outs.append((y, cs, y2, aux, yf))
+            for a, b in zip(*outs):
+                assert torch.equal(a, b)
+
+
 def test_compact_plan_and_rows(ops):
     g = _g(11)
     b, n, d, nmod = 7, 128, 256, 3

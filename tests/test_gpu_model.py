@@ -378,6 +378,26 @@ def test_eval_f16x2_selection_and_features_match_reference_goldens(tag, preset, 
     assert err < 1e-4
 
 
+def test_eval_f16x2_rollout_recomputed_option_selects_identically():
+    """cfg.MODEL.SPLIT_ROLLOUT_RECOMPUTE (round 4, default off): the split-precision rollout recomputes every layer's probabilities
+    from the q / k half pairs (editor_attn_rollout_step_f16x2) instead of reading the materialised fp32 tensor - the reference's
+    selection bit for bit all the same, in both split scopes; features equal to the default form's."""
+    g = load_golden("f3_eval_vitb_256x128")
+    seed, batch = int(g["seed"]), int(g["batch"])
+    cams = config.preset("RGBNT201")[2]
+    img, label, cam, view = _cuda_batch(*synth.make_batch(seed + 1, batch, 256, 128, cams))
+    for dtype in ("f16x2", "f16x2s"):
+        outs = []
+        for rec in (False, True):
+            m, cfg, c, cams = _model("RGBNT201", seed, dtype, drop_path=0.0, split_rollout_recompute=rec)
+            assert m.split_rollout_recompute == rec
+            m.eval()
+            with torch.no_grad():
+                outs.append(m(img, cam_label=cam, view_label=view).clone())
+            assert torch.equal(m.last_aux["index"].cpu().bool(), t(g["index"])), (dtype, rec)
+        assert torch.equal(outs[0], outs[1])
+
+
 def test_hipgraph_replay_matches_eager_training():
     """The whole training step (forward, HIP loss head, backward with the side-stream weight gradients, fused SGD with
     drop-path) captured into a hipGraph and replayed == the same number of eager steps: identical kernels on identical
