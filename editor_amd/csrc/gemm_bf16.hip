@@ -1306,6 +1306,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_group_kernel(GemmGroupArgs g
     pp_body<F16, false, false, true, 8, 8, false>(ga.p[pi], t - ga.start[pi], split);
 }
 
+// GROUPED forward / dgrad products (round 4): up to four products of IDENTICAL shape, layout and epilogue kind with different
+// operands - the three per-modality blocks of the HMA head, whose ~7 400 live token rows make 87 tiles of a 768-wide output each
+// (a third of a round of 256 CUs per launch) - as ONE launch: grid = the problems' tiles back to back.  Each workgroup runs the
+// plain kernel's body on its problem's arguments: same tiles, same arithmetic, bit-identical to the separate launches.
+template <bool F16, bool C_F32>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_fgroup_kernel(GemmGroupArgs ga)
+{
+    const int ntile = ga.start[1];                               // tiles per problem (all equal)
+    int pi = (int)blockIdx.x / ntile;
+    pi = __builtin_amdgcn_readfirstlane(pi);
+    pp_body<F16, true, true, C_F32, 8, 8, false>(ga.p[pi], (int)blockIdx.x - pi * ntile, 0);
+}
+
 __global__ void scale_c_kernel(float* C, long rows, int cols, long ld, float beta)
 {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1637,6 +1650,58 @@ int gemm_wgrad_group(int count, const uint16_t* const* dy, const uint16_t* const
 }
 
 }  // namespace
+
+template <bool F16>
+int gemm_fwd_group(int count, const uint16_t* const* A, const uint16_t* const* B, void* const* C, int c_f32, int M, int N, int K,
+                   long lda, long ldb, long ldc, float alpha, const float* const* bias, const float* const* rowscale, int epilogue,
+                   void* const* aux, long ldaux, const int* m_live, hipStream_t stream)
+{
+    if (count < 1 || count > kMaxGroup || M < 256 || N < 256 || (N & 255) || K < BK || (K % BK)) return (int)hipErrorInvalidValue;
+    if ((lda & 7) || (ldb & 7) || (ldc & 7) || (ldaux & 7)) return (int)hipErrorInvalidValue;
+    const bool aux_grad = (epilogue & EDITOR_EPI_AUX_GRAD) != 0;
+    epilogue &= ~(EDITOR_EPI_FORCE_PP | EDITOR_EPI_AUX_GRAD);
+    if (epilogue != EDITOR_EPI_NONE && epilogue != EDITOR_EPI_RESIDUAL && epilogue != EDITOR_EPI_GELU && epilogue != EDITOR_EPI_GELU_BWD)
+        return (int)hipErrorInvalidValue;
+    if (aux_grad && epilogue != EDITOR_EPI_GELU && epilogue != EDITOR_EPI_GELU_BWD) return (int)hipErrorInvalidValue;
+    GemmGroupArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.n = count;
+    const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
+    for (int i = 0; i < count; ++i) {
+        if (!A[i] || !B[i] || !C[i]) return (int)hipErrorInvalidValue;
+        void* ax = aux ? aux[i] : nullptr;
+        if (epilogue != EDITOR_EPI_NONE && !ax && epilogue != EDITOR_EPI_GELU) return (int)hipErrorInvalidValue;
+        if ((reinterpret_cast<uintptr_t>(A[i]) | reinterpret_cast<uintptr_t>(B[i]) | reinterpret_cast<uintptr_t>(C[i])) & 15)
+            return (int)hipErrorInvalidValue;
+        GemmB16Args g{(const bf16_t*)A[i], (const bf16_t*)B[i], C[i], M, N, K, lda, ldb, ldc, alpha, 0.f, bias ? bias[i] : nullptr,
+                      rowscale ? rowscale[i] : nullptr, 1, tiles_m, tiles_n, epilogue, ax, ldaux, 0, m_live, 0, 1, nullptr, nullptr, 1,
+                      aux_grad ? 1 : 0, 0, nullptr, nullptr, nullptr, 0, 0};
+        ga.p[i] = g;
+        ga.start[i] = i * tiles_m * tiles_n;
+    }
+    ga.start[count] = count * tiles_m * tiles_n;
+    for (int i = count + 1; i <= kMaxGroup; ++i) ga.start[i] = ga.start[count];
+    constexpr int LDS = 256 * (256 * 2 + 16) + (int)kLutBytes;
+    const dim3 grid(count * tiles_m * tiles_n);
+    if (c_f32) {
+        if (int e = ensure_lds<gemm_bf16_pp_fgroup_kernel<F16, true>>(LDS)) return e;
+        hipLaunchKernelGGL((gemm_bf16_pp_fgroup_kernel<F16, true>), grid, dim3(512), LDS, stream, ga);
+    } else {
+        if (int e = ensure_lds<gemm_bf16_pp_fgroup_kernel<F16, false>>(LDS)) return e;
+        hipLaunchKernelGGL((gemm_bf16_pp_fgroup_kernel<F16, false>), grid, dim3(512), LDS, stream, ga);
+    }
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_gemm_group(int dtype, int count, const uint16_t* const* A, const uint16_t* const* B, void* const* C, int c_f32,
+    int M, int N, int K, long lda, long ldb, long ldc, float alpha, const float* const* bias, const float* const* rowscale,
+    int epilogue, void* const* aux, long ldaux, const int* m_live, hipStream_t stream)
+{
+    if (dtype == 2) return gemm_fwd_group<true>(count, A, B, C, c_f32, M, N, K, lda, ldb, ldc, alpha, bias, rowscale, epilogue, aux, ldaux, m_live, stream);
+    if (dtype == 1) return gemm_fwd_group<false>(count, A, B, C, c_f32, M, N, K, lda, ldb, ldc, alpha, bias, rowscale, epilogue, aux, ldaux, m_live, stream);
+    return (int)hipErrorInvalidValue;
+}
 
 extern "C" int editor_gemm_wgrad_group(int dtype, int count, const uint16_t* const* dy, const uint16_t* const* x, float* const* dw,
     const int* N, const int* K, int M, float alpha, int splitk, float* ws, const int* m_live, hipStream_t stream)

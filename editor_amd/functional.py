@@ -187,6 +187,108 @@ WGRAD_DEFER_JOIN = os.environ.get("EDITOR_WGRAD_DEFER", "1") != "0"       # meas
 DEFER_REDUCE = os.environ.get("EDITOR_DEFER_REDUCE", "1") != "0"     # measurement switch: ops.ReduceQueue in the block backward
 
 
+# ---- launch requests (round 4) ------------------------------------------------------------------------------------------------
+# The forward and backward of a transformer block are written as GENERATORS that yield their large GEMM launches (and the grouped
+# weight-gradient launch) as requests instead of issuing them.  One block: `_drive` issues every request as it comes - the same
+# launches in the same order as before.  Several blocks of identical shape (the HMA head's per-modality blocks, GroupedBlocksFn):
+# `_drive_group` advances them in lockstep and sends requests that agree in everything but their operands out as ONE grouped launch
+# (ops.gemm_group: 87 live tiles per product and modality are a third of a round of the 256 CUs).  Same kernels, same tiles: the
+# results are bit-identical either way.
+class _GemmReq:
+    __slots__ = ("args", "kw")
+
+    def __init__(self, *args, **kw):
+        self.args, self.kw = args, kw
+
+
+class _WgradReq:
+    __slots__ = ("jobs", "m", "alpha", "m_live", "deferred", "dev")
+
+    def __init__(self, jobs, m, alpha, m_live, deferred, dev):
+        self.jobs, self.m, self.alpha, self.m_live, self.deferred, self.dev = jobs, m, alpha, m_live, deferred, dev
+
+
+def _run_wgrads(reqs):
+    """the grouped weight-gradient launches of one or several blocks: side stream (joined one block later when the gradients land in
+    sinks, see GROUP_WGRAD below) or inline"""
+    dev = reqs[0].dev
+    if WGRAD_SIDE_STREAM:
+        if any(r.deferred for r in reqs):
+            join_side_stream(dev)                   # the PREVIOUS block's grouped launch (had a whole block of slack)
+        ready = torch.cuda.current_stream(dev).record_event()
+        side = _side_stream(dev)
+        side.wait_event(ready)
+        for r in reqs:
+            _SIDE_KEEP.append([(j[0], j[1]) for j in r.jobs])      # operands stay referenced until the join
+        with torch.cuda.stream(side):
+            for r in reqs:
+                ops.gemm_wgrad_group(r.jobs, r.m, r.alpha, r.m_live)
+    else:
+        for r in reqs:
+            ops.gemm_wgrad_group(r.jobs, r.m, r.alpha, r.m_live)
+
+
+def _run_req(req):
+    if isinstance(req, _GemmReq):
+        ops.gemm(*req.args, **req.kw)
+    else:
+        _run_wgrads([req])
+
+
+def _drive(gen):
+    """run a block generator alone: every request is issued as it is yielded"""
+    try:
+        while True:
+            _run_req(next(gen))
+    except StopIteration as e:
+        return e.value
+
+
+_GROUP_SLOT = [0, 1]        # (slot, slots) of the block whose generator is running: its share of per-stream scratch (ops.ReduceQueue)
+
+
+def _drive_group(gens):
+    """run block generators of identical structure in lockstep, grouping the requests they yield together"""
+    n = len(gens)
+    results = [None] * n
+    while True:
+        reqs, stopped = [], 0
+        for i, g_ in enumerate(gens):
+            _GROUP_SLOT[0], _GROUP_SLOT[1] = i, n
+            try:
+                reqs.append(next(g_))
+            except StopIteration as e:
+                results[i] = e.value
+                stopped += 1
+            finally:
+                _GROUP_SLOT[0], _GROUP_SLOT[1] = 0, 1
+        if stopped == n:
+            return results
+        if stopped:
+            raise RuntimeError("grouped blocks left lockstep (their shapes / options must be identical)")
+        if all(isinstance(r, _GemmReq) for r in reqs) and ops.gemm_group_ok([(r.args, r.kw) for r in reqs]):
+            ops.gemm_group([(r.args, r.kw) for r in reqs])
+        elif all(isinstance(r, _WgradReq) for r in reqs):
+            _run_wgrads(reqs)
+        else:
+            for r in reqs:
+                _run_req(r)
+
+
+class _SubCtx:
+    """what a block generator needs of an autograd ctx, for the blocks inside GroupedBlocksFn"""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = tuple(needs_input_grad)
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
 # EDITOR_REVERSE_ROWS=1 (A/B switch, round 4): the GEMMs whose row operand is a tensor LARGER than the 256 MB Infinity Cache that the
 # previous launch has just written - fc2 after fc1's GELU output (304 MB at B = 128), fc1's dgrad after fc2's dgrad, the qkv dgrad
 # after the attention backward's dqkv (228 MB) - take their tile rows last-first (ops.EPI_REVERSE_ROWS): they start with the rows
@@ -194,8 +296,13 @@ DEFER_REDUCE = os.environ.get("EDITOR_DEFER_REDUCE", "1") != "0"     # measureme
 REVERSE_ROWS = ops.EPI_REVERSE_ROWS if os.environ.get("EDITOR_REVERSE_ROWS", "0") == "1" else 0
 
 
-def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None, gs=1.0, dw_out=None,
-                db_out=None, dxcs_out=None, w_t=None, defer=None, aux_is_grad=True, rq=None, rev=0):
+def _linear_bwd(*args, **kw):
+    """_linear_bwd_gen run alone (the small fp32 linears, PatchEmbedFn): every launch issued in place"""
+    return _drive(_linear_bwd_gen(*args, **kw))
+
+
+def _linear_bwd_gen(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None, gs=1.0, dw_out=None,
+                    db_out=None, dxcs_out=None, w_t=None, defer=None, aux_is_grad=True, rq=None, rev=0):
     """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy) (or the
     caller's, when the kernel that produced dy summed its columns on the way).  dx_colsum: also return colsum(dx) - the
     bias gradient of the layer BELOW - from the dgrad's own epilogue when it can deliver it (else None).
@@ -214,12 +321,12 @@ def _linear_bwd(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, 
     # B = W stored (Kred=n, Nout=k): row-k operand (trans_b = 1); or its k-major copy W^T (Nout=k, Kred=n): trans_b = 0
     wb, ldb, tb = (w_t, n, 0) if w_t is not None else (w_act, k, 1)
     if gelu_pre is None:
-        ops.gemm(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, epilogue=rev, m_live=m_live, colsum=dxcs, colsum_scale=inv, tag="dgrad",
-                 rq=rq)
+        yield _GemmReq(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, epilogue=rev, m_live=m_live, colsum=dxcs, colsum_scale=inv, tag="dgrad",
+                       rq=rq)
     else:
         ag = ops.EPI_AUX_GRAD if (dy.dtype in ops.HALF_DTYPES and aux_is_grad) else 0   # 16-bit: gelu_pre holds gelu'(pre-activation)
-        ops.gemm(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, epilogue=ops.EPI_GELU_BWD | ag, aux=gelu_pre, m_live=m_live,
-                 colsum=dxcs, colsum_scale=inv, tag="dgrad", rq=rq)
+        yield _GemmReq(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, epilogue=ops.EPI_GELU_BWD | ag, aux=gelu_pre, m_live=m_live,
+                       colsum=dxcs, colsum_scale=inv, tag="dgrad", rq=rq)
     dw = dw_out if dw_out is not None else torch.empty(n, k, dtype=torch.float32, device=dy.device)
     if need_bias and db is None:
         db = db_out if db_out is not None else torch.empty(n, dtype=torch.float32, device=dy.device)
@@ -285,9 +392,18 @@ class TransformerBlockFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, mask, probs_out,
-                heads, eps, act_dtype, rowscale_attn, rowscale_mlp, cu=None, max_t=None, m_live=None, qk_scale=None,
-                sink=None, pend_branch=None, pend_rs=None, defer_out=False, branch16=False):
+    def forward(ctx, *args):
+        return _drive(TransformerBlockFn.forward_gen(ctx, *args))
+
+    @staticmethod
+    def backward(ctx, dx2, *_unused):
+        return _drive(TransformerBlockFn.backward_gen(ctx, dx2))
+
+    @staticmethod
+    def forward_gen(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, mask, probs_out,
+                    heads, eps, act_dtype, rowscale_attn, rowscale_mlp, cu=None, max_t=None, m_live=None, qk_scale=None,
+                    sink=None, pend_branch=None, pend_rs=None, defer_out=False, branch16=False):
+        # (a generator: the four large products of the plain 16-bit path are YIELDED as launch requests, see _drive / _drive_group)
         # branch16 (cfg.MODEL.BRANCH16; bf16 backbone blocks): the projection and fc2 products write their 16-bit branch output with
         # the plain epilogue and the residual add happens inside the LayerNorm that follows (ops.resid_add_layernorm_fwd) - the
         # next block's LayerNorm-1 for the fc2 branch: `defer_out` makes this node return (x1, fc2 branch) instead of x2, and
@@ -363,7 +479,8 @@ class TransformerBlockFn(torch.autograd.Function):
                 x2d, h1, mean1, rstd1 = ops.resid_add_layernorm_fwd(x2d, pend_branch, pend_rs, n1w, n1b, eps)
             else:
                 h1, mean1, rstd1 = ops.layernorm_fwd(x2d, n1w, n1b, eps, act_dtype, mask, 0, m_live=m_live)
-            qkv = _linear_fwd(h1, wq, qkvb, act_dtype, m_live)
+            qkv = torch.empty(m, 3 * d, dtype=act_dtype, device=x.device)
+            yield _GemmReq(h1, wq, qkv, m, 3 * d, d, d, d, 3 * d, 0, 0, bias=qkvb, m_live=m_live)
             if isinstance(probs_out, list):            # bf16 backbone: no probability tensor; the rollout recomputes it
                 ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, None, cu=cu, scale=qk_scale)
                 probs_out.append((qkv, attn_saved))
@@ -376,8 +493,8 @@ class TransformerBlockFn(torch.autograd.Function):
             del br1
         else:
             x1 = torch.empty_like(x2d)              # x1 = x + rs * (ao Wp^T + b): residual add in the GEMM epilogue
-            ops.gemm(ao, wp, x1, m, d, d, d, d, d, 0, 0, bias=projb, rowscale=rowscale_attn,
-                     epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)
+            yield _GemmReq(ao, wp, x1, m, d, d, d, d, d, 0, 0, bias=projb, rowscale=rowscale_attn,
+                           epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)
             h2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, eps, act_dtype, mask, 0, m_live=m_live)
         hidden = w1.shape[0]
         # (a no-grad forward - model.eval() under torch.no_grad(), engine/processor.py:217-270 - saves nothing for a backward: the
@@ -389,15 +506,15 @@ class TransformerBlockFn(torch.autograd.Function):
         # epilogue instead of an erfc + exponential per element); the f32 parity kernels keep the pre-activation
         light = ACT_LIGHT and act_dtype in ops.HALF_DTYPES
         ag = ops.EPI_AUX_GRAD if (act_dtype in ops.HALF_DTYPES and not light) else 0     # light: `a` keeps the pre-activation
-        ops.gemm(h2, w1, g, m, hidden, d, d, d, hidden, 0, 0, bias=fc1b, epilogue=ops.EPI_GELU | ag, aux=a, m_live=m_live)
+        yield _GemmReq(h2, w1, g, m, hidden, d, d, d, hidden, 0, 0, bias=fc1b, epilogue=ops.EPI_GELU | ag, aux=a, m_live=m_live)
         br2 = None
         if defer_out:                               # (x1, fc2 branch): the consumer's LayerNorm adds them
             br2 = torch.empty(m, d, dtype=act_dtype, device=x.device)
             ops.gemm(g, w2, br2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b)
         else:
             x2 = torch.empty_like(x2d)
-            ops.gemm(g, w2, x2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b, rowscale=rowscale_mlp,
-                     epilogue=ops.EPI_RESIDUAL | (REVERSE_ROWS if m_live is None else 0), aux=x1, m_live=m_live)
+            yield _GemmReq(g, w2, x2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b, rowscale=rowscale_mlp,
+                           epilogue=ops.EPI_RESIDUAL | (REVERSE_ROWS if m_live is None else 0), aux=x1, m_live=m_live)
         if light:
             h1 = h2 = g = None                      # recomputed by the backward (n1b / n2b / eps ride along)
         ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
@@ -412,7 +529,7 @@ class TransformerBlockFn(torch.autograd.Function):
         return x2.view(x.shape)
 
     @staticmethod
-    def backward(ctx, dx2, *_unused):
+    def backward_gen(ctx, dx2):
         (x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w, qkvw, projw, fc1w, fc2w, mask,
          attn_saved, rs_attn, rs_mlp, cu, m_live) = ctx.saved_tensors
         b, t, d, heads, act_dtype, hb_qkv, hb_proj, hb_fc1, hb_fc2, xshape, qk_scale, sink = ctx.meta
@@ -437,15 +554,15 @@ class TransformerBlockFn(torch.autograd.Function):
         deferred = jobs is not None and sink is not None and WGRAD_SIDE_STREAM and WGRAD_DEFER_JOIN
         # the block's six second-stage reductions (LayerNorm dgamma / dbeta x2, bias gradients, the fc2 dgrad's column sums) as
         # ONE launch at the end (ops.ReduceQueue); only with the grouped weight gradients, where every producer runs on this stream
-        rq = ops.ReduceQueue(dx2.device) if (DEFER_REDUCE and jobs is not None) else None
+        rq = ops.ReduceQueue(dx2.device, _GROUP_SLOT[0], _GROUP_SLOT[1]) if (DEFER_REDUCE and jobs is not None) else None
         # ---- MLP branch:  x2 = x1 + rs * fc2(gelu(fc1(LN2(x1))))
         dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2, gs, cs_out=sv[11], rq=rq)
-        da, dw2, db2, da_cs = _linear_bwd(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live, db=dbias,
+        da, dw2, db2, da_cs = yield from _linear_bwd_gen(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live, db=dbias,
                                           dx_colsum=hb_fc1, gs=gs, dw_out=sv[10], db_out=sv[11],
                                           dxcs_out=sv[9], w_t=w2t, defer=jobs, aux_is_grad=light is None, rq=rq)   # da = (dy W2) * gelu'(a)
         if light is not None:
             h2 = ops.layernorm_fwd(x1, n2w, light[1], light[2], act_dtype, mask, 0, want_stats=False, m_live=m_live)[0]
-        dh2, dw1, db1 = _linear_bwd(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs, gs=gs, dw_out=sv[8], db_out=sv[9], w_t=w1t,
+        dh2, dw1, db1 = yield from _linear_bwd_gen(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs, gs=gs, dw_out=sv[8], db_out=sv[9], w_t=w1t,
                                     defer=jobs, rq=rq, rev=REVERSE_ROWS if m_live is None else 0)
         fuse_cast = (FUSE_LN_CAST and m_live is None and mask is None and act_dtype in ops.HALF_DTYPES
                      and d % 256 == 0 and d <= 1024)
@@ -460,28 +577,17 @@ class TransformerBlockFn(torch.autograd.Function):
                                                 dy_scale=1.0 / gs, dgb_out=sink.ln_pair(6) if sink is not None else None, rq=rq)
             # ---- attention branch:  x1 = x + rs * proj(attn(qkv(LN1(x))))
             dy, dbias = _scaled_cast_colsum(dx1, rs_attn, act_dtype, m_live, hb_proj, gs, cs_out=sv[5], rq=rq)
-        dao, dwp, dbp = _linear_bwd(dy, ao, wp, hb_proj, m_live=m_live, db=dbias, gs=gs, dw_out=sv[4], db_out=sv[5], w_t=wpt,
+        dao, dwp, dbp = yield from _linear_bwd_gen(dy, ao, wp, hb_proj, m_live=m_live, db=dbias, gs=gs, dw_out=sv[4], db_out=sv[5], w_t=wpt,
                                     defer=jobs, rq=rq)
         dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, amask, attn_saved, ao, cu=cu, scale=qk_scale)
         if light is not None:
             h1 = ops.layernorm_fwd(x2d, n1w, light[0], light[2], act_dtype, mask, 0, want_stats=False, m_live=m_live)[0]
-        dh1, dwq, dbq = _linear_bwd(dqkv, h1, wq, hb_qkv, m_live=m_live, gs=gs, dw_out=sv[2], db_out=sv[3], w_t=wqt,
+        dh1, dwq, dbq = yield from _linear_bwd_gen(dqkv, h1, wq, hb_qkv, m_live=m_live, gs=gs, dw_out=sv[2], db_out=sv[3], w_t=wqt,
                                     defer=jobs, rq=rq, rev=REVERSE_ROWS if m_live is None else 0)
         if jobs:
             # every dy exists: the block's four weight gradients in one launch.  Side stream (joined one block later)
             # unless a gradient sink needs them at the end of THIS block
-            dev = dx2.device
-            if WGRAD_SIDE_STREAM:
-                if deferred:
-                    join_side_stream(dev)                   # the PREVIOUS block's grouped launch (had a whole block of slack)
-                ready = torch.cuda.current_stream(dev).record_event()
-                side = _side_stream(dev)
-                side.wait_event(ready)
-                _SIDE_KEEP.append([(j[0], j[1]) for j in jobs])      # operands stay referenced until the join
-                with torch.cuda.stream(side):
-                    ops.gemm_wgrad_group(jobs, m, 1.0 / gs, m_live)
-            else:
-                ops.gemm_wgrad_group(jobs, m, 1.0 / gs, m_live)
+            yield _WgradReq(jobs, m, 1.0 / gs, m_live, deferred, dx2.device)
         dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1, m_live=m_live,
                                            dy_scale=1.0 / gs, dgb_out=sink.ln_pair(0) if sink is not None else None, rq=rq)
         if rq is not None:
@@ -495,6 +601,52 @@ class TransformerBlockFn(torch.autograd.Function):
             grads = tuple(None if v is not None else g_ for g_, v in zip(grads, sv))
             sink.done()
         return (dx.view(xshape),) + grads + (None,) * 17
+
+
+GROUP_BLOCKS = os.environ.get("EDITOR_GROUP_BLOCKS", "1") != "0"      # A/B switch: GroupedBlocksFn for the HMA modality blocks
+
+
+class GroupedBlocksFn(torch.autograd.Function):
+    """`nblk` transformer blocks of IDENTICAL shape and options on different inputs and weights - the per-modality blocks of
+    BlockMask.forward (vit_pytorch.py:311-317: blocksR / blocksN / blocksT) - as one autograd node whose forward and backward run
+    the blocks in lockstep (TransformerBlockFn.forward_gen / backward_gen under _drive_group): every large product of the three blocks
+    leaves as ONE grouped launch.  Arguments: nblk, then nblk x the argument list of TransformerBlockFn.forward (same length each).
+    Returns the nblk outputs.  Bit-identical to nblk TransformerBlockFn nodes (tests/test_gpu_model.py)."""
+
+    @staticmethod
+    def forward(ctx, nblk, *flat):
+        per = len(flat) // nblk
+        assert per * nblk == len(flat) and per >= 20
+        subs, gens = [], []
+        for i in range(nblk):
+            sc = _SubCtx(ctx.needs_input_grad[1 + i * per:1 + (i + 1) * per])
+            subs.append(sc)
+            gens.append(TransformerBlockFn.forward_gen(sc, *flat[i * per:(i + 1) * per]))
+        outs = _drive_group(gens)
+        saved = []
+        for sc in subs:
+            sc.nsaved = len(sc.saved_tensors)
+            saved.extend(sc.saved_tensors)
+            sc.saved_tensors = ()
+        ctx.save_for_backward(*saved)
+        ctx.subs, ctx.per = subs, per
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        saved, off = ctx.saved_tensors, 0
+        gens = []
+        for sc, dout in zip(ctx.subs, douts):
+            sc.saved_tensors = saved[off:off + sc.nsaved]
+            off += sc.nsaved
+            gens.append(TransformerBlockFn.backward_gen(sc, dout))
+        res = _drive_group(gens)
+        for sc in ctx.subs:
+            sc.saved_tensors = ()
+        out = (None,)
+        for r in res:
+            out = out + tuple(r[:ctx.per])
+        return out
 
 
 def _scaled_cast_colsum(dx, rowscale, dtype, m_live, want_colsum, gs=1.0, cs_out=None, rq=None):

@@ -477,12 +477,18 @@ class EDITOR(nn.Module):
         xa = fn.GatherRowsFn.apply(feats_s.reshape(nmod * b * t, d), plan.map_a, plan.live_a, 1, plan.ma, "none")   # layout A
         mods = []
         xa_mod = torch.split(xa, plan.ma, dim=0)       # (split's backward is one cat; slices would zero-fill and add)
+        flat = []
         for i, tag in enumerate(m_[2] for m_ in self.modalities):
             args = _block_args(getattr(fb, "norm" + tag), getattr(fb, "attn" + tag), getattr(fb, "norm" + tag + "_"),
                                getattr(fb, "mlp" + tag))
-            mods.append(fn.TransformerBlockFn.apply(xa_mod[i], *args, plan.mask_a, None,
-                                                    self.hma_heads, 1e-5, self.fn_dtype_hma, None, None, plan.cu, t,
-                                                    plan.live_a, None, self._sink("hma." + tag)))
+            flat.append((xa_mod[i], *args, plan.mask_a, None, self.hma_heads, 1e-5, self.fn_dtype_hma, None, None, plan.cu, t,
+                         plan.live_a, None, self._sink("hma." + tag)))
+        if fn.GROUP_BLOCKS and self.fn_dtype_hma in ops.HALF_DTYPES and not self.act_light:
+            # the per-modality blocks are identical in shape and independent: one node, their products as grouped launches
+            # (round 4: ~7 400 live rows per modality are 87 tiles of a 768-wide product - a third of a round of the 256 CUs)
+            mods = list(fn.GroupedBlocksFn.apply(len(flat), *[v for blk in flat for v in blk]))
+        else:
+            mods = [fn.TransformerBlockFn.apply(*blk) for blk in flat]
         xa = torch.cat(mods, dim=0)
         loss_ocfr = None
         if self.training:

@@ -130,18 +130,22 @@ class ReduceQueue:
     the totals before the block ends.  Round 4: 95 -> ~31 reduce launches per step, same bits (same summation order)."""
     ARENA_FLOATS = 16 << 20           # 64 MiB; one block's six sets are ~31 MB at D = 768, ~42 MB at D = 1024
 
-    def __init__(self, device):
+    def __init__(self, device, slot=0, nslots=1):
+        # slot / nslots: blocks whose backwards run in LOCKSTEP (functional.GroupedBlocksFn) each take their own part of the arena -
+        # their partial rows are live at the same time
         key = (device.index, _raw_stream(device.index if device.index is not None else torch.cuda.current_device()))
         buf = _ARENA.get(key)
         if buf is None:               # never freed: a captured hipGraph replays launches that hold its address
             buf = _ARENA[key] = torch.empty(self.ARENA_FLOATS, dtype=torch.float32, device=device)
-        self.buf, self.off, self.jobs = buf, 0, []
+        span = (self.ARENA_FLOATS // int(nslots)) // 64 * 64
+        self.base, self.limit = int(slot) * span, (int(slot) + 1) * span
+        self.buf, self.off, self.jobs = buf, self.base, []
 
     def region(self, nfloats):
         n = (int(nfloats) + 63) // 64 * 64
-        if n > self.buf.numel():
+        if n > self.limit - self.base:
             return None               # (does not fit at all: the caller reduces on the spot)
-        if self.off + n > self.buf.numel() or len(self.jobs) >= 7:
+        if self.off + n > self.limit or len(self.jobs) >= 7:
             self.flush()
         r = self.buf[self.off:self.off + n]
         self.off += n
@@ -164,7 +168,7 @@ class ReduceQueue:
                 call("editor_reduce_rows_multi", n, parts, cnt, ncol, outs, scale)
         self.jobs = []
         if reset:
-            self.off = 0
+            self.off = self.base
 
 
 _DT_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
@@ -631,6 +635,53 @@ def wgrad_group_split(tiles, ktiles, cus=256):
         if eff > best_eff + 0.02:
             best, best_eff = s_, eff
     return best
+
+
+GROUP_FWD = os.environ.get("EDITOR_GROUP_FWD", "1") != "0"     # A/B switch: the HMA modality blocks' products as grouped launches
+
+
+def gemm_group_ok(reqs):
+    """Can these ops.gemm requests (args tuples + keyword dicts of IDENTICAL shape) leave as ONE editor_gemm_group launch?  Products of
+    the 256 x 256 ping-pong kernel only: 16-bit k-major operands, full 256-wide column tiles, no split-K / colsum / offsets, and the
+    tile plan of ops.gemm must be the full-tile ping-pong kernel for them (the compacted HMA head's live-row products)."""
+    if not GROUP_FWD or len(reqs) < 2 or len(reqs) > 4:
+        return False
+    a0, kw0 = reqs[0]
+    (a, b, c, m, n, k, lda, ldb, ldc), ta, tb = a0[:9], a0[9] if len(a0) > 9 else 0, a0[10] if len(a0) > 10 else 0
+    if a.dtype not in HALF_DTYPES or ta or tb or m < 2048 or n < 256 or n % 256 or k % 64 or kw0.get("m_live") is None:
+        return False
+    if lda != k or ldb != k or ldc != n:
+        return False
+    keys = ("alpha", "beta", "splitk", "a_off", "b_off", "c_off", "epilogue", "colsum")      # (rq only matters with colsum)
+    for args, kw in reqs:
+        if tuple(args[3:]) != tuple(a0[3:]) or args[0].dtype != a.dtype or args[1].dtype != a.dtype or args[2].dtype != c.dtype:
+            return False
+        if any(kw.get(q) != kw0.get(q) for q in keys) or kw.get("m_live") is not kw0.get("m_live"):
+            return False
+        if kw.get("beta", 0.0) != 0.0 or kw.get("splitk", 1) != 1 or kw.get("colsum") is not None:
+            return False
+        if kw.get("a_off", 0) or kw.get("b_off", 0) or kw.get("c_off", 0) or (int(kw.get("epilogue", 0)) & (0xF000 | EPI_PIPE128 | EPI_COLSUM)):
+            return False
+        if (kw.get("bias") is None) != (kw0.get("bias") is None) or (kw.get("rowscale") is None) != (kw0.get("rowscale") is None) \
+                or (kw.get("aux") is None) != (kw0.get("aux") is None):
+            return False
+        if not (args[0].is_contiguous() and args[1].is_contiguous() and args[2].is_contiguous()):
+            return False
+    return True
+
+
+def gemm_group(reqs):
+    """The requests of gemm_group_ok as one launch (editor_gemm_group): bit-identical to the separate ops.gemm calls."""
+    import ctypes
+    cnt = len(reqs)
+    a0, kw0 = reqs[0]
+    a, b, c, m, n, k = a0[:6]
+    arr = lambda ts: None if ts[0] is None else (ctypes.c_void_p * cnt)(*[t.data_ptr() for t in ts])
+    with torch.cuda.device(a.device):
+        call("editor_gemm_group", _DT_CODE[a.dtype], cnt, arr([r[0][0] for r in reqs]), arr([r[0][1] for r in reqs]),
+             arr([r[0][2] for r in reqs]), 1 if c.dtype == torch.float32 else 0, m, n, k, k, k, n, float(kw0.get("alpha", 1.0)),
+             arr([r[1].get("bias") for r in reqs]), arr([r[1].get("rowscale") for r in reqs]),
+             int(kw0.get("epilogue", 0)) & ~EPI_FORCE_PP, arr([r[1].get("aux") for r in reqs]), n, kw0.get("m_live"))
 
 
 def gemm_wgrad_group(jobs, m, alpha=1.0, m_live=None):

@@ -243,6 +243,17 @@ int editor_gemm_wgrad_group(int dtype, int count, const uint16_t* const* dy, con
                             const int* N, const int* K, int M, float alpha, int splitk, float* ws, const int* m_live,
                             editor_stream_t stream);
 
+/* GROUPED forward / dgrad products (round 4): `count` <= 4 products C_i = alpha A_i B_i^T (+ bias_i) (* rowscale_i) (+ epilogue) of
+ * IDENTICAL shape and epilogue kind, both operands k-major (A_i (M,K), B_i (N,K)), as ONE launch of the 256x256 ping-pong kernel -
+ * the three per-modality blocks of BlockMask (vit_pytorch.py:311-317), whose kept tokens fill a third of the chip each.  A, B, C,
+ * bias, rowscale, aux: HOST arrays of `count` device pointers (bias / rowscale / aux may be NULL, or hold NULL entries); dtype:
+ * 1 = bf16, 2 = f16; epilogue: EDITOR_EPI_NONE / _RESIDUAL / _GELU / _GELU_BWD (| EDITOR_EPI_AUX_GRAD); M >= 256, N % 256 == 0,
+ * K % 64 == 0; m_live as editor_gemm_bf16 (shared by the problems).  Bit-identical to `count` calls of editor_gemm_bf16 / _f16. */
+int editor_gemm_group(int dtype, int count, const uint16_t* const* A, const uint16_t* const* B, void* const* C, int c_f32, int M,
+                      int N, int K, long lda, long ldb, long ldc, float alpha, const float* const* bias,
+                      const float* const* rowscale, int epilogue, void* const* aux, long ldaux, const int* m_live,
+                      editor_stream_t stream);
+
 /* the same contraction on IEEE-half operands (v_mfma_f32_16x16x32_f16): C half or fp32 */
 int editor_gemm_f16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda, long ldb,
                     long ldc, int transA, int transB, float alpha, float beta, const float* bias,

@@ -398,6 +398,48 @@ def test_eval_f16x2_rollout_recomputed_option_selects_identically():
         assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_grouped_hma_blocks_are_bit_identical(dtype):
+    """Round 4: the three per-modality blocks of the HMA head as ONE autograd node (functional.GroupedBlocksFn) whose products leave
+    as grouped launches (editor_gemm_group) == three TransformerBlockFn nodes, bit for bit: every output, the loss and every
+    parameter gradient of a training step (the same kernels on the same tiles; only the launch grouping differs)."""
+    from editor_amd import functional as fn, losses, ops
+    seed, batch = 3, 16
+    res = []
+    calls = {"n": 0}
+    real = ops.gemm_group
+
+    def counted(reqs):
+        calls["n"] += 1
+        return real(reqs)
+    for grouped in (False, True):
+        old = fn.GROUP_BLOCKS
+        fn.GROUP_BLOCKS = grouped
+        ops.gemm_group = counted
+        try:
+            m, cfg, c, cams = _model("RGBNT201", seed, dtype, drop_path=0.0)
+            m.train()
+            img, label, cam, view = _cuda_batch(*synth.make_batch(seed, batch, 256, 128, cams, instances=4))
+            n0 = calls["n"]
+            outs = m(img, label=label, cam_label=cam, view_label=view, writer=_Writer(), epoch=1)
+            loss = losses.loss_pairs(outs, label)
+            loss.backward()
+            torch.cuda.synchronize()
+            grads = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+            res.append(([o.detach().clone() for o in outs], loss.detach().clone(), grads, calls["n"] - n0))
+        finally:
+            fn.GROUP_BLOCKS = old
+            ops.gemm_group = real
+    (o0, l0, g0, n_plain), (o1, l1, g1, n_grp) = res
+    assert n_plain == 0 and n_grp == 8, (n_plain, n_grp)           # 4 forward products + 4 dgrads of the three blocks, grouped
+    assert torch.equal(l0, l1)
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+
+
 def test_hipgraph_replay_matches_eager_training():
     """The whole training step (forward, HIP loss head, backward with the side-stream weight gradients, fused SGD with
     drop-path) captured into a hipGraph and replayed == the same number of eager steps: identical kernels on identical
