@@ -62,6 +62,75 @@ __device__ __forceinline__ void store_tile(char* stg, const float4_t (&o)[ND], b
 }
 
 
+// ---------------------------------------------------------------------------------------------------------
+// Column sums of the backward's output tiles (the qkv bias gradient), taken from the accumulators on their way out:
+// editor_attention_bwd_colsum_*.  A 16-row tile sits as o[dt][r] = (row li, column dt*16 + 4*lg + r): the sum over its
+// rows is a sum over the 16 lanes of a DPP row.  Reduce-scatter butterfly - partners i <-> 15-i (row_mirror), i <-> 7-i
+// (row_half_mirror), i <-> 3-i and i <-> i^1 (quad_perm) - in which a lane keeps the half of the values its own lane bit
+// selects and hands the other half over: 15 DPP additions + 30 selects for 16 values, and lane li ends up with the total of
+// value li (dt = li / 4, r = li % 4).  Fixed order: deterministic.  (colsum_kernel read the 16-bit tensor back: 228 MB per
+// backbone layer.)  CS_SLOTS accumulators per lane: values 0-15 in slot 0; head widths 32 / 96: the 8 values of the odd half
+// in their own slot on lanes li < 8 (three butterfly steps and one plain exchange with lane li ^ 8).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int CS_SLOTS = (ND * 4 + 15) / 16;
+// (96-wide heads beyond 160 tokens: the dK / dV pass is at its register budget - the column sums are not built there)
+template <int NT> constexpr bool kCols = HD <= 64 || NT <= 10;
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_REV = 0x1B, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_ROR8 = 0x128;
+// 8 values -> lane (li & 7) of each half row holds the total of value (li & 7) over the 8 lanes of its half
+__device__ __forceinline__ float scatter8(const float (&u)[8], bool b2, bool b1, bool b0)
+{
+    float w[4], x[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = (b2 ? u[4 + j] : u[j]) + dpp_f<DPP_ROW_HALF_MIRROR>(b2 ? u[j] : u[4 + j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) x[j] = (b1 ? w[2 + j] : w[j]) + dpp_f<DPP_QUAD_REV>(b1 ? w[j] : w[2 + j]);
+    return (b0 ? x[1] : x[0]) + dpp_f<DPP_QUAD_XOR1>(b0 ? x[0] : x[1]);
+}
+// adds the column sums of the tile's first `nrows` rows to the lane's accumulators
+__device__ __forceinline__ void tile_colsum(const float4_t (&o)[ND], int nrows, int lane, float (&mine)[CS_SLOTS])
+{
+    const int li = lane & 15;
+    const bool hi = li & 8, b2 = li & 4, b1 = li & 2, b0 = li & 1;
+    const bool live = li < nrows;
+#pragma unroll
+    for (int c = 0; c < CS_SLOTS; ++c) {
+        if (c * 4 + 4 <= ND) {                      // sixteen values: o[4c .. 4c+3]
+            float u[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float lo = live ? o[c * 4 + (j >> 2)][j & 3] : 0.f, up = live ? o[c * 4 + 2 + (j >> 2)][j & 3] : 0.f;
+                u[j] = (hi ? up : lo) + dpp_f<DPP_ROW_MIRROR>(hi ? lo : up);
+            }
+            mine[c] += scatter8(u, b2, b1, b0);
+        } else {                                    // eight values: o[4c], o[4c+1]
+            float u[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = live ? o[c * 4 + (j >> 2)][j & 3] : 0.f;
+            const float t = scatter8(u, b2, b1, b0);
+            mine[c] += t + dpp_f<DPP_ROW_ROR8>(t);                       // (lane i ^ 8 holds the same value index for the other half row)
+        }
+    }
+}
+// the workgroup's waves fold their accumulators through LDS (`red`: nw x HD floats, free once everyone has left the tile loop -
+// the caller's barrier) in wave order; threads c < HD then write column c of `dst`
+__device__ __forceinline__ void wave_colsum_park(const float (&mine)[CS_SLOTS], float* red, int lane)
+{
+    const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < CS_SLOTS; ++c) {
+        const bool full = c * 4 + 4 <= ND;
+        if (full || li < 8) {
+            const int idx = c * 16 + (full ? li : (li & 7));
+            red[(idx >> 2) * 16 + 4 * lg + (idx & 3)] = mine[c];
+        }
+    }
+}
+
 struct AttnArgs {
     const bf16_t* qkv; const bf16_t* dout; const bf16_t* out_fwd;
     bf16_t* out; bf16_t* dqkv; float* probs; float* lse; float* delta;
@@ -71,6 +140,7 @@ struct AttnArgs {
     const int* cu;                        // varlen: sequence b owns packed rows [cu[b], cu[b+1]); NULL = dense (b*T)
     long Mtot;                            // total packed rows (lse / delta are laid out [heads][Mtot])
     int stage_out;                        // outputs leave through per-wave LDS staging (store_tile); 0: direct 8-byte stores
+    float* colparts;                      // backward: [B][3 * heads * HD] column sums of dqkv per sequence (or NULL), see tile_colsum
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -144,6 +214,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
     const long row_idx0 = (long)hh * a.Mtot + row0;                // lse / delta index of row 0
     const long prow0 = ((long)b * a.heads + hh) * a.T;             // probability rows (dense mode only)
     char* stg = a.stage_out ? smem + 2 * Tp * ROWB + w * STG_BYTES : nullptr;     // this wave's output staging (store_tile)
+    float csum[CS_SLOTS];                                          // BWD: column sums of this wave's dQ tiles (a.colparts)
+#pragma unroll
+    for (int c = 0; c < CS_SLOTS; ++c) csum[c] = 0.f;
 
     for (int q0 = w * 16; q0 < T; q0 += nw * 16) {
         const int q = q0 + li;
@@ -355,8 +428,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
 #pragma unroll
             for (int dt = 0; dt < ND; ++dt) o[dt] *= a.scale;
             store_tile<F16>(stg, o, a.dqkv + (row0 + q0) * ld + hh * HD, ld, T - q0, lane);
+            if (kCols<NT> && a.colparts) tile_colsum(o, 16, lane, csum);   // (query rows beyond the sequence end: P == 0, exact zeros)
         } else {
             store_tile<F16>(stg, o, a.out + (row0 + q0) * D + hh * HD, D, T - q0, lane);
+        }
+    }
+    if constexpr (BWD && kCols<NT>) {
+        if (a.colparts) {                                          // (workgroup-uniform)
+            __syncthreads();                                       // everyone has left the tile loop: the K image is free
+            float* red = reinterpret_cast<float*>(smem);
+            wave_colsum_park(csum, red + w * HD, lane);
+            __syncthreads();
+            if (threadIdx.x < HD) {
+                float t = 0.f;
+                for (int i = 0; i < nw; ++i) t += red[i * HD + threadIdx.x];
+                a.colparts[(long)b * 3 * D + hh * HD + threadIdx.x] = t;
+            }
         }
     }
 }
@@ -396,6 +483,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const float sc = a.scale * kLog2e;
+    float csk[CS_SLOTS], csv[CS_SLOTS];                            // column sums of this wave's dK / dV tiles (a.colparts)
+#pragma unroll
+    for (int c = 0; c < CS_SLOTS; ++c) csk[c] = csv[c] = 0.f;
 
     for (int k0 = w * 16; k0 < T; k0 += nw * 16) {
         const int key = k0 + li;
@@ -486,6 +576,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
             for (int dt = 0; dt < ND; ++dt) dk[dt] *= a.scale;
             store_tile<F16>(stg, dk, kdst, ld, T - k0, lane);
             store_tile<F16>(stg, dv, kdst + D, ld, T - k0, lane);
+            if (kCols<NT> && a.colparts) {
+                // FULL: the tile rows of keys beyond the sequence end hold finite garbage that is never stored - dropped here (last
+                // tile only); otherwise they are exact zeros (P == 0)
+                if (FULL && T - k0 < 16) { tile_colsum(dk, T - k0, lane, csk); tile_colsum(dv, T - k0, lane, csv); }
+                else { tile_colsum(dk, 16, lane, csk); tile_colsum(dv, 16, lane, csv); }
+            }
+        }
+    }
+    if (kCols<NT> && a.colparts) {
+        __syncthreads();                                           // the Q image is free
+        float* red = reinterpret_cast<float*>(smem);
+        wave_colsum_park(csk, red + (w * 2) * HD, lane);
+        wave_colsum_park(csv, red + (w * 2 + 1) * HD, lane);
+        __syncthreads();
+        if (threadIdx.x < 2 * HD) {
+            const int which = threadIdx.x / HD, c = threadIdx.x % HD;
+            float t = 0.f;
+            for (int i = 0; i < nw; ++i) t += red[(i * 2 + which) * HD + c];
+            a.colparts[(long)b * 3 * D + (1 + which) * D + hh * HD + c] = t;
         }
     }
 }
@@ -1113,6 +1222,7 @@ template <int NT, bool F16>
 int launch_all(const AttnArgs& a_in, int B, int mode, hipStream_t stream)
 {
     AttnArgs a = a_in;
+    if (a.colparts && HD > 64 && NT > 10) return (int)hipErrorInvalidValue;      // (not built there: see kCols)
     const int threads = pick_threads(a.T);
     // Per-wave output staging (store_tile) for the backward passes, when the LDS has room for it next to the images.
     // Measured (tools/attn_prof.sh, T = 129): dK/dV 136 -> 126 us, dQ 111 -> 109 us; the forward gets SLOWER with it
@@ -1147,7 +1257,7 @@ int launch_all(const AttnArgs& a_in, int B, int mode, hipStream_t stream)
         if constexpr (NT <= 10) {
             // dense backbone sequences, opt-in (EDITOR_ATTN_FUSED_BWD=1): S / P / dP / dS once, dQ and dK / dV from the same
             // workgroup; bit-identical to the two-pass form and, as measured, slower
-            if (full && g_fused_bwd) {
+            if (full && g_fused_bwd && !a.colparts) {
                 auto kf = attn_bwd_fused_kernel<NT, F16>;
                 if ((rc = set_lds(kf, fused_bwd_lds<NT>()))) return rc;
                 hipLaunchKernelGGL(kf, grid, dim3(NT / 2 * 64), fused_bwd_lds<NT>(), stream, a);
@@ -1190,7 +1300,7 @@ int launch_all(const AttnArgs& a_in, int B, int mode, hipStream_t stream)
 template <bool F16>
 int launch_long(const AttnArgs& a, int B, int mode, hipStream_t stream)
 {
-    if (a.probs) return (int)hipErrorInvalidValue;                 // (no probability output: the backbone's sequences are short)
+    if (a.probs || a.colparts) return (int)hipErrorInvalidValue;   // (no probability output / column sums: the backbone's sequences are short)
     const dim3 grid(B * a.heads, (a.T + 63) / 64);
     const size_t img = (size_t)2 * LCH * ROWB;
     int rc;
@@ -1240,11 +1350,12 @@ int attention_fwd_h16(const uint16_t* qkv, int B, int T, int heads, int hd, floa
 template <bool F16>
 int attention_bwd_h16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, int B, int T, int heads,
                       int hd, float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace, const int* cu, long Mtot,
-                      hipStream_t stream)
+                      float* colparts, hipStream_t stream)
 {
     if (hd != HD || T < 1 || B < 1 || !workspace || !lse || (cu && mask)) return (int)hipErrorInvalidValue;
     if (!cu) Mtot = (long)B * T;
-    AttnArgs a{qkv, dout, out, nullptr, dqkv, nullptr, const_cast<float*>(lse), workspace, mask, T, heads, scale, 0, cu, Mtot, 0};
+    AttnArgs a{qkv, dout, out, nullptr, dqkv, nullptr, const_cast<float*>(lse), workspace, mask, T, heads, scale, 0, cu, Mtot, 0,
+               colparts};
     return dispatch<F16>(a, B, 1, stream);
 }
 
@@ -1357,14 +1468,36 @@ ATTN_DECL_WIDTHS(editor_attention_bwd_f16, BWD_ARGS)
 extern "C" int ATTN_ENTRY(editor_attention_bwd_bf16)(BWD_ARGS)
 {
     ATTN_OTHER_WIDTHS(editor_attention_bwd_bf16, qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, stream);
-    return attention_bwd_h16<false>(qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, stream);
+    return attention_bwd_h16<false>(qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, nullptr, stream);
 }
 extern "C" int ATTN_ENTRY(editor_attention_bwd_f16)(BWD_ARGS)
 {
     ATTN_OTHER_WIDTHS(editor_attention_bwd_f16, qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, stream);
-    return attention_bwd_h16<true>(qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, stream);
+    return attention_bwd_h16<true>(qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, nullptr, stream);
 }
 #undef BWD_ARGS
+
+// the same backward that ALSO leaves the column sums of dqkv (the qkv bias gradient) as one partial row per sequence:
+// colparts[B][3 * heads * hd] floats, to be folded by editor_reduce_rows(_multi) - instead of a colsum pass over the 16-bit dqkv.
+// Sequences of <= 608 tokens (the two-pass kernels); longer ones: hipErrorInvalidValue (the caller sums dqkv itself).
+#define BWDC_ARGS const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, int B, int T, int heads, int hd, \
+                  float scale, const uint8_t* mask, uint16_t* dqkv, float* workspace, const int* cu, long Mtot, float* colparts, \
+                  hipStream_t stream
+ATTN_DECL_WIDTHS(editor_attention_bwd_colsum_bf16, BWDC_ARGS)
+ATTN_DECL_WIDTHS(editor_attention_bwd_colsum_f16, BWDC_ARGS)
+extern "C" int ATTN_ENTRY(editor_attention_bwd_colsum_bf16)(BWDC_ARGS)
+{
+    ATTN_OTHER_WIDTHS(editor_attention_bwd_colsum_bf16, qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, colparts, stream);
+    if (!colparts) return (int)hipErrorInvalidValue;
+    return attention_bwd_h16<false>(qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, colparts, stream);
+}
+extern "C" int ATTN_ENTRY(editor_attention_bwd_colsum_f16)(BWDC_ARGS)
+{
+    ATTN_OTHER_WIDTHS(editor_attention_bwd_colsum_f16, qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, colparts, stream);
+    if (!colparts) return (int)hipErrorInvalidValue;
+    return attention_bwd_h16<true>(qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, colparts, stream);
+}
+#undef BWDC_ARGS
 
 #if ATTN_HD == 64
 extern "C" int editor_attention_bwd_mode(int fused)

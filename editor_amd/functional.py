@@ -295,6 +295,51 @@ class _SubCtx:
 # that are still cached instead of the ones the producer wrote first.  Same bits (tools/repro_check.py).
 REVERSE_ROWS = ops.EPI_REVERSE_ROWS if os.environ.get("EDITOR_REVERSE_ROWS", "0") == "1" else 0
 
+# LayerNorm-1's backward of block i+1 also writes what block i's backward STARTS with: the 16-bit, drop-path- and loss-scaled copy of
+# dL/dx (operand of the fc2 dgrad / wgrad) and its column sums (the fc2 bias gradient) - ops.layernorm_bwd_cast, as LayerNorm-2's
+# backward already does for the projection - instead of a cast_rows_colsum pass over the fp32 gradient one launch later
+# (-152 MB read per backbone layer).  The two autograd nodes meet through a `_CastBox`: block i leaves one in `_CAST_SLOT` when its
+# forward returns (holding a weak reference to its output), block i+1's forward picks it up if its input IS that tensor object; in the backward the
+# producer fills it and the consumer checks that the gradient it is handed is the very tensor the producer returned, unmodified
+# (storage, size, version counter) - anything else (a second consumer of the block output, hooks) falls back to the plain pass.
+HANDOFF_CAST = os.environ.get("EDITOR_HANDOFF_CAST", "1") != "0"
+_CAST_SLOT = [None]
+
+
+class _CastBox:
+    __slots__ = ("out", "m", "dtype", "rowscale", "has_bias", "gs", "cs_out", "handoff")
+
+    def __init__(self, out, m, dtype, rowscale, has_bias, gs, cs_out):
+        self.out, self.m, self.dtype = weakref.ref(out), m, dtype      # (the tensor OBJECT the node returns: an address can be re-used)
+        self.rowscale, self.has_bias, self.gs, self.cs_out = rowscale, has_bias, gs, cs_out
+        self.handoff = None
+
+    def put(self, dx, dy16, dbias):
+        self.handoff = (dx, dy16, dbias, dx._version)
+
+    def take(self, dx2):
+        """(dy16, dbias) if `dx2` is the gradient the producer returned, untouched; else None."""
+        h, self.handoff = self.handoff, None
+        if h is None or dx2.data_ptr() != h[0].data_ptr() or dx2.numel() != h[0].numel() or dx2.dtype != h[0].dtype:
+            return None
+        if h[0]._version != h[3] or dx2._version != h[3]:
+            return None
+        return h[1], h[2]
+
+
+def _cast_boxes(ctx, x, out, m, d, act_dtype, mask, cu, m_live, rowscale_mlp, has_fc2_bias, sink, plain):
+    """forward side of HANDOFF_CAST: ctx.feeds_box = the box of the block whose output `x` is; ctx.box = this block's own."""
+    prev, _CAST_SLOT[0] = _CAST_SLOT[0], None
+    ctx.feeds_box = ctx.box = None
+    if not (HANDOFF_CAST and FUSE_LN_CAST and plain and act_dtype in ops.HALF_DTYPES and cu is None and mask is None
+            and m_live is None and d % 256 == 0 and d <= 1024):
+        return
+    if prev is not None and prev.out() is x and prev.m == m and prev.dtype == act_dtype:
+        ctx.feeds_box = prev
+    ctx.box = _CAST_SLOT[0] = _CastBox(out, m, act_dtype, rowscale_mlp, has_fc2_bias, grad_scale(act_dtype),
+                                       sink.views[11] if sink is not None else None)
+
+
 
 def _linear_bwd(*args, **kw):
     """_linear_bwd_gen run alone (the small fp32 linears, PatchEmbedFn): every launch issued in place"""
@@ -471,7 +516,9 @@ class TransformerBlockFn(torch.autograd.Function):
             ctx.gs = grad_scale(act_dtype)
             ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None,
                         tuple(x.shape), qk_scale, sink)
-            return x2.view(x.shape)
+            out = x2.view(x.shape)
+            _cast_boxes(ctx, x, out, m, d, act_dtype, mask, cu, m_live, rowscale_mlp, fc2b is not None, sink, True)
+            return out
         wp, w1, w2 = (act_weight(w, act_dtype) for w in (projw, fc1w, fc2w))
         if not head_done:
             wq = act_weight(qkvw, act_dtype)
@@ -525,8 +572,13 @@ class TransformerBlockFn(torch.autograd.Function):
                     tuple(x.shape), qk_scale, sink)
         if defer_out:
             ctx.mark_non_differentiable(br2)
+            _CAST_SLOT[0] = None
+            ctx.feeds_box = ctx.box = None
             return x1.view(x.shape), br2
-        return x2.view(x.shape)
+        out = x2.view(x.shape)
+        _cast_boxes(ctx, x, out, m, d, act_dtype, mask, cu, m_live, rowscale_mlp, fc2b is not None, sink,
+                    pend_branch is None and not branch16)
+        return out
 
     @staticmethod
     def backward_gen(ctx, dx2):
@@ -556,7 +608,12 @@ class TransformerBlockFn(torch.autograd.Function):
         # ONE launch at the end (ops.ReduceQueue); only with the grouped weight gradients, where every producer runs on this stream
         rq = ops.ReduceQueue(dx2.device, _GROUP_SLOT[0], _GROUP_SLOT[1]) if (DEFER_REDUCE and jobs is not None) else None
         # ---- MLP branch:  x2 = x1 + rs * fc2(gelu(fc1(LN2(x1))))
-        dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2, gs, cs_out=sv[11], rq=rq)
+        box = getattr(ctx, "box", None)
+        handed = box.take(dx2) if box is not None else None
+        if handed is not None:
+            dy, dbias = handed                       # left by the next block's LayerNorm-1 backward (HANDOFF_CAST)
+        else:
+            dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2, gs, cs_out=sv[11], rq=rq)
         da, dw2, db2, da_cs = yield from _linear_bwd_gen(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live, db=dbias,
                                           dx_colsum=hb_fc1, gs=gs, dw_out=sv[10], db_out=sv[11],
                                           dxcs_out=sv[9], w_t=w2t, defer=jobs, aux_is_grad=light is None, rq=rq)   # da = (dy W2) * gelu'(a)
@@ -579,17 +636,31 @@ class TransformerBlockFn(torch.autograd.Function):
             dy, dbias = _scaled_cast_colsum(dx1, rs_attn, act_dtype, m_live, hb_proj, gs, cs_out=sv[5], rq=rq)
         dao, dwp, dbp = yield from _linear_bwd_gen(dy, ao, wp, hb_proj, m_live=m_live, db=dbias, gs=gs, dw_out=sv[4], db_out=sv[5], w_t=wpt,
                                     defer=jobs, rq=rq)
-        dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, amask, attn_saved, ao, cu=cu, scale=qk_scale)
+        dbq = None
+        if hb_qkv and ops.attention_bwd_colsum_ok(qkv, t, hd, attn_saved):
+            # the qkv bias gradient = colsum(dqkv) from the attention backward's own accumulators (one partial row per sequence),
+            # not from a pass over the 16-bit dqkv it has just written
+            dbq = sv[3] if sv[3] is not None else torch.empty(qkv.shape[1], dtype=torch.float32, device=qkv.device)
+        dqkv = ops.attention_bwd(qkv, dao, b, t, heads, hd, amask, attn_saved, ao, cu=cu, scale=qk_scale, colsum=dbq,
+                                 colsum_scale=1.0 / gs, rq=rq)
         if light is not None:
             h1 = ops.layernorm_fwd(x2d, n1w, light[0], light[2], act_dtype, mask, 0, want_stats=False, m_live=m_live)[0]
-        dh1, dwq, dbq = yield from _linear_bwd_gen(dqkv, h1, wq, hb_qkv, m_live=m_live, gs=gs, dw_out=sv[2], db_out=sv[3], w_t=wqt,
+        dh1, dwq, dbq = yield from _linear_bwd_gen(dqkv, h1, wq, hb_qkv, m_live=m_live, db=dbq, gs=gs, dw_out=sv[2], db_out=sv[3], w_t=wqt,
                                     defer=jobs, rq=rq, rev=REVERSE_ROWS if m_live is None else 0)
         if jobs:
             # every dy exists: the block's four weight gradients in one launch.  Side stream (joined one block later)
             # unless a gradient sink needs them at the end of THIS block
             yield _WgradReq(jobs, m, 1.0 / gs, m_live, deferred, dx2.device)
-        dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1, m_live=m_live,
-                                           dy_scale=1.0 / gs, dgb_out=sink.ln_pair(0) if sink is not None else None, rq=rq)
+        fb = getattr(ctx, "feeds_box", None)
+        if fb is not None and fuse_cast:
+            # ... and hands the block BELOW the start of its backward (see HANDOFF_CAST): its drop-path row scale, its bias-gradient slot
+            dx, dn1w, dn1b, dy_below, db_below = ops.layernorm_bwd_cast(
+                dh1, x2d, n1w, mean1, rstd1, dx1, fb.rowscale, fb.gs, dy_scale=1.0 / gs,
+                dgb_out=sink.ln_pair(0) if sink is not None else None, want_colsum=fb.has_bias, cs_out=fb.cs_out, rq=rq)
+            fb.put(dx, dy_below, db_below)
+        else:
+            dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1, m_live=m_live,
+                                               dy_scale=1.0 / gs, dgb_out=sink.ln_pair(0) if sink is not None else None, rq=rq)
         if rq is not None:
             rq.flush()                               # the block's partial rows -> dgamma / dbeta / bias gradients, one launch
         if not deferred:

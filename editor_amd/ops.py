@@ -750,9 +750,24 @@ def attention_bwd_mode(fused=-1):
     return int(_lib.lib().cdll.editor_attention_bwd_mode(int(fused)))
 
 
-def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None, cu=None, scale=None):
+ATTN_BWD_COLSUM = os.environ.get("EDITOR_ATTN_COLSUM", "1") == "1"
+
+
+def attention_bwd_colsum_ok(qkv, t, hd, saved=None):
+    """True if attention_bwd can deliver colsum(dqkv) - the qkv bias gradient - from its own accumulators (the fused 16-bit two-pass
+    kernels: sequences of <= 608 tokens, 96-wide heads <= 160), include/editor_hip.h: editor_attention_bwd_colsum_*."""
+    return (ATTN_BWD_COLSUM and qkv.dtype in HALF_DTYPES and hd in ATTN_HEAD_WIDTHS and not (saved is not None and saved.dim() == 4)
+            and t <= (608 if hd <= 64 else 160))
+
+
+def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None, cu=None, scale=None, colsum=None, colsum_scale=1.0,
+                  rq=None):
+    """-> dqkv.  colsum (fp32 vector of 3*heads*hd, only when attention_bwd_colsum_ok): also filled with colsum(dqkv) * colsum_scale -
+    one partial row per sequence from the kernels, folded here or, with a ReduceQueue, at the end of the block."""
     scale = float(scale or hd ** -0.5)
     rows = qkv.shape[0]
+    if colsum is not None and not attention_bwd_colsum_ok(qkv, t, hd, saved):
+        raise ValueError("attention_bwd: column sums are not available for this call (attention_bwd_colsum_ok)")
     if qkv.dtype == torch.float32:
         dqkv = torch.empty_like(qkv)
         ws = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
@@ -768,7 +783,19 @@ def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None, c
                 attention_bwd_mode(1)
         dqkv = _packed_alloc(rows, qkv.shape[1], qkv.dtype, qkv.device, cu)
         ws = torch.empty(heads * rows, dtype=torch.float32, device=qkv.device)
-        call(_h16(qkv, "attention_bwd"), qkv, dout, out, saved, b, t, heads, hd, scale, mask, dqkv, ws, cu, rows)
+        if colsum is None:
+            call(_h16(qkv, "attention_bwd"), qkv, dout, out, saved, b, t, heads, hd, scale, mask, dqkv, ws, cu, rows)
+        else:
+            ncol = qkv.shape[1]
+            parts = rq.region(b * ncol) if rq is not None else None
+            queued = parts is not None
+            if not queued:
+                parts = torch.empty(b * ncol, dtype=torch.float32, device=qkv.device)
+            call(_h16(qkv, "attention_bwd_colsum"), qkv, dout, out, saved, b, t, heads, hd, scale, mask, dqkv, ws, cu, rows, parts)
+            if queued:
+                rq.add(parts, b, ncol, colsum, float(colsum_scale))
+            else:
+                call("editor_reduce_rows", parts, b, ncol, colsum, 0, float(colsum_scale))
     return dqkv
 
 

@@ -304,6 +304,16 @@ int editor_attention_fwd_bf16(const uint16_t* qkv, int B, int T, int heads, int 
 int editor_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, int B,
                               int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv,
                               float* workspace, const int* cu, long Mtot, editor_stream_t stream);
+/* The same backward, which ALSO leaves the column sums of dqkv - the qkv bias gradient (Attention.qkv, vit_pytorch.py:177,186) -
+ * as one partial row per sequence: colparts[B][3*heads*hd] fp32 (every entry written), taken from the dQ / dK / dV accumulators on
+ * their way out (fp32, before the 16-bit rounding) and to be folded by editor_reduce_rows(_multi); replaces an editor_colsum pass
+ * over dqkv.  T <= 608 (hd = 96: T <= 160); otherwise hipErrorInvalidValue and the caller sums dqkv itself.  Deterministic. */
+int editor_attention_bwd_colsum_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, int B,
+                                     int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv,
+                                     float* workspace, const int* cu, long Mtot, float* colparts, editor_stream_t stream);
+int editor_attention_bwd_colsum_f16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, int B,
+                                    int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv,
+                                    float* workspace, const int* cu, long Mtot, float* colparts, editor_stream_t stream);
 /* Split-precision attention forward (COMPUTE_DTYPE 'f16x2'): q, k, v as half pairs qkv = qkv_hi + qkv_lo (both (rows,
  * 3*heads*64), the split output of the qkv product); every contraction is three half MFMAs into one fp32 accumulator
  * (S = Q_lo K_hi + Q_hi K_lo + Q_hi K_hi; O likewise on the 2^12-scaled probability pair), the softmax is the reference's

@@ -558,6 +558,75 @@ def test_attention_varlen_other_head_widths(ops, hd, heads):
     assert float(dqkv[total:].abs().max()) == 0.0
 
 
+def _colsum_case(ops, dtype, hd, heads, b, t, form, seed):
+    """attention_bwd(colsum=...) against the plain entry: same dqkv bits, and the column sums equal the sums of the fp32 values the
+    stored 16-bit dqkv was rounded from - i.e. they differ from colsum(stored dqkv) by at most the rounding of each entry."""
+    d = heads * hd
+    g = _g(seed)
+    mask = cu = None
+    if form == "varlen":
+        lens = [t] + [max(1, int(x)) for x in torch.randint(1, t + 1, (b - 1,), generator=g)]
+        cu_h = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+        total = int(cu_h[-1])
+        rows = (total + 63) // 64 * 64
+        cu = cu_h.cuda()
+    else:
+        rows = total = b * t
+        if form == "masked":
+            mask = (torch.rand(b, t, generator=g) > 0.3)
+            mask[:, 0] = True
+            mask = mask.to(torch.uint8).cuda()
+    qkv = (torch.randn(rows, 3 * d, generator=g) * 0.9).to(dtype)
+    do = torch.randn(rows, d, generator=g).to(dtype)
+    qkv[total:] = 0
+    do[total:] = 0
+    qkv, do = qkv.cuda(), do.cuda()
+    o, lse = ops.attention_fwd(qkv, b, t, heads, hd, mask, None, cu=cu)
+    ref = ops.attention_bwd(qkv, do, b, t, heads, hd, mask, lse, o, cu=cu)
+    cs = torch.full((3 * d,), float("nan"), device="cuda")
+    got = ops.attention_bwd(qkv, do, b, t, heads, hd, mask, lse, o, cu=cu, colsum=cs, colsum_scale=0.5)
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    stored = ref.double()
+    want = stored.sum(0)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    # every entry within half an ulp of its fp32 value (+ fp32 summation noise)
+    bound = stored.abs().sum(0) * (0.5 * eps + 4e-6) + 1e-6
+    err = (cs.double() * 2.0 - want).abs()
+    assert torch.isfinite(cs).all()
+    assert bool((err <= bound).all()), (float((err / bound).max()), form, t, hd)
+    # and far inside that bound on average: the sums are of the unrounded values, not garbage that happens to fit
+    assert float(err.mean() / stored.abs().sum(0).mean()) < 0.1 * eps
+    # deterministic
+    cs2 = torch.empty_like(cs)
+    ops.attention_bwd(qkv, do, b, t, heads, hd, mask, lse, o, cu=cu, colsum=cs2, colsum_scale=0.5)
+    assert torch.equal(cs, cs2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("form,t", [("dense", 129), ("dense", 100), ("dense", 193), ("dense", 300), ("masked", 129), ("varlen", 129),
+                                    ("varlen", 387)])
+def test_attention_bwd_column_sums(ops, dtype, form, t):
+    """The qkv bias gradient from the attention backward's own accumulators (editor_attention_bwd_colsum_*), 64-wide heads: every
+    kernel form (unrolled dense, short dense, 14- and 26-tile, token-masked, packed sequences incl. the joint block's 387)."""
+    _colsum_case(ops, dtype, 64, 12, 6, t, form, seed=t)
+
+
+@pytest.mark.parametrize("hd,heads,t", [(32, 12, 129), (32, 12, 200), (96, 8, 129), (96, 8, 77)])
+@pytest.mark.parametrize("form", ["dense", "varlen"])
+def test_attention_bwd_column_sums_other_head_widths(ops, hd, heads, t, form):
+    _colsum_case(ops, torch.bfloat16, hd, heads, 5, t, form, seed=hd + t)
+
+
+def test_attention_bwd_column_sums_refused_where_not_built(ops):
+    """96-wide heads beyond 160 tokens and sequences beyond 608 tokens: no in-kernel column sums - ops says so up front."""
+    import editor_amd.ops as ops_mod
+    q96 = torch.zeros(4, 3 * 8 * 96, dtype=torch.bfloat16, device="cuda")
+    q64 = torch.zeros(4, 3 * 12 * 64, dtype=torch.bfloat16, device="cuda")
+    assert ops_mod.attention_bwd_colsum_ok(q96, 160, 96) and not ops_mod.attention_bwd_colsum_ok(q96, 193, 96)
+    assert ops_mod.attention_bwd_colsum_ok(q64, 608, 64) and not ops_mod.attention_bwd_colsum_ok(q64, 609, 64)
+    assert not ops_mod.attention_bwd_colsum_ok(q64.float(), 129, 64)
+
+
 @pytest.mark.parametrize("hd,heads", [(32, 12), (96, 8)])
 @pytest.mark.parametrize("t", [129, 193])
 def test_rollout_recomputed_other_head_widths(ops, hd, heads, t):

@@ -440,6 +440,78 @@ def test_grouped_hma_blocks_are_bit_identical(dtype):
         assert torch.equal(g0[k], g1[k]), k
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_layernorm1_backward_hands_the_block_below_its_start(dtype):
+    """Round 4 (functional.HANDOFF_CAST): LayerNorm-1's backward of block i+1 also writes the 16-bit, drop-path-scaled gradient copy
+    and the fc2 bias gradient that block i's backward starts from.  Three backbone blocks in a chain, with drop-path row scales:
+    outputs, input gradient and every parameter gradient equal the plain form (cast_rows_colsum in block i) bit for bit; the
+    fused pass really ran (2 of 3 blocks); and a gradient that is NOT the tensor the producer returned (a hook that clones it) makes
+    the consumer fall back - same bits again."""
+    from editor_amd import functional as fn, ops
+    from editor_amd.modeling.make_model import _block_args
+    m, cfg, c, cams = _model("RGBNT201", 11, dtype, drop_path=0.1)
+    base = m.BACKBONE.base
+    blocks = list(base.blocks)[:3]
+    act = m.fn_dtype
+    b, tk, d = 64, 129, 768          # (64 x 129 token rows: a multiple of 64 - grouped weight gradients, deferred reductions)
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(b, tk, d, generator=g).cuda()
+    w_out = (torch.randn(b, tk, d, generator=g) * 1e-3).cuda()       # (f16: the gradients travel loss-scaled - keep them in range)
+    rs = [((torch.rand(b * tk, generator=g) > 0.2).float() / 0.8).cuda() for _ in range(6)]
+    calls = {"ln_cast": 0, "cast_cs": 0}
+    real_ln, real_cs = ops.layernorm_bwd_cast, ops.cast_rows_colsum
+
+    def ln_cast(*a, **k):
+        calls["ln_cast"] += 1
+        return real_ln(*a, **k)
+
+    def cast_cs(*a, **k):
+        calls["cast_cs"] += 1
+        return real_cs(*a, **k)
+
+    def run(handoff, clone_hook):
+        old = fn.HANDOFF_CAST
+        fn.HANDOFF_CAST = handoff
+        ops.layernorm_bwd_cast, ops.cast_rows_colsum = ln_cast, cast_cs
+        calls["ln_cast"] = calls["cast_cs"] = 0
+        try:
+            for blk in blocks:
+                for p in blk.parameters():
+                    p.grad = None
+            x = x0.clone().requires_grad_(True)
+            h = x
+            for i, blk in enumerate(blocks):
+                h = fn.TransformerBlockFn.apply(h, *_block_args(blk.norm1, blk.attn, blk.norm2, blk.mlp), None, None, base.heads, 1e-6,
+                                                act, rs[2 * i], rs[2 * i + 1], None, None, None, base.qk_scale, None, None, None,
+                                                False, False)
+                if clone_hook and i == 0:
+                    h.register_hook(lambda gr: gr.clone())
+            (h * w_out).sum().backward()
+            torch.cuda.synchronize()
+            grads = [p.grad.clone() for blk in blocks for p in blk.parameters()]
+            return h.detach().clone(), x.grad.clone(), grads, dict(calls)
+        finally:
+            fn.HANDOFF_CAST = old
+            ops.layernorm_bwd_cast, ops.cast_rows_colsum = real_ln, real_cs
+
+    ref = run(False, False)
+    got = run(True, False)
+    hooked = run(True, True)
+    # plain: LayerNorm-2's fused pass in each block, the stand-alone pass at the start of each block
+    assert ref[3] == {"ln_cast": 3, "cast_cs": 3}, ref[3]
+    # handed over: blocks 2 and 1 (in forward numbering) also from their LayerNorm-1; only the top block casts for itself
+    assert got[3] == {"ln_cast": 5, "cast_cs": 1}, got[3]
+    # hook on block 0's output: block 1 still hands over (5 fused passes) but block 0 does not recognise the gradient and casts itself
+    assert hooked[3] == {"ln_cast": 5, "cast_cs": 2}, hooked[3]
+    names = [n for i, blk in enumerate(blocks) for n, _ in blk.named_parameters(prefix="blocks.%d" % i)]
+    for other in (got, hooked):
+        assert torch.isfinite(ref[1]).all() and float(ref[1].abs().max()) > 0
+        assert torch.equal(ref[0], other[0])
+        assert torch.equal(ref[1], other[1]), float((ref[1] - other[1]).abs().max())
+        for n, a, bb in zip(names, ref[2], other[2]):
+            assert torch.equal(a, bb), (n, float((a - bb).abs().max()), float(a.abs().max()))
+
+
 def test_hipgraph_replay_matches_eager_training():
     """The whole training step (forward, HIP loss head, backward with the side-stream weight gradients, fused SGD with
     drop-path) captured into a hipGraph and replayed == the same number of eager steps: identical kernels on identical
