@@ -625,6 +625,24 @@ def test_attention_bwd_column_sums_refused_where_not_built(ops):
     assert ops_mod.attention_bwd_colsum_ok(q96, 160, 96) and not ops_mod.attention_bwd_colsum_ok(q96, 193, 96)
     assert ops_mod.attention_bwd_colsum_ok(q64, 608, 64) and not ops_mod.attention_bwd_colsum_ok(q64, 609, 64)
     assert not ops_mod.attention_bwd_colsum_ok(q64.float(), 129, 64)
+    # the C entry itself: NULL partial rows, a sequence beyond 608 tokens and 96-wide heads beyond 160 are errors, not silent no-ops;
+    # ops.attention_bwd(colsum=...) refuses what attention_bwd_colsum_ok refuses
+    def raw(hd, heads, t, parts=True):
+        b = 2
+        qkv = (torch.randn(b * t, 3 * heads * hd) * 0.5).bfloat16().cuda()
+        o, lse = ops.attention_fwd(qkv, b, t, heads, hd, None, None)
+        dq = torch.empty_like(qkv)
+        ws = torch.empty(heads * b * t, device="cuda")
+        cp = torch.empty(b * 3 * heads * hd, device="cuda") if parts else None
+        ops_mod.call("editor_attention_bwd_colsum_bf16", qkv, o, o, lse, b, t, heads, hd, hd ** -0.5, None, dq, ws, None, b * t, cp)
+    raw(64, 12, 129)
+    for bad in ((64, 12, 129, False), (64, 12, 640), (96, 8, 193)):
+        with pytest.raises(RuntimeError):
+            raw(*bad)
+    with pytest.raises(ValueError):
+        qkv = torch.zeros(2 * 193, 3 * 8 * 96, dtype=torch.bfloat16, device="cuda")
+        ops.attention_bwd(qkv, qkv[:, :768].contiguous(), 2, 193, 8, 96, None, torch.zeros(8 * 2 * 193, device="cuda"),
+                          qkv[:, :768].contiguous(), colsum=torch.empty(3 * 768, device="cuda"))
 
 
 @pytest.mark.parametrize("hd,heads", [(32, 12), (96, 8)])
