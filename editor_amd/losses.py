@@ -43,7 +43,10 @@ def _loss_func(cfg=None):
     def loss_func(score, feat, target, target_cam=None):
         if feat.shape[0] != target.shape[0]:                          # make_loss.py:38-39
             target = target.repeat(feat.shape[0] // target.shape[0])
-        return idw * cross_entropy_label_smooth(score, target) + trw * triplet_soft_margin(feat, target)
+        # (a weight of exactly 1.0 - the shipped value of both - is not multiplied in: x * 1.0 == x bit for bit, and each product is
+        #  a one-element launch in the forward and another in the backward)
+        ce, tri = cross_entropy_label_smooth(score, target), triplet_soft_margin(feat, target)
+        return (ce if idw == 1.0 else idw * ce) + (tri if trw == 1.0 else trw * tri)
 
     return loss_func
 
