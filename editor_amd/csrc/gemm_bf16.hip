@@ -1703,6 +1703,61 @@ extern "C" int editor_gemm_group(int dtype, int count, const uint16_t* const* A,
     return (int)hipErrorInvalidValue;
 }
 
+#ifdef EDITOR_DEBUG_TRACE
+// Probe (debug build only, tools/hetero_probe.py): ONE launch whose first `nmem` workgroups stream memory (d = s0 + s1 over
+// n4 float4, grid-stride over those workgroups - a stand-in for an HBM-bound pass such as a LayerNorm backward) while the others run
+// the ping-pong kernel's body on the tiles of a forward product.  Same resource footprint for both roles (one workgroup per CU), so
+// the first nmem workgroups to be dispatched hold nmem CUs for as long as their stream lasts and the tiles cycle over the rest:
+// does an MFMA-bound and an HBM-bound role overlap INSIDE a launch, where two queues do not (4.1e)?
+struct HeteroArgs { GemmB16Args g; const float4_t* s0; const float4_t* s1; float4_t* d; long n4; int nmem; };
+template <bool F16>
+__global__ __launch_bounds__(512) void gemm_hetero_probe_kernel(HeteroArgs h)
+{
+    if ((int)blockIdx.x < h.nmem) {
+        constexpr int U = 8;                                    // 16 x 16-byte loads in flight per thread: 128 KiB per workgroup
+        const long stride = (long)h.nmem * 512;
+        long i = (long)blockIdx.x * 512 + threadIdx.x;
+        for (; i + (U - 1) * stride < h.n4; i += U * stride) {
+            float4_t a[U], b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a[u] = __builtin_nontemporal_load(h.s0 + i + u * stride); b[u] = __builtin_nontemporal_load(h.s1 + i + u * stride); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                __builtin_nontemporal_store(a[u] + b[u], h.d + i + u * stride);
+            }
+        }
+        for (; i < h.n4; i += stride) {
+            h.d[i] = h.s0[i] + h.s1[i];
+        }
+        return;
+    }
+    pp_body<F16, true, true, false, 8, 8, false>(h.g, (int)blockIdx.x - h.nmem, 0);
+}
+
+// tiles == 0: only the memory role (nmem workgroups); n4 == 0: only the product (the memory workgroups return at once)
+extern "C" int editor_probe_gemm_hetero(const uint16_t* A, const uint16_t* B, void* C, int M, int N, int K, const float* bias,
+                                        int with_tiles, const float* s0, const float* s1, float* d, long n4, int nmem,
+                                        hipStream_t stream)
+{
+    if (M < 256 || N < 256 || (N & 255) || K < BK || (K % BK) || nmem < 0 || (nmem & 7)) return (int)hipErrorInvalidValue;
+    const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
+    HeteroArgs h;
+    memset(&h, 0, sizeof(h));
+    GemmB16Args g{(const bf16_t*)A, (const bf16_t*)B, C, M, N, K, (long)K, (long)K, (long)N, 1.f, 0.f, bias, nullptr, 1, tiles_m, tiles_n,
+                  EDITOR_EPI_NONE, nullptr, (long)N, 0, nullptr, 0, 1, nullptr, nullptr, 1, 0, 0, nullptr, nullptr, nullptr, 0, 0};
+    h.g = g;
+    h.s0 = reinterpret_cast<const float4_t*>(s0); h.s1 = reinterpret_cast<const float4_t*>(s1); h.d = reinterpret_cast<float4_t*>(d);
+    h.n4 = n4; h.nmem = nmem;
+    constexpr int LDS = 256 * (256 * 2 + 16) + (int)kLutBytes;
+    if (int e = ensure_lds<gemm_hetero_probe_kernel<false>>(LDS)) return e;
+    const int grid = nmem + (with_tiles ? tiles_m * tiles_n : 0);
+    if (grid < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((gemm_hetero_probe_kernel<false>), dim3(grid), dim3(512), LDS, stream, h);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+#endif
+
 extern "C" int editor_gemm_wgrad_group(int dtype, int count, const uint16_t* const* dy, const uint16_t* const* x, float* const* dw,
     const int* N, const int* K, int M, float alpha, int splitk, float* ws, const int* m_live, hipStream_t stream)
 {

@@ -37,6 +37,12 @@ int editor_probe_resid_add_layernorm(const float* x, const uint16_t* branch, con
  * accumulator file, one workgroup barrier per K-tile): C (M,N) 16-bit = A (M,K) B (N,K)^T, N % 256 == 0, K % 64 == 0 */
 int editor_probe_gemm_w4(const uint16_t* A, const uint16_t* B, uint16_t* C, int f16, int M, int N, int K, long lda, long ldb,
                          long ldc, int ablate /* 1 no LDS-DMA in the loop, 2 no MFMAs, 4 no fragment reads */, editor_stream_t stream);
+/* libeditor_gemm_trace.so only (csrc/gemm_bf16.hip built with -DEDITOR_DEBUG_TRACE; tools/hetero_probe.py): ONE launch in which the
+ * first nmem workgroups (a multiple of 8) stream memory - d = s0 + s1 over n4 float4 - and the others run the ping-pong kernel's body
+ * on the tiles of C (M,N) bf16 = A (M,K) B (N,K)^T + bias: do an HBM-bound and an MFMA-bound role overlap inside a launch?
+ * with_tiles = 0: the memory role alone; n4 = 0: the product alone (on the CUs the idle memory workgroups free at once). */
+int editor_probe_gemm_hetero(const uint16_t* A, const uint16_t* B, void* C, int M, int N, int K, const float* bias, int with_tiles,
+                             const float* s0, const float* s1, float* d, long n4, int nmem, editor_stream_t stream);
 #ifdef __cplusplus
 }
 #endif
