@@ -1710,11 +1710,10 @@ extern "C" int editor_gemm_group(int dtype, int count, const uint16_t* const* A,
 // the first nmem workgroups to be dispatched hold nmem CUs for as long as their stream lasts and the tiles cycle over the rest:
 // does an MFMA-bound and an HBM-bound role overlap INSIDE a launch, where two queues do not (4.1e)?
 struct HeteroArgs { GemmB16Args g; const float4_t* s0; const float4_t* s1; float4_t* d; long n4; int nmem; };
-template <bool F16>
+template <bool F16, int U>                                      // U: 2 U x 16-byte loads in flight per thread (U = 8: 128 KiB per workgroup)
 __global__ __launch_bounds__(512) void gemm_hetero_probe_kernel(HeteroArgs h)
 {
     if ((int)blockIdx.x < h.nmem) {
-        constexpr int U = 8;                                    // 16 x 16-byte loads in flight per thread: 128 KiB per workgroup
         const long stride = (long)h.nmem * 512;
         long i = (long)blockIdx.x * 512 + threadIdx.x;
         for (; i + (U - 1) * stride < h.n4; i += U * stride) {
@@ -1737,7 +1736,7 @@ __global__ __launch_bounds__(512) void gemm_hetero_probe_kernel(HeteroArgs h)
 // tiles == 0: only the memory role (nmem workgroups); n4 == 0: only the product (the memory workgroups return at once)
 extern "C" int editor_probe_gemm_hetero(const uint16_t* A, const uint16_t* B, void* C, int M, int N, int K, const float* bias,
                                         int with_tiles, const float* s0, const float* s1, float* d, long n4, int nmem,
-                                        hipStream_t stream)
+                                        int unroll, hipStream_t stream)
 {
     if (M < 256 || N < 256 || (N & 255) || K < BK || (K % BK) || nmem < 0 || (nmem & 7)) return (int)hipErrorInvalidValue;
     const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
@@ -1749,10 +1748,12 @@ extern "C" int editor_probe_gemm_hetero(const uint16_t* A, const uint16_t* B, vo
     h.s0 = reinterpret_cast<const float4_t*>(s0); h.s1 = reinterpret_cast<const float4_t*>(s1); h.d = reinterpret_cast<float4_t*>(d);
     h.n4 = n4; h.nmem = nmem;
     constexpr int LDS = 256 * (256 * 2 + 16) + (int)kLutBytes;
-    if (int e = ensure_lds<gemm_hetero_probe_kernel<false>>(LDS)) return e;
     const int grid = nmem + (with_tiles ? tiles_m * tiles_n : 0);
     if (grid < 1) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((gemm_hetero_probe_kernel<false>), dim3(grid), dim3(512), LDS, stream, h);
+#define HETERO_CASE(Uv) case Uv: { if (int e = ensure_lds<gemm_hetero_probe_kernel<false, Uv>>(LDS)) return e;                 \
+        hipLaunchKernelGGL((gemm_hetero_probe_kernel<false, Uv>), dim3(grid), dim3(512), LDS, stream, h); break; }
+    switch (unroll) { HETERO_CASE(4) HETERO_CASE(8) HETERO_CASE(16) default: return (int)hipErrorInvalidValue; }
+#undef HETERO_CASE
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

@@ -42,7 +42,8 @@ int editor_probe_gemm_w4(const uint16_t* A, const uint16_t* B, uint16_t* C, int 
  * on the tiles of C (M,N) bf16 = A (M,K) B (N,K)^T + bias: do an HBM-bound and an MFMA-bound role overlap inside a launch?
  * with_tiles = 0: the memory role alone; n4 = 0: the product alone (on the CUs the idle memory workgroups free at once). */
 int editor_probe_gemm_hetero(const uint16_t* A, const uint16_t* B, void* C, int M, int N, int K, const float* bias, int with_tiles,
-                             const float* s0, const float* s1, float* d, long n4, int nmem, editor_stream_t stream);
+                             const float* s0, const float* s1, float* d, long n4, int nmem,
+                             int unroll /* 4, 8, 16: 2 x unroll 16-byte loads in flight per thread */, editor_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ def main():
     fn = tr.editor_probe_gemm_hetero
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + \
-                  [ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
+                  [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     m, n, k = 3 * 128 * 129, 3072, 768
@@ -38,9 +38,9 @@ def main():
     n4 = nf // 4
     stream = _lib._raw_stream(torch.cuda.current_device())
 
-    def call(with_tiles, n4_, nmem):
+    def call(with_tiles, n4_, nmem, unroll=8):
         rc = fn(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, bias.data_ptr(), with_tiles, s0.data_ptr(), s1.data_ptr(),
-                d.data_ptr(), n4_, nmem, stream)
+                d.data_ptr(), n4_, nmem, unroll, stream)
         if rc:
             raise RuntimeError("editor_probe_gemm_hetero -> %d" % rc)
 
@@ -75,6 +75,13 @@ def main():
         t_h = timeit(lambda: call(1, n4, nmem))
         print("nmem = %3d: memory role alone on %3d CUs %7.1f us (%.2f TB/s), product beside %3d idle workgroups %7.1f us, "
               "BOTH IN ONE LAUNCH %7.1f us  (sum of the full-chip times %.1f)" % (nmem, nmem, t_mo, mb / t_mo, nmem, t_go, t_h, t_g + t_m))
+    # bytes in flight per workgroup: 64 / 128 / 256 KiB
+    for unroll in (4, 8, 16):
+        for nmem in (32, 64):
+            t_mo = timeit(lambda: call(0, n4, nmem, unroll))
+            t_h = timeit(lambda: call(1, n4, nmem, unroll))
+            print("%3d KiB in flight per workgroup, nmem = %2d: memory role alone %7.1f us (%.1f GB/s per CU), both in one launch %7.1f us"
+                  % (unroll * 16, nmem, t_mo, mb * 1e3 / t_mo / nmem, t_h))
 
 
 if __name__ == "__main__":
