@@ -1306,6 +1306,132 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_group_kernel(GemmGroupArgs g
     pp_body<F16, false, false, true, 8, 8, false>(ga.p[pi], t - ga.start[pi], split);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// A MEMORY-BOUND ROLE inside the weight-gradient launch (round 4, last experiment; DESIGN 9, tools/hetero_probe.py: an HBM-bound and
+// an MFMA-bound kernel do not overlap across queues on this runtime, but two ROLES of one launch do - a CU streams ~55 GB/s, so a
+// quarter of the chip carries 3 TB/s while the rest multiplies).  The LayerNorm-1 backward of a block (with the 16-bit gradient copy
+// for the block below, norm.hip: layernorm_bwd_kernel<T, NV, CAST = true>) is independent of the block's grouped weight gradients
+// and adjacent to them: here its rows are taken by the first `nmem` workgroups of the launch - wave per row as in the stand-alone
+// kernel, the same arithmetic per row, so dx and the 16-bit copy are bit-identical; the partial sums (dgamma / dbeta / column sums of
+// the copy) come out as one row per memory workgroup instead of one per block of the stand-alone grid.
+struct LnRoleArgs {
+    const uint16_t* dy; const float* x; const float* gamma; const float* mean; const float* rstd; long M; int D;
+    const float* dx_in; float* dx_out; float* partials; float dy_scale;
+    uint16_t* cast_out; const float* cast_rowscale; float cast_scale; float* cast_partials;
+    int nmem;
+};
+template <bool F16, int NV>
+__device__ __forceinline__ void ln_bwd_cast_role(const LnRoleArgs& a, const int wg, float* red /* [8][3][1024] floats */)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int D = a.D;
+    float4 g[NV], dg[NV], db[NV], ccs[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i]; ccs[i] = dg[i];
+        g[i] = *reinterpret_cast<const float4*>(a.gamma + (i * 64 + lane) * 4);
+    }
+    // R rows per wave in flight: a workgroup of the role has 8 waves on its CU where the stand-alone kernel has 16 workgroups' worth -
+    // with one row per wave (two dependent memory phases per row) the role reached ~15 GB/s per CU; every load of R rows is issued
+    // before the first is used
+    constexpr int R = 2;
+    for (long row0 = (long)wg * 8 * R + w; row0 < a.M; row0 += (long)a.nmem * 8 * R) {
+        float4 xv[R][NV], rin[R][NV];
+        uint2 dyv[R][NV];
+        float mean[R], rstd[R], rsc[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const long row = row0 + j * 8;
+            const bool live = row < a.M;
+            mean[j] = live ? a.mean[row] : 0.f;
+            rstd[j] = live ? a.rstd[row] : 0.f;
+            rsc[j] = (live && a.cast_rowscale) ? a.cast_rowscale[row] : 1.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c0 = (i * 64 + lane) * 4;
+                xv[j][i] = live ? *reinterpret_cast<const float4*>(a.x + row * D + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                dyv[j][i] = live ? *reinterpret_cast<const uint2*>(a.dy + row * D + c0) : make_uint2(0u, 0u);
+                rin[j][i] = (live && a.dx_in) ? *reinterpret_cast<const float4*>(a.dx_in + row * D + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const long row = row0 + j * 8;
+            if (row >= a.M) break;                               // (wave-uniform)
+            float4 xh[NV], d[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float2_t_ lo = H16<F16>::unpack2(dyv[j][i].x), hi = H16<F16>::unpack2(dyv[j][i].y);
+                d[i] = make_float4(lo.x * a.dy_scale, lo.y * a.dy_scale, hi.x * a.dy_scale, hi.y * a.dy_scale);
+                xh[i] = make_float4((xv[j][i].x - mean[j]) * rstd[j], (xv[j][i].y - mean[j]) * rstd[j], (xv[j][i].z - mean[j]) * rstd[j],
+                                    (xv[j][i].w - mean[j]) * rstd[j]);
+                dg[i].x += d[i].x * xh[i].x; dg[i].y += d[i].y * xh[i].y; dg[i].z += d[i].z * xh[i].z; dg[i].w += d[i].w * xh[i].w;
+                db[i].x += d[i].x; db[i].y += d[i].y; db[i].z += d[i].z; db[i].w += d[i].w;
+                d[i].x *= g[i].x; d[i].y *= g[i].y; d[i].z *= g[i].z; d[i].w *= g[i].w;
+                s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+                s2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
+            }
+            s1 = wave_sum(s1) / (float)D;
+            s2 = wave_sum(s2) / (float)D;
+            const float r = rsc[j] * a.cast_scale;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c0 = (i * 64 + lane) * 4;
+                float4 o;
+                o.x = rstd[j] * (d[i].x - s1 - xh[i].x * s2) + rin[j][i].x;
+                o.y = rstd[j] * (d[i].y - s1 - xh[i].y * s2) + rin[j][i].y;
+                o.z = rstd[j] * (d[i].z - s1 - xh[i].z * s2) + rin[j][i].z;
+                o.w = rstd[j] * (d[i].w - s1 - xh[i].w * s2) + rin[j][i].w;
+                *reinterpret_cast<float4*>(a.dx_out + row * D + c0) = o;
+                o.x *= r; o.y *= r; o.z *= r; o.w *= r;
+                uint2 pk; pk.x = H16<F16>::pack2(o.x, o.y); pk.y = H16<F16>::pack2(o.z, o.w);
+                *reinterpret_cast<uint2*>(a.cast_out + row * D + c0) = pk;
+                const float2_t_ rl = H16<F16>::unpack2(pk.x), rh = H16<F16>::unpack2(pk.y);
+                ccs[i].x += rl.x; ccs[i].y += rl.y; ccs[i].z += rh.x; ccs[i].w += rh.y;
+            }
+        }
+    }
+    // this workgroup's partial rows: [which = dgamma, dbeta, column sums of the copy][D], its eight waves folded in a fixed order
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c0 = (i * 64 + lane) * 4;
+        *reinterpret_cast<float4*>(&red[(w * 3 + 0) * 1024 + c0]) = dg[i];
+        *reinterpret_cast<float4*>(&red[(w * 3 + 1) * 1024 + c0]) = db[i];
+        *reinterpret_cast<float4*>(&red[(w * 3 + 2) * 1024 + c0]) = ccs[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 3 * D; c += 512) {
+        const int which = c / D, col = c % D;
+        float t = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) t += red[(ww * 3 + which) * 1024 + col];
+        if (which < 2) a.partials[((long)wg * 2 + which) * D + col] = t;
+        else if (a.cast_partials) a.cast_partials[(long)wg * D + col] = t;
+    }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_group_ln_kernel(GemmGroupArgs ga, LnRoleArgs ln)
+{
+    if ((int)blockIdx.x < ln.nmem) {                              // (workgroup-uniform: the memory role never meets the tiles' barriers)
+        extern __shared__ __attribute__((aligned(16))) char smem_ln[];
+        if (ln.D == 768) ln_bwd_cast_role<F16, 3>(ln, (int)blockIdx.x, reinterpret_cast<float*>(smem_ln));
+        else ln_bwd_cast_role<F16, 4>(ln, (int)blockIdx.x, reinterpret_cast<float*>(smem_ln));
+        return;
+    }
+    // (the weight-gradient group's own order, gemm_bf16_pp_group_kernel, over the remaining workgroups; nmem is a multiple of 8)
+    const int ntile = ga.start[ga.n], total = (int)gridDim.x - ln.nmem;
+    const int L = (int)blockIdx.x - ln.nmem, xcd = L & 7, q = total >> 3, r = total & 7;
+    const int Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    const int split = Lp / ntile, t = Lp % ntile;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxGroup; ++i) pi += (i < ga.n && t >= ga.start[i]) ? 1 : 0;
+    pi = __builtin_amdgcn_readfirstlane(pi);
+    pp_body<F16, false, false, true, 8, 8, false>(ga.p[pi], t - ga.start[pi], split);
+}
+
 // GROUPED forward / dgrad products (round 4): up to four products of IDENTICAL shape, layout and epilogue kind with different
 // operands - the three per-modality blocks of the HMA head, whose ~7 400 live token rows make 87 tiles of a 768-wide output each
 // (a third of a round of 256 CUs per launch) - as ONE launch: grid = the problems' tiles back to back.  Each workgroup runs the
@@ -1605,7 +1731,7 @@ int gemm_f16x2(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi,
 // ws: splitk * sum_i N_i K_i floats of slabs; fixed-order reduction per problem afterwards (deterministic).
 template <bool F16>
 int gemm_wgrad_group(int count, const uint16_t* const* dy, const uint16_t* const* x, float* const* dw, const int* N, const int* K,
-                     int M, float alpha, int splitk, float* ws, const int* m_live, hipStream_t stream)
+                     int M, float alpha, int splitk, float* ws, const int* m_live, hipStream_t stream, const LnRoleArgs* ln = nullptr)
 {
     if (count < 1 || count > kMaxGroup || M < 64 || (M % 64) || splitk < 1 || !ws) return (int)hipErrorInvalidValue;
     GemmGroupArgs ga;
@@ -1631,8 +1757,13 @@ int gemm_wgrad_group(int count, const uint16_t* const* dy, const uint16_t* const
     }
     ga.start[count] = tiles;
     constexpr int LDS = 256 * (256 * 2 + 16) + (int)kLutBytes;
-    if (int e = ensure_lds<gemm_bf16_pp_group_kernel<F16>>(LDS)) return e;
-    hipLaunchKernelGGL(gemm_bf16_pp_group_kernel<F16>, dim3(tiles * splitk), dim3(512), LDS, stream, ga);
+    if (ln) {
+        if (int e = ensure_lds<gemm_bf16_pp_group_ln_kernel<F16>>(LDS)) return e;
+        hipLaunchKernelGGL(gemm_bf16_pp_group_ln_kernel<F16>, dim3(ln->nmem + tiles * splitk), dim3(512), LDS, stream, ga, *ln);
+    } else {
+        if (int e = ensure_lds<gemm_bf16_pp_group_kernel<F16>>(LDS)) return e;
+        hipLaunchKernelGGL(gemm_bf16_pp_group_kernel<F16>, dim3(tiles * splitk), dim3(512), LDS, stream, ga);
+    }
     EDITOR_LAUNCH_CHECK();
     SlabJobs sj;
     memset(&sj, 0, sizeof(sj));
@@ -1764,6 +1895,25 @@ extern "C" int editor_gemm_wgrad_group(int dtype, int count, const uint16_t* con
 {
     if (dtype == 2) return gemm_wgrad_group<true>(count, dy, x, dw, N, K, M, alpha, splitk, ws, m_live, stream);
     if (dtype == 1) return gemm_wgrad_group<false>(count, dy, x, dw, N, K, M, alpha, splitk, ws, m_live, stream);
+    return (int)hipErrorInvalidValue;
+}
+
+extern "C" int editor_gemm_wgrad_group_ln(int dtype, int count, const uint16_t* const* dy, const uint16_t* const* x, float* const* dw,
+    const int* N, const int* K, int M, float alpha, int splitk, float* ws,
+    const uint16_t* ln_dy, float ln_dy_scale, const float* ln_x, const float* gamma, const float* mean, const float* rstd, long ln_M,
+    int D, const float* dx_in, float* dx_out, float* partials, uint16_t* cast_out, const float* cast_rowscale, float cast_scale,
+    float* cast_partials, int nmem, hipStream_t stream)
+{
+    if ((D != 768 && D != 1024) || nmem < 8 || (nmem & 7) || nmem > 256 || ln_M < 1 || !ln_dy || !ln_x || !gamma || !mean || !rstd ||
+        !dx_out || !partials || !cast_out)
+        return (int)hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(ln_dy) & 7) || ((reinterpret_cast<uintptr_t>(ln_x) | reinterpret_cast<uintptr_t>(dx_out) |
+         reinterpret_cast<uintptr_t>(dx_in) | reinterpret_cast<uintptr_t>(gamma)) & 15) || (reinterpret_cast<uintptr_t>(cast_out) & 7))
+        return (int)hipErrorInvalidValue;
+    LnRoleArgs ln{ln_dy, ln_x, gamma, mean, rstd, ln_M, D, dx_in, dx_out, partials, ln_dy_scale, cast_out, cast_rowscale, cast_scale,
+                  cast_partials, nmem};
+    if (dtype == 2) return gemm_wgrad_group<true>(count, dy, x, dw, N, K, M, alpha, splitk, ws, nullptr, stream, &ln);
+    if (dtype == 1) return gemm_wgrad_group<false>(count, dy, x, dw, N, K, M, alpha, splitk, ws, nullptr, stream, &ln);
     return (int)hipErrorInvalidValue;
 }
 

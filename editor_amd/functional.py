@@ -303,6 +303,8 @@ REVERSE_ROWS = ops.EPI_REVERSE_ROWS if os.environ.get("EDITOR_REVERSE_ROWS", "0"
 # producer fills it and the consumer checks that the gradient it is handed is the very tensor the producer returned, unmodified
 # (storage, size, version counter) - anything else (a second consumer of the block output, hooks) falls back to the plain pass.
 HANDOFF_CAST = os.environ.get("EDITOR_HANDOFF_CAST", "1") != "0"
+# (opt-in) LayerNorm-1's backward as a memory-bound ROLE of the block's weight-gradient launch - see backward_gen, DESIGN 9
+WGRAD_LN = os.environ.get("EDITOR_WGRAD_LN", "0") == "1"
 _CAST_SLOT = [None]
 
 
@@ -647,12 +649,23 @@ class TransformerBlockFn(torch.autograd.Function):
             h1 = ops.layernorm_fwd(x2d, n1w, light[0], light[2], act_dtype, mask, 0, want_stats=False, m_live=m_live)[0]
         dh1, dwq, dbq = yield from _linear_bwd_gen(dqkv, h1, wq, hb_qkv, m_live=m_live, db=dbq, gs=gs, dw_out=sv[2], db_out=sv[3], w_t=wqt,
                                     defer=jobs, rq=rq, rev=REVERSE_ROWS if m_live is None else 0)
-        if jobs:
+        fb = getattr(ctx, "feeds_box", None)
+        ln_done = False
+        if jobs and WGRAD_LN and fb is not None and fuse_cast and not deferred:
+            # (opt-in, round 4) the block's four weight gradients AND LayerNorm-1's backward as two ROLES of one launch on this stream:
+            # the memory-bound rows on a quarter of the CUs beside the tiles on the rest (ops.gemm_wgrad_group_ln)
+            dx, dn1w, dn1b, dy_below, db_below = ops.gemm_wgrad_group_ln(
+                jobs, m, 1.0 / gs, dh1, x2d, n1w, mean1, rstd1, dx1, fb.rowscale, fb.gs, dy_scale=1.0 / gs,
+                dgb_out=sink.ln_pair(0) if sink is not None else None, want_colsum=fb.has_bias, cs_out=fb.cs_out, rq=rq)
+            fb.put(dx, dy_below, db_below)
+            ln_done = True
+        elif jobs:
             # every dy exists: the block's four weight gradients in one launch.  Side stream (joined one block later)
             # unless a gradient sink needs them at the end of THIS block
             yield _WgradReq(jobs, m, 1.0 / gs, m_live, deferred, dx2.device)
-        fb = getattr(ctx, "feeds_box", None)
-        if fb is not None and fuse_cast:
+        if ln_done:
+            pass
+        elif fb is not None and fuse_cast:
             # ... and hands the block BELOW the start of its backward (see HANDOFF_CAST): its drop-path row scale, its bias-gradient slot
             dx, dn1w, dn1b, dy_below, db_below = ops.layernorm_bwd_cast(
                 dh1, x2d, n1w, mean1, rstd1, dx1, fb.rowscale, fb.gs, dy_scale=1.0 / gs,

@@ -702,6 +702,55 @@ def gemm_wgrad_group(jobs, m, alpha=1.0, m_live=None):
          ia(ns), ia(ks), m, float(alpha), sk, ws, m_live)
 
 
+WGRAD_LN_CUS = int(os.environ.get("EDITOR_WGRAD_LN_CUS", "64"))      # workgroups (= CUs) of the memory role, a multiple of 8
+
+
+def gemm_wgrad_group_ln(jobs, m, alpha, dy, x2d, gamma, mean, rstd, dx_in, rowscale, scale=1.0, dy_scale=1.0, dgb_out=None,
+                        want_colsum=True, cs_out=None, rq=None, nmem=None):
+    """gemm_wgrad_group(jobs, m, alpha) AND layernorm_bwd_cast(dy, x2d, gamma, mean, rstd, dx_in, rowscale, scale, dy_scale, ...) in ONE
+    launch: the LayerNorm backward as a memory-bound role on `nmem` CUs beside the weight-gradient tiles on the others
+    (include/editor_hip.h: editor_gemm_wgrad_group_ln).  -> dx, dgamma, dbeta, dx16, colsum(dx16) / scale (None unless want_colsum)."""
+    cnt = len(jobs)
+    nmem = int(nmem or WGRAD_LN_CUS)
+    dt = _DT_CODE[jobs[0][0].dtype]
+    ns = [j[0].shape[1] for j in jobs]
+    ks = [j[1].shape[1] for j in jobs]
+    tiles = sum((n // 256) * (k // 256) for n, k in zip(ns, ks))
+    sk = wgrad_group_split(tiles, m // 64)
+    ws = workspace(jobs[0][0].device, sk * sum(n * k for n, k in zip(ns, ks)))
+    arr = lambda ts: (ctypes.c_void_p * cnt)(*[t.data_ptr() for t in ts])
+    ia = lambda v: (ctypes.c_int * cnt)(*v)
+    for jdy, jx, jdw in jobs:
+        assert jdy.is_contiguous() and jx.is_contiguous() and jdw.is_contiguous() and jdy.shape[0] == m == jx.shape[0]
+    rows, d = x2d.shape
+    assert dy.dtype == jobs[0][0].dtype and dy.shape == x2d.shape and d in (768, 1024)
+    dev = x2d.device
+    dx = torch.empty(rows, d, dtype=torch.float32, device=dev)
+    dx16 = torch.empty(rows, d, dtype=dy.dtype, device=dev)
+    dgb = dgb_out if dgb_out is not None else torch.empty(2, d, dtype=torch.float32, device=dev)
+    cs = None
+    if want_colsum:
+        cs = cs_out if cs_out is not None else torch.empty(d, dtype=torch.float32, device=dev)
+    parts = rq.region(nmem * 3 * d) if rq is not None else None
+    queued = parts is not None
+    if not queued:
+        parts = torch.empty(nmem * 3 * d, dtype=torch.float32, device=dev)
+    cparts = parts[nmem * 2 * d:]
+    call("editor_gemm_wgrad_group_ln", dt, cnt, arr([j[0] for j in jobs]), arr([j[1] for j in jobs]), arr([j[2] for j in jobs]),
+         ia(ns), ia(ks), m, float(alpha), sk, ws,
+         dy, float(dy_scale), x2d, gamma, mean, rstd, rows, d, dx_in, dx, parts, dx16, rowscale, float(scale),
+         cparts if want_colsum else None, nmem)
+    if queued:
+        rq.add(parts, nmem, 2 * d, dgb, 1.0)
+        if want_colsum:
+            rq.add(cparts, nmem, d, cs, 1.0 / float(scale))
+    else:
+        call("editor_reduce_rows", parts, nmem, 2 * d, dgb, 0, 1.0)
+        if want_colsum:
+            call("editor_reduce_rows", cparts, nmem, d, cs, 0, 1.0 / float(scale))
+    return dx, dgb[0], dgb[1], dx16, cs
+
+
 # head widths the fused 16-bit attention / rollout kernels are built for (csrc/attention_bf16.hip compiled per width, round 4:
 # 64 = ViT-B/L, DeiT-B; 96 = ViT-small's backbone; 32 = DeiT-small's HMA heads)
 ATTN_HEAD_WIDTHS = (32, 64, 96)

@@ -242,6 +242,19 @@ int editor_gemm_f16x2(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t
 int editor_gemm_wgrad_group(int dtype, int count, const uint16_t* const* dy, const uint16_t* const* x, float* const* dw,
                             const int* N, const int* K, int M, float alpha, int splitk, float* ws, const int* m_live,
                             editor_stream_t stream);
+/* The same launch (dense rows: no m_live) with a MEMORY-BOUND ROLE riding in it (round 4, opt-in: cfg / EDITOR_WGRAD_LN=1): the first
+ * `nmem` workgroups (8 .. 256, a multiple of 8) do the LayerNorm backward that is independent of, and adjacent to, the block's
+ * weight gradients (Block.norm1, vit_pytorch.py:215-220 backward) WITH the 16-bit copy of its result for the block below - exactly
+ * editor_layernorm_bwd_cast_parts' arithmetic per row (D = 768 or 1024): dx_out = dLN(ln_dy * ln_dy_scale) + dx_in, cast_out =
+ * 16-bit(dx_out * cast_rowscale[row] * cast_scale); partial rows, ONE PER MEMORY WORKGROUP: partials [nmem][2][D] (dgamma, dbeta),
+ * cast_partials [nmem][D] (column sums of the rounded copy; NULL to skip) - to be folded by editor_reduce_rows(_multi) with P = nmem.
+ * On this runtime an HBM-bound and an MFMA-bound kernel do not overlap across queues; two roles of one launch do. */
+int editor_gemm_wgrad_group_ln(int dtype, int count, const uint16_t* const* dy, const uint16_t* const* x, float* const* dw,
+                               const int* N, const int* K, int M, float alpha, int splitk, float* ws,
+                               const uint16_t* ln_dy, float ln_dy_scale, const float* ln_x, const float* gamma, const float* mean,
+                               const float* rstd, long ln_M, int D, const float* dx_in, float* dx_out, float* partials,
+                               uint16_t* cast_out, const float* cast_rowscale, float cast_scale, float* cast_partials, int nmem,
+                               editor_stream_t stream);
 
 /* GROUPED forward / dgrad products (round 4): `count` <= 4 products C_i = alpha A_i B_i^T (+ bias_i) (* rowscale_i) (+ epilogue) of
  * IDENTICAL shape and epilogue kind, both operands k-major (A_i (M,K), B_i (N,K)), as ONE launch of the 256x256 ping-pong kernel -
