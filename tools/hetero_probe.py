@@ -26,7 +26,8 @@ def main():
                   [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
-    m, n, k = 3 * 128 * 129, 3072, 768
+    m, n, k = 3 * 128 * 129, int(os.environ.get("PROBE_N", 3072)), int(os.environ.get("PROBE_K", 768))
+    print("product %d x %d x %d (%d tiles)" % (m, n, k, (m + 255) // 256 * (n // 256)))
     a = torch.randn(m, k, device=dev, generator=g).bfloat16()
     w = (torch.randn(n, k, device=dev, generator=g) * 0.05).bfloat16()
     bias = torch.randn(n, device=dev, generator=g)
@@ -66,7 +67,7 @@ def main():
     mb = 3 * nf * 4 / 1e6
     t_g = timeit(lambda: call(1, 0, 0))
     t_m = timeit(lambda: call(0, n4, 1024))
-    print("product alone (2 328 tiles on 256 CUs)          %7.1f us" % t_g)
+    print("product alone on 256 CUs                         %7.1f us" % t_g)
     print("memory role alone on every CU (%d MB moved)      %7.1f us = %.2f TB/s" % (mb, t_m, mb / t_m))
     print("one after the other                              %7.1f us" % (t_g + t_m))
     for nmem in (16, 32, 48, 64, 96):
