@@ -1864,6 +1864,35 @@ __global__ __launch_bounds__(512) void gemm_hetero_probe_kernel(HeteroArgs h)
     pp_body<F16, true, true, false, 8, 8, false>(h.g, (int)blockIdx.x - h.nmem, 0);
 }
 
+// the same with the REAL LayerNorm-backward role (ln_bwd_cast_role) as the memory-bound part: is it the role or its partner that
+// made editor_gemm_wgrad_group_ln slow?
+template <bool F16>
+__global__ __launch_bounds__(512) void gemm_hetero_ln_probe_kernel(GemmB16Args g, LnRoleArgs ln)
+{
+    if ((int)blockIdx.x < ln.nmem) {
+        extern __shared__ __attribute__((aligned(16))) char smem_ln[];
+        ln_bwd_cast_role<F16, 3>(ln, (int)blockIdx.x, reinterpret_cast<float*>(smem_ln));
+        return;
+    }
+    pp_body<F16, true, true, false, 8, 8, false>(g, (int)blockIdx.x - ln.nmem, 0);
+}
+extern "C" int editor_probe_gemm_hetero_ln(const uint16_t* A, const uint16_t* B, void* C, int M, int N, int K, const float* bias,
+    int with_tiles, const uint16_t* ln_dy, const float* ln_x, const float* gamma, const float* mean, const float* rstd, long ln_M,
+    const float* dx_in, float* dx_out, float* partials, uint16_t* cast_out, float* cast_partials, int nmem, hipStream_t stream)
+{
+    if (M < 256 || N < 256 || (N & 255) || K < BK || (K % BK) || nmem < 8 || (nmem & 7)) return (int)hipErrorInvalidValue;
+    const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
+    GemmB16Args g{(const bf16_t*)A, (const bf16_t*)B, C, M, N, K, (long)K, (long)K, (long)N, 1.f, 0.f, bias, nullptr, 1, tiles_m, tiles_n,
+                  EDITOR_EPI_NONE, nullptr, (long)N, 0, nullptr, 0, 1, nullptr, nullptr, 1, 0, 0, nullptr, nullptr, nullptr, 0, 0};
+    LnRoleArgs ln{ln_dy, ln_x, gamma, mean, rstd, ln_M, 768, dx_in, dx_out, partials, 1.f, cast_out, nullptr, 1.f, cast_partials, nmem};
+    constexpr int LDS = 256 * (256 * 2 + 16) + (int)kLutBytes;
+    if (int e = ensure_lds<gemm_hetero_ln_probe_kernel<false>>(LDS)) return e;
+    const int grid = nmem + (with_tiles ? tiles_m * tiles_n : 0);
+    hipLaunchKernelGGL((gemm_hetero_ln_probe_kernel<false>), dim3(grid), dim3(512), LDS, stream, g, ln);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
 // tiles == 0: only the memory role (nmem workgroups); n4 == 0: only the product (the memory workgroups return at once)
 extern "C" int editor_probe_gemm_hetero(const uint16_t* A, const uint16_t* B, void* C, int M, int N, int K, const float* bias,
                                         int with_tiles, const float* s0, const float* s1, float* d, long n4, int nmem,

@@ -44,6 +44,11 @@ int editor_probe_gemm_w4(const uint16_t* A, const uint16_t* B, uint16_t* C, int 
 int editor_probe_gemm_hetero(const uint16_t* A, const uint16_t* B, void* C, int M, int N, int K, const float* bias, int with_tiles,
                              const float* s0, const float* s1, float* d, long n4, int nmem,
                              int unroll /* 4, 8, 16: 2 x unroll 16-byte loads in flight per thread */, editor_stream_t stream);
+/* ... and with the real LayerNorm-backward role of editor_gemm_wgrad_group_ln (D = 768, bf16) in place of the plain stream */
+int editor_probe_gemm_hetero_ln(const uint16_t* A, const uint16_t* B, void* C, int M, int N, int K, const float* bias, int with_tiles,
+                                const uint16_t* ln_dy, const float* ln_x, const float* gamma, const float* mean, const float* rstd,
+                                long ln_M, const float* dx_in, float* dx_out, float* partials, uint16_t* cast_out,
+                                float* cast_partials, int nmem, editor_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

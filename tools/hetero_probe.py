@@ -76,6 +76,35 @@ def main():
         t_h = timeit(lambda: call(1, n4, nmem))
         print("nmem = %3d: memory role alone on %3d CUs %7.1f us (%.2f TB/s), product beside %3d idle workgroups %7.1f us, "
               "BOTH IN ONE LAUNCH %7.1f us  (sum of the full-chip times %.1f)" % (nmem, nmem, t_mo, mb / t_mo, nmem, t_go, t_h, t_g + t_m))
+    # the REAL LayerNorm-backward role (the one editor_gemm_wgrad_group_ln carries) in place of the plain stream
+    fl = tr.editor_probe_gemm_hetero_ln
+    fl.restype = ctypes.c_int
+    fl.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_long] + \
+                  [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]
+    rows, dd = 3 * 128 * 129, 768
+    ldy = torch.randn(rows, dd, device=dev, generator=g).bfloat16()
+    lx = torch.randn(rows, dd, device=dev, generator=g)
+    gam = torch.ones(dd, device=dev)
+    mean = torch.zeros(rows, device=dev)
+    rstd = torch.ones(rows, device=dev)
+    dxi = torch.randn(rows, dd, device=dev, generator=g)
+    dxo = torch.empty(rows, dd, device=dev)
+    c16 = torch.empty(rows, dd, device=dev, dtype=torch.bfloat16)
+    parts = torch.empty(256 * 3 * dd, device=dev)
+
+    def call_ln(with_tiles, nmem):
+        rc = fl(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, bias.data_ptr(), with_tiles, ldy.data_ptr(), lx.data_ptr(),
+                gam.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, dxi.data_ptr(), dxo.data_ptr(), parts.data_ptr(),
+                c16.data_ptr(), parts[256 * 2 * dd:].data_ptr(), nmem, stream)
+        if rc:
+            raise RuntimeError("editor_probe_gemm_hetero_ln -> %d" % rc)
+
+    lmb = rows * dd * (2 + 4 + 4 + 4 + 2) / 1e6
+    for nmem in (32, 64, 96, 256):
+        t_lo = timeit(lambda: call_ln(0, nmem))
+        t_lh = timeit(lambda: call_ln(1, nmem)) if nmem < 256 else float("nan")
+        print("LayerNorm-backward role (%d MB), nmem = %3d: alone %7.1f us (%.1f GB/s per CU, %.2f TB/s), beside the product's tiles %7.1f us "
+              "(product alone %.1f)" % (lmb, nmem, t_lo, lmb * 1e3 / t_lo / nmem, lmb / t_lo, t_lh, t_g))
     # bytes in flight per workgroup: 64 / 128 / 256 KiB
     for unroll in (4, 8, 16):
         for nmem in (32, 64):
