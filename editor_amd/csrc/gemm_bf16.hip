@@ -78,6 +78,7 @@ struct GemmB16Args {
                                              // grouped weight-gradient launch does its own XCD mapping)
     int prefer_pipe;                         // EDITOR_EPI_PIPE128
     int rev_rows;                            // EDITOR_EPI_REVERSE_ROWS: tile rows taken last-first (ping-pong kernel)
+    int stagger;                             // EDITOR_EPI_STAGGER(c): the first round's workgroups start spread over c * 2048 cycles (ping-pong kernel)
     int ablate;                              // debug build only (EDITOR_GEMM_ABLATE, tools/gemm_bound_probe.py): 1 = no LDS-DMA inside the
                                              // K loop, 2 = no MFMAs, 4 = no fragment reads - what each costs, by deletion
 };
@@ -883,6 +884,16 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
         if (g.live_is_k) ktiles = min(ktiles, (live + BK - 1) / BK);
         else if (m0 >= live) return;
     }
+    // EDITOR_EPI_STAGGER: every tile of a launch takes the same time, so the 256 CUs run in LOCKSTEP - all in their K loops (matrix
+    // cores busy, HBM idle), then all in their epilogues (HBM saturated: every epilogue kind measures ~12 B per clock and CU = the
+    // chip's HBM rate, matrix cores idle).  The first round's workgroups (one per CU) therefore start spread over `stagger` cycles,
+    // 32 phases per XCD; the hardware hands every later tile to the CU that frees up, so the phases persist, some CUs are in their
+    // epilogue while the others multiply, and the late starters simply take one tile less of the (partly filled) last round.
+    if (g.stagger && by == 0 && bid < 256 && (int)gridDim.x > 256) {
+        const unsigned wait = ((unsigned)g.stagger >> 5) * (unsigned)((bid >> 3) & 31);
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while ((unsigned)(__builtin_amdgcn_s_memtime() - t0) < wait) __builtin_amdgcn_s_sleep(8);
+    }
     const int nkb = ktiles;                                     // K-tiles of one operand half (SPLIT)
     if constexpr (SPLIT) ktiles *= 3;
     const int per = (ktiles + g.splitk - 1) / g.splitk;
@@ -1628,7 +1639,9 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
     if (tile_frags != 0 && tile_frags != 13) return (int)hipErrorInvalidValue;
     const bool prefer_pipe = (epilogue & EDITOR_EPI_PIPE128) != 0 && !want_colsum && !force_pp && tile_frags == 0;
     const bool rev_rows = (epilogue & EDITOR_EPI_REVERSE_ROWS) != 0;
-    epilogue &= ~(EDITOR_EPI_COLSUM | EDITOR_EPI_FORCE_PP | EDITOR_EPI_AUX_GRAD | EDITOR_EPI_PIPE128 | 0xF000 | EDITOR_EPI_REVERSE_ROWS);
+    const int stagger = ((epilogue >> 17) & 63) * 2048;                 // EDITOR_EPI_STAGGER(c)
+    epilogue &= ~(EDITOR_EPI_COLSUM | EDITOR_EPI_FORCE_PP | EDITOR_EPI_AUX_GRAD | EDITOR_EPI_PIPE128 | 0xF000 | EDITOR_EPI_REVERSE_ROWS |
+                  EDITOR_EPI_STAGGER(63));
     if (aux_grad && epilogue != EDITOR_EPI_GELU && epilogue != EDITOR_EPI_GELU_BWD) return (int)hipErrorInvalidValue;
     if (want_colsum && (c_f32 || epilogue == EDITOR_EPI_RESIDUAL || splitk > 1 || !splitk_ws || transA || M < 2048 || N < 512 ||
                         (N & 7) || (ldc & 7) || (ldaux & 7) || (K % BK) || beta != 0.f || m_live))
@@ -1658,7 +1671,7 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
                   slabs ? 0.f : beta, bias, rowscale, splitk, (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux,
                   slabs ? 1 : 0,
                   m_live, transA ? 1 : 0, 0, want_colsum ? splitk_ws : nullptr, nullptr, force_pp ? 1 : 0, aux_grad ? 1 : 0,
-                  tile_frags, nullptr, nullptr, nullptr, 0, prefer_pipe ? 1 : 0, rev_rows ? 1 : 0};
+                  tile_frags, nullptr, nullptr, nullptr, 0, prefer_pipe ? 1 : 0, rev_rows ? 1 : 0, stagger};
     if (m_live && (!pipe || (splitk > 1 && !slabs))) return (int)hipErrorInvalidValue;   // live-row form: pipelined path only
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
     int rc;

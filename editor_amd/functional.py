@@ -43,10 +43,16 @@ def grad_scale(dtype):
     return F16_GRAD_SCALE if dtype == torch.float16 else 1.0
 
 
-def set_model_options(grad_scale_f16=None, act_light=None):
+FWD_GRAD = True        # torch.is_grad_enabled() as EDITOR.forward saw it (it is always False inside Function.forward, and
+                       # ctx.needs_input_grad reflects requires_grad whatever the grad mode: ADVICE r4)
+
+
+def set_model_options(grad_scale_f16=None, act_light=None, grad_enabled=None):
     """Per-MODEL options, installed by EDITOR.forward for the nodes it is about to create (every node captures them in its
     ctx at forward time, so two models with different settings can live in one process).  None = keep."""
-    global ACT_LIGHT
+    global ACT_LIGHT, FWD_GRAD
+    if grad_enabled is not None:
+        FWD_GRAD = bool(grad_enabled)
     if grad_scale_f16 is not None:
         set_f16_grad_scale(grad_scale_f16)
     if act_light is not None:
@@ -294,6 +300,9 @@ class _SubCtx:
 # after the attention backward's dqkv (228 MB) - take their tile rows last-first (ops.EPI_REVERSE_ROWS): they start with the rows
 # that are still cached instead of the ones the producer wrote first.  Same bits (tools/repro_check.py).
 REVERSE_ROWS = ops.EPI_REVERSE_ROWS if os.environ.get("EDITOR_REVERSE_ROWS", "0") == "1" else 0
+# EDITOR_STAGGER_QKV=c (A/B switch, round 5): the qkv forward's first round of workgroups starts spread over c * 2048 cycles
+# (ops.EPI_STAGGER) - the one product the spread helped in tools/stagger_sweep.py (rotating operands: 214 -> 186 us)
+STAGGER_QKV = ops.EPI_STAGGER(int(os.environ.get("EDITOR_STAGGER_QKV", "0")))
 
 # LayerNorm-1's backward of block i+1 also writes what block i's backward STARTS with: the 16-bit, drop-path- and loss-scaled copy of
 # dL/dx (operand of the fc2 dgrad / wgrad) and its column sums (the fc2 bias gradient) - ops.layernorm_bwd_cast, as LayerNorm-2's
@@ -380,6 +389,10 @@ def _linear_bwd_gen(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=No
         need_colsum = True
     else:
         need_colsum = False
+    if need_colsum and m_live is not None:
+        #  ops.colsum sums ALL m rows; behind *m_live the rows of dy are unwritten (cast_rows / the dgrads skip dead tiles).
+        # The only live-row products are the compacted HMA head's, whose linears have no bias (vit_pytorch.py:232-237,150-156).
+        raise RuntimeError("bias gradient of a live-row (compacted) product: editor_colsum has no m_live form")
     sk, skf = _splitk_for(n, k, m)
     if defer is not None:
         # the weight gradient joins the block's grouped launch (issued by the caller once the last dy exists)
@@ -502,7 +515,7 @@ class TransformerBlockFn(torch.autograd.Function):
                            epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)
             del aol
             h2, h2l, mean2, rstd2 = ops.layernorm_fwd_split(x1, n2w, n2b, eps, mask, m_live)
-            a = torch.empty(m, hidden, dtype=act_dtype, device=x.device) if any(ctx.needs_input_grad) else None
+            a = torch.empty(m, hidden, dtype=act_dtype, device=x.device) if (FWD_GRAD and any(ctx.needs_input_grad)) else None
             g = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
             gl = torch.empty_like(g)
             ops.gemm_split((h2, h2l), w1, g, gl, m, hidden, d, alpha=inv_ws, bias=fc1b, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD,
@@ -529,7 +542,8 @@ class TransformerBlockFn(torch.autograd.Function):
             else:
                 h1, mean1, rstd1 = ops.layernorm_fwd(x2d, n1w, n1b, eps, act_dtype, mask, 0, m_live=m_live)
             qkv = torch.empty(m, 3 * d, dtype=act_dtype, device=x.device)
-            yield _GemmReq(h1, wq, qkv, m, 3 * d, d, d, d, 3 * d, 0, 0, bias=qkvb, m_live=m_live)
+            yield _GemmReq(h1, wq, qkv, m, 3 * d, d, d, d, 3 * d, 0, 0, bias=qkvb, m_live=m_live,
+                           epilogue=STAGGER_QKV if m_live is None else 0)
             if isinstance(probs_out, list):            # bf16 backbone: no probability tensor; the rollout recomputes it
                 ao, attn_saved = ops.attention_fwd(qkv, b, t, heads, hd, amask, None, cu=cu, scale=qk_scale)
                 probs_out.append((qkv, attn_saved))
@@ -548,7 +562,7 @@ class TransformerBlockFn(torch.autograd.Function):
         hidden = w1.shape[0]
         # (a no-grad forward - model.eval() under torch.no_grad(), engine/processor.py:217-270 - saves nothing for a backward: the
         #  16-bit fc1 epilogue then writes ONE output instead of two, 304 MB per layer less at B = 128)
-        need_a = any(ctx.needs_input_grad) or act_dtype not in ops.HALF_DTYPES
+        need_a = (FWD_GRAD and any(ctx.needs_input_grad)) or act_dtype not in ops.HALF_DTYPES
         a = torch.empty(m, hidden, dtype=act_dtype, device=x.device) if need_a else None
         g = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
         # 16-bit modes: `a` receives gelu'(pre-activation) - all the backward needs of it (one multiply in the fc2 dgrad

@@ -512,7 +512,7 @@ class EDITOR(nn.Module):
 
     # -- forward (make_model.py:150-258) ----------------------------------------------------------
     def forward(self, x, cam_label=None, label=None, view_label=None, img_path=None, mode=1, writer=None, epoch=None):
-        fn.set_model_options(self.grad_scale_f16, self.act_light)
+        fn.set_model_options(self.grad_scale_f16, self.act_light, torch.is_grad_enabled())
         mods = [x[m_[0]].contiguous() for m_ in self.modalities]             # make_model.py:153-155
         rgb = mods[0]
         nmod = self.nmod

@@ -414,6 +414,12 @@ EPI_AUX_GRAD = 0x400          # with EPI_GELU / EPI_GELU_BWD (16-bit): aux = gel
 EPI_FORCE_PP = 0x200          # run the 256x256 ping-pong kernel whatever the shape heuristic says (tests)
 EPI_REVERSE_ROWS = 0x10000    # ping-pong kernel: tile rows last-first (the consumer of a just-written tensor larger than the
                               # 256 MB Infinity Cache starts with the rows that are still in it)
+def EPI_STAGGER(c):
+    """OR-able (ping-pong kernel, > 256 tiles): the first round's workgroups start spread over c * 2048 shader cycles
+    (include/editor_hip.h) - the CUs leave lockstep, HBM-bound epilogues run beside the other CUs' K loops.  Same bits."""
+    return (int(c) & 63) << 17
+
+
 EPI_PIPE128 = 0x800           # prefer the 256x128 three-stage kernel (few token rows; gemm_tile_plan below)
 SHORT_TILES = os.environ.get("EDITOR_SHORT_TILES", "1") != "0"      # gemm_tile_rows below (measurement switch)
 # expected live share of a compacted launch's rows for the tile plan below; 0 = off, the default: measured (round 4, same box, twice

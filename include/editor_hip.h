@@ -50,6 +50,10 @@ typedef struct ihipStream_t* editor_stream_t;   /* == hipStream_t */
                                   * last-first - for the consumer of a tensor larger than the Infinity Cache that the previous
                                   * launch has just written (fc2 after fc1's GELU output, fc1's dgrad after fc2's).  Same
                                   * results bit for bit (every tile is computed as before). */
+#define EDITOR_EPI_STAGGER(c) (((c) & 63) << 17) /* OR-able (256x256 ping-pong kernel, more than 256 tiles; ignored otherwise): the
+                                  * first round's workgroups start spread over c * 2048 shader cycles, so that the CUs leave
+                                  * lockstep and one CU's HBM-bound epilogue runs beside the others' K loops.  Same results bit
+                                  * for bit.  The caller picks c ~ one tile period (editor_amd.ops.gemm_stagger). */
 #define EDITOR_EPI_TILE_ROWS(h) ((((h) / 16) & 15) << 12) /* OR-able, h = 208 | 256 (ping-pong kernel, both operands k-major,
                                    * split-K 1, beta 0): rows per output tile.  M = 49 536 token rows x 768 columns are 582 full
                                    * tiles = 2.27 rounds of the 256 CUs; 208-row tiles make it 2.8 rounds of smaller tiles.
