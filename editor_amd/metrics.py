@@ -8,8 +8,8 @@ kernels of csrc/retrieval.hip; there is no CPU fallback.
     R1_mAP_eval / R1_mAP                                           utils/metrics.py:242-283 / 193-239
 Differences, all deliberate: distance matrices stay on the device (pass `.cpu().numpy()` yourself if a numpy array is
 wanted - `compute()` does, as the reference returns one); exactly tied distances rank by gallery index (numpy's default
-argsort leaves their order unspecified); eval_func_msrv does not write the reference's `re.txt` rank-list dump;
-`reranking=True` (utils/reranking.py) is not part of this row and raises.
+argsort leaves their order unspecified); eval_func_msrv does not write the reference's `re.txt` rank-list dump.
+    re_ranking(qf, gf, k1, k2, lambda_value)                       utils/reranking.py:30-101 (R1_mAP_eval(reranking=True), :275-278)
 """
 import numpy as np
 import torch
@@ -58,6 +58,35 @@ def argsort_rows(distmat):
     order = torch.empty(q, g, dtype=torch.int32, device=distmat.device)
     call("editor_rank_sort", distmat, q, g, p, keys, order)
     return order
+
+
+def re_ranking(probFea, galFea, k1, k2, lambda_value, local_distmat=None, only_local=False):
+    """k-reciprocal re-ranking (utils/reranking.py:30-101) on the device: (Q, G) fp32 final distance, a device tensor.
+    Dense N x N stages over all N = Q + G images (csrc/rerank.hip); the float16 storage / arithmetic of the reference is reproduced."""
+    if local_distmat is not None or only_local:
+        raise NotImplementedError("re_ranking: local_distmat / only_local are not used by the path (utils/metrics.py:278)")
+    qf, gf = _rows(probFea), _rows(galFea)
+    if not qf.is_cuda:
+        raise RuntimeError("re_ranking: features must be on the GPU (there is no CPU fallback)")
+    nq, n = qf.shape[0], qf.shape[0] + gf.shape[0]
+    dev = qf.device
+    feat = torch.cat([qf, gf]).contiguous()
+    dist = euclidean_distance(feat, feat)
+    od = torch.empty(n, n, dtype=torch.float32, device=dev)
+    call("editor_rerank_normalise", dist, n, torch.empty(n, dtype=torch.float32, device=dev), od)
+    del dist
+    rank = argsort_rows(od)
+    v = torch.empty(n, n, dtype=torch.float16, device=dev)
+    call("editor_rerank_weights", od, rank, n, int(k1), int(np.around(k1 / 2)), v)
+    if k2 != 1:
+        vq = torch.empty_like(v)
+        call("editor_rerank_expand", v, rank, n, int(k2), vq)
+        v = vq
+    del rank
+    final = torch.empty(nq, n - nq, dtype=torch.float32, device=dev)
+    w16 = int(np.float16(1 - lambda_value).view(np.uint16))
+    call("editor_rerank_final", v, torch.empty_like(v), od, n, nq, w16, float(np.float32(lambda_value)), final)
+    return final
 
 
 def _evaluate(distmat, q_pids, g_pids, q_aux, g_aux, max_rank):
@@ -130,9 +159,11 @@ class R1_mAP_eval():
     def compute(self, vis=0):
         qf, gf, q_pids, g_pids, q_camids, g_camids = self._split()
         if self.reranking:
-            raise NotImplementedError("k-reciprocal re-ranking (utils/reranking.py) is outside row N2")
-        print('=> Computing DistMat with euclidean_distance')
-        distmat = euclidean_distance(qf, gf)
+            print('=> Enter reranking')
+            distmat = re_ranking(qf, gf, k1=50, k2=15, lambda_value=0.3)          # utils/metrics.py:278
+        else:
+            print('=> Computing DistMat with euclidean_distance')
+            distmat = euclidean_distance(qf, gf)
         # the reference's max_rank attribute is not forwarded to eval_func (utils/metrics.py:282): default 50
         cmc, m_ap = eval_func(distmat, q_pids, g_pids, q_camids, g_camids)
         return cmc, m_ap, distmat.cpu().numpy(), self.pids, self.camids, qf, gf

@@ -441,6 +441,22 @@ int editor_rank_metrics(const int* order, const long* q_pids, const long* g_pids
                         int Q, int G, int max_rank, double* ap, int* first_pos, double* totals, int* cmc_counts,
                         editor_stream_t stream);
 
+/* k-reciprocal re-ranking (utils/metrics.py:275-278 -> utils/reranking.py:30-101), dense over ALL N = Q + G images; the caller
+ * (editor_amd.metrics.re_ranking) strings the stages together: editor_distmat_f32(feat, feat) -> _normalise -> editor_rank_sort(od)
+ * -> _weights -> _expand (k2 > 1) -> _final.  V matrices are N x N IEEE-half bit patterns, exactly as the reference stores them.
+ *   _normalise  reranking.py:37-47   colmax[i] = max_k dist[k,i]; od[i,j] = dist[j,i] / colmax[i]
+ *   _weights    reranking.py:51-72   V (zero-filled by the call) <- exp(-od[i, R*(i,k1)]) / sum over the expanded k-reciprocal set;
+ *                                    k1 + 1 <= 64 <= N, k1_half = int(np.around(k1 / 2)) (the caller rounds as numpy does) + 1 <= 32
+ *   _expand     reranking.py:74-79   Vq[i,:] = half(mean over r < k2 of V[rank[i,r],:]) (fp32 accumulation in rank order)
+ *   _final      reranking.py:81-101  Vt = scratch for V^T; final_dist (Q, N-Q) fp32 = half(jaccard * half(1 - lambda)) + od * lambda,
+ *                                    the Jaccard sums in half arithmetic over ascending columns; one_minus_lambda_f16_bits = the bit
+ *                                    pattern of np.float16(1 - lambda), lambda = np.float32(lambda) */
+int editor_rerank_normalise(const float* dist, int N, float* colmax, float* od, editor_stream_t stream);
+int editor_rerank_weights(const float* od, const int* rank, int N, int k1, int k1_half, uint16_t* V, editor_stream_t stream);
+int editor_rerank_expand(const uint16_t* V, const int* rank, int N, int k2, uint16_t* Vq, editor_stream_t stream);
+int editor_rerank_final(const uint16_t* V, uint16_t* Vt, const float* od, int N, int Q, int one_minus_lambda_f16_bits,
+                        float lambda, float* final_dist, editor_stream_t stream);
+
 /* ---- input transform on device (data/datasets/make_dataloader.py:245-253, 55-146) ------------ */
 
 /* RandomHorizontalFlip -> Pad(pad, 0) -> RandomCrop(H,W) -> ToTensor -> Normalize(mean,std) -> RandomErasing('pixel')

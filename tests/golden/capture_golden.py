@@ -455,3 +455,29 @@ def f13_resize(seed=131):
 
 if __name__ == "__main__" and "f13" in sys.argv[1:]:
     f13_resize()
+
+
+def f17_rerank(seed=171):
+    """F17 (row N2, utils/metrics.py:275-278): the reference's k-reciprocal re_ranking (utils/reranking.py) on seeded features,
+    with the evaluator's constants (k1 = 50, k2 = 15, lambda = 0.3) and the paper's (20, 6, 0.3), and R1_mAP_eval(reranking=True)."""
+    np.str = str
+    sys.path.insert(0, "/root/reference")
+    import contextlib, io
+    import utils.metrics as M
+    from utils.reranking import re_ranking
+    nq, ng, d = 48, 208, 64
+    feats, pids, camids, scenes = retrieval_case(seed, nq, ng, d, 12, 4)
+    nrm = F.normalize(feats, dim=1, p=2)
+    out = {}
+    for tag, (k1, k2) in (("a", (50, 15)), ("b", (20, 6)), ("c", (21, 1))):
+        out["final_" + tag] = re_ranking(nrm[:nq], nrm[nq:], k1, k2, 0.3)
+    ev = M.R1_mAP_eval(nq, max_rank=50, feat_norm=True, reranking=True)
+    ev.reset()
+    ev.update((feats, pids, camids))
+    with contextlib.redirect_stdout(io.StringIO()):
+        cmc, m_ap, dist = ev.compute()[:3]
+    save("f17_rerank", seed=seed, cmc=cmc, mAP=np.float64(m_ap), dist=dist, **out)
+
+
+if __name__ == "__main__" and "f17" in sys.argv[1:]:
+    f17_rerank()

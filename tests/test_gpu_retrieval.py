@@ -82,3 +82,70 @@ def test_exact_ties_and_unmatched_queries():
     assert np.array_equal(cmc, cmc_ref) and abs(m_ap - map_ref) < 1e-12
     with pytest.raises(AssertionError):
         metrics.eval_func(dist[:3], pids[:3], pids[nq:], camids[:3], camids[nq:])
+
+
+def _rerank_check(final_dev, final_ref, tol_frac=2e-4):
+    """The device path reproduces the reference's float16 arithmetic step by step; what may differ is the last bit of expf /
+    of the fp32 distance contraction, which the half rounding of a weight hides except on a rounding boundary: at most a
+    `tol_frac` share of entries may differ, each by no more than two half ulps of a Jaccard term (2 * 4.9e-4 * 0.7)."""
+    d = np.abs(final_dev - final_ref)
+    assert d.max() < 1.5e-3, d.max()
+    assert (d > 2e-6).mean() <= tol_frac, (d > 2e-6).mean()
+
+
+def test_rerank_matches_reference_golden():
+    from editor_amd import metrics
+    g = load_golden("f17_rerank")
+    nq = 48
+    feats, pids, camids, scenes = _case(int(g["seed"]), nq, 208, 64, 12, 4)
+    nrm = metrics.normalize(feats.cuda())
+    for tag, (k1, k2) in (("a", (50, 15)), ("b", (20, 6)), ("c", (21, 1))):
+        final = metrics.re_ranking(nrm[:nq], nrm[nq:], k1, k2, 0.3)
+        assert final.dtype == torch.float32 and tuple(final.shape) == (nq, 208)
+        _rerank_check(final.cpu().numpy(), g["final_" + tag])
+    ev = metrics.R1_mAP_eval(nq, max_rank=50, feat_norm=True, reranking=True)
+    ev.reset()
+    for s in range(0, nq + 208, 37):
+        ev.update((feats[s:s + 37].cuda(), pids[s:s + 37], camids[s:s + 37]))
+    cmc, m_ap, dist = ev.compute()[:3]
+    _rerank_check(dist, g["dist"])
+    assert np.abs(cmc - g["cmc"]).max() <= 1.0 / nq + 1e-6 and abs(m_ap - float(g["mAP"])) < 2e-3
+
+
+@pytest.mark.parametrize("nq,ng,d,ids,k1,k2", [(64, 836, 256, 30, 50, 15), (33, 1500, 64, 50, 20, 6), (100, 4200, 128, 80, 50, 15)])
+def test_rerank_stages_match_oracle(nq, ng, d, ids, k1, k2):
+    """Stage by stage against the numpy oracle, each stage fed with the ORACLE's previous stage (so that a last-bit difference in
+    one stage cannot hide behind another): normalised distance, reciprocal weights, local expansion, final distance."""
+    from editor_amd import metrics
+    from editor_amd._lib import call
+    from oracle import reranking_ref as rr
+    feats, pids, camids, scenes = _case(300 + ng, nq, ng, d, ids, 4)
+    nrm = torch.nn.functional.normalize(feats, dim=1, p=2)
+    final_ref, st = rr.re_ranking(nrm[:nq], nrm[nq:], k1, k2, 0.3, stages=True)
+    n = nq + ng
+    dev = torch.device("cuda")
+    # normalised distance from the device distance matrix
+    fd = nrm.cuda()
+    dist = metrics.euclidean_distance(fd, fd)
+    od = torch.empty(n, n, device=dev)
+    call("editor_rerank_normalise", dist, n, torch.empty(n, device=dev), od)
+    assert np.abs(od.cpu().numpy() - st["od"]).max() < 5e-6
+    # weights from the oracle's od and ranking: the set logic is exact, the weights equal up to expf's last bit
+    od_r, rank_r = torch.from_numpy(st["od"]).cuda(), torch.from_numpy(st["rank"]).cuda()
+    v = torch.empty(n, n, dtype=torch.float16, device=dev)
+    call("editor_rerank_weights", od_r, rank_r, n, k1, int(np.around(k1 / 2)), v)
+    vh, vr = v.cpu().numpy(), st["v"]
+    assert np.array_equal(vh != 0, vr != 0)
+    assert (vh != vr).mean() < 1e-6 and np.abs(vh.astype(np.float32) - vr.astype(np.float32)).max() < 2e-3
+    # local expansion and the final distance from the oracle's V: pure half / fp32 arithmetic in a fixed order -> exact
+    v_r = torch.from_numpy(st["v"]).cuda()
+    vq = torch.empty_like(v_r)
+    call("editor_rerank_expand", v_r, rank_r, n, k2, vq)
+    assert np.array_equal(vq.cpu().numpy().view(np.uint16), st["vq"].view(np.uint16))
+    final = torch.empty(nq, ng, device=dev)
+    vq_r = torch.from_numpy(st["vq"]).cuda()
+    call("editor_rerank_final", vq_r, torch.empty_like(vq_r), od_r, n, nq, int(np.float16(1 - 0.3).view(np.uint16)),
+         float(np.float32(0.3)), final)
+    assert np.array_equal(final.cpu().numpy(), final_ref)
+    # end to end
+    _rerank_check(metrics.re_ranking(fd[:nq], fd[nq:], k1, k2, 0.3).cpu().numpy(), final_ref, tol_frac=2e-3)

@@ -145,3 +145,21 @@ def test_f8_retrieval_metrics():
     cmc_r, map_r, _ = mr.eval_func(raw, pids[:nq], pids[nq:], camids[:nq], camids[nq:], 20)
     assert np.array_equal(raw[:8], g["dist_raw"])
     assert np.array_equal(cmc_r, g["cmc_raw"]) and map_r == float(g["mAP_raw"])
+
+
+def test_f17_rerank_oracle_equals_reference():
+    """oracle/reranking_ref.py against the reference's own re_ranking (utils/reranking.py:30-101) and
+    R1_mAP_eval(reranking=True) (utils/metrics.py:275-283): bit for bit, three (k1, k2) settings incl. k2 = 1 and an odd k1."""
+    import numpy as np
+    from oracle import metrics_ref as mr
+    from oracle import reranking_ref as rr
+    g = load_golden("f17_rerank")
+    nq = 48
+    feats, pids, camids, scenes = _retrieval_case(int(g["seed"]), nq, 208, 64, 12, 4)
+    nrm = torch.nn.functional.normalize(feats, dim=1, p=2)
+    for tag, (k1, k2) in (("a", (50, 15)), ("b", (20, 6)), ("c", (21, 1))):
+        final = rr.re_ranking(nrm[:nq], nrm[nq:], k1, k2, 0.3)
+        assert final.dtype == np.float32 and np.array_equal(final, g["final_" + tag]), tag
+    assert np.array_equal(g["dist"], g["final_a"])
+    cmc, m_ap, _ = mr.eval_func(g["dist"], pids[:nq], pids[nq:], camids[:nq], camids[nq:], 50)
+    assert np.array_equal(cmc, g["cmc"]) and m_ap == float(g["mAP"])
