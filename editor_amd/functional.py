@@ -301,8 +301,9 @@ class _SubCtx:
 # that are still cached instead of the ones the producer wrote first.  Same bits (tools/repro_check.py).
 REVERSE_ROWS = ops.EPI_REVERSE_ROWS if os.environ.get("EDITOR_REVERSE_ROWS", "0") == "1" else 0
 # EDITOR_STAGGER_QKV=c (A/B switch, round 5): the qkv forward's first round of workgroups starts spread over c * 2048 cycles
-# (ops.EPI_STAGGER) - the one product the spread helped in tools/stagger_sweep.py (rotating operands: 214 -> 186 us)
-STAGGER_QKV = ops.EPI_STAGGER(int(os.environ.get("EDITOR_STAGGER_QKV", "0")))
+# (ops.EPI_STAGGER) - the one product the spread helped in tools/stagger_sweep.py (rotating operands: 214 -> 186 us; every other
+# product of the path is flat or slower with it).  In the step, same box, twice each: 42.56 / 42.57 -> 42.31 / 42.34 ms replay-only.
+STAGGER_QKV = ops.EPI_STAGGER(int(os.environ.get("EDITOR_STAGGER_QKV", "24")))
 
 # LayerNorm-1's backward of block i+1 also writes what block i's backward STARTS with: the 16-bit, drop-path- and loss-scaled copy of
 # dL/dx (operand of the fc2 dgrad / wgrad) and its column sums (the fc2 bias gradient) - ops.layernorm_bwd_cast, as LayerNorm-2's

@@ -131,7 +131,8 @@ def test_rerank_stages_match_oracle(nq, ng, d, ids, k1, k2):
     call("editor_rerank_normalise", dist, n, torch.empty(n, device=dev), od)
     assert np.abs(od.cpu().numpy() - st["od"]).max() < 5e-6
     # weights from the oracle's od and ranking: the set logic is exact, the weights equal up to expf's last bit
-    od_r, rank_r = torch.from_numpy(st["od"]).cuda(), torch.from_numpy(st["rank"]).cuda()
+    od_r = torch.from_numpy(np.ascontiguousarray(st["od"])).cuda()
+    rank_r = torch.from_numpy(np.ascontiguousarray(st["rank"])).cuda()
     v = torch.empty(n, n, dtype=torch.float16, device=dev)
     call("editor_rerank_weights", od_r, rank_r, n, k1, int(np.around(k1 / 2)), v)
     vh, vr = v.cpu().numpy(), st["v"]
