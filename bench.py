@@ -67,6 +67,17 @@ class _GemmProbe:
     def __init__(self):
         self.calls = []
         self.recording = False
+        self.timing = None          # list while ONE eager step is timed launch by launch, in place (in_situ below)
+
+    def _timed(self, kind, work, fn):
+        """fn() between two HIP events on the CURRENT stream (= the stream the launch goes to: the wrappers run inside whatever
+        stream context the caller set)."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.timing.append((kind, work, e0, e1))
+        return r
 
     def install(self):
         from editor_amd import ops
@@ -81,8 +92,26 @@ class _GemmProbe:
                 # compacted HMA launches are sized for the worst case; count only the live rows (device scalar,
                 # read after the timed region) as algorithmic work
                 probe.calls.append([kind, (m, n, k, kw.get("m_live"), bool(ta)), (a, b, c, m, n, k) + args, dict(kw)])
+            if probe.timing is not None and a.dtype in (torch.bfloat16, torch.float16):
+                ta = args[3] if len(args) > 3 else kw.get("trans_a", 0)
+                tb = args[4] if len(args) > 4 else kw.get("trans_b", 0)
+                kind = kw.get("tag") or ("fwd" if not ta and not tb else ("dgrad" if not ta else "wgrad"))
+                return probe._timed(kind, (m, n, k, kw.get("m_live"), bool(ta)), lambda: probe._orig(a, b, c, m, n, k, *args, **kw))
             return probe._orig(a, b, c, m, n, k, *args, **kw)
         ops.gemm = recorded
+        # the HMA head's per-modality blocks leave as grouped launches (editor_gemm_group): `cnt` products of identical shape
+        self._orig_fgroup = ops.gemm_group
+
+        def recorded_fgroup(reqs):
+            a0, kw0 = reqs[0]
+            m, n, k = a0[3:6]
+            kind = kw0.get("tag") or "fwd"
+            if probe.recording:
+                probe.calls.append([kind, (m * len(reqs), n, k, kw0.get("m_live"), False, len(reqs)), ("fgroup", list(reqs)), {}])
+            if probe.timing is not None:
+                return probe._timed(kind, (m * len(reqs), n, k, kw0.get("m_live"), False, len(reqs)), lambda: probe._orig_fgroup(reqs))
+            return probe._orig_fgroup(reqs)
+        ops.gemm_group = recorded_fgroup
         # split-precision forward products ('f16x2'): algorithmic FLOPs 2 m n k (the three MFMA passes are the price of
         # fp32-class products on the half matrix cores, not extra algorithmic work)
         self._orig_split = ops.gemm_split
@@ -90,6 +119,8 @@ class _GemmProbe:
         def recorded_split(a, b, c, c_lo, m, n, k, **kw):
             if probe.recording:
                 probe.calls.append(["fwd", (m, n, k, kw.get("m_live"), False), ("split", a, b, c, c_lo, m, n, k), dict(kw)])
+            if probe.timing is not None:
+                return probe._timed("fwd", (m, n, k, kw.get("m_live"), False), lambda: probe._orig_split(a, b, c, c_lo, m, n, k, **kw))
             return probe._orig_split(a, b, c, c_lo, m, n, k, **kw)
         ops.gemm_split = recorded_split
         # the four weight gradients of a block as one grouped launch (editor_gemm_wgrad_group)
@@ -100,6 +131,9 @@ class _GemmProbe:
                 nk = sum(j[0].shape[1] * j[1].shape[1] for j in jobs)
                 # (m, n, k) of the probe's FLOP formula 2 m n k with the token rows as the reduction: n * k -> sum_i N_i K_i
                 probe.calls.append(["wgrad", (nk, 1, m, m_live, True), ("group", list(jobs), m, alpha, m_live), {}])
+            if probe.timing is not None:
+                nk = sum(j[0].shape[1] * j[1].shape[1] for j in jobs)
+                return probe._timed("wgrad", (nk, 1, m, m_live, True), lambda: probe._orig_group(jobs, m, alpha, m_live))
             return probe._orig_group(jobs, m, alpha, m_live)
         ops.gemm_wgrad_group = recorded_group
 
@@ -108,25 +142,56 @@ class _GemmProbe:
         ops.gemm = self._orig
         ops.gemm_split = self._orig_split
         ops.gemm_wgrad_group = self._orig_group
+        ops.gemm_group = self._orig_fgroup
 
     def _run(self, args, kw):
         if args and isinstance(args[0], str):
             if args[0] == "group":
                 return self._orig_group(*args[1:], **kw)
+            if args[0] == "fgroup":
+                return self._orig_fgroup(args[1])
             return self._orig_split(*args[1:], **kw)
         return self._orig(*args, **kw)
+
+    @staticmethod
+    def _flops(work):
+        """algorithmic FLOPs 2 m n k of a launch with its LIVE row count (compacted HMA launches are sized for the worst case;
+        a grouped launch of cnt products shares one live count per product)"""
+        m, n, k, live, ta = work[:5]
+        cnt = work[5] if len(work) > 5 else 1
+        if live is not None:
+            rows = int(live.item())
+            if ta:
+                k = min(k, rows)
+            else:
+                m = min(m, rows * cnt)
+        return 2.0 * m * n * k
+
+    def in_situ(self, step_fn):
+        """ONE eager step with every 16-bit GEMM launch (incl. a weight-gradient launch's slab reduction) bracketed by HIP events on
+        the stream it runs on, the weight gradients on the MAIN stream (so that no launch shares the chip with another and the
+        durations add up: the `serial` profile's condition, profiles/rNN_bench_kernel_stats_serial.csv) -> {kind: (flops, ms, n)}.
+        The operands are the step's own, in the cache state the step leaves them in - the figure the rocprofv3 kernel-trace summary
+        of the same command must agree with."""
+        from editor_amd import functional as fn
+        side, fn.WGRAD_SIDE_STREAM = fn.WGRAD_SIDE_STREAM, False
+        self.timing = []
+        try:
+            step_fn()
+            torch.cuda.synchronize()
+        finally:
+            fn.WGRAD_SIDE_STREAM = side
+            rec, self.timing = self.timing, None
+        by_kind = {}
+        for kind, work, e0, e1 in rec:
+            f, ms, n = by_kind.get(kind, (0.0, 0.0, 0))
+            by_kind[kind] = (f + self._flops(work), ms + e0.elapsed_time(e1), n + 1)
+        return by_kind
 
     def replay(self, reps=3):
         by_kind = {}
         for call in self.calls:                            # algorithmic FLOPs with the live row count
-            m, n, k, live, ta = call[1]
-            if live is not None:
-                rows = int(live.item())
-                if ta:
-                    k = min(k, rows)
-                else:
-                    m = min(m, rows)
-            call[1] = 2.0 * m * n * k
+            call[1] = self._flops(call[1])
         for kind in ("fwd", "dgrad", "wgrad"):
             calls = [c for c in self.calls if c[0] == kind]
             if not calls:
@@ -158,6 +223,19 @@ def _event_us(fn, nsets=1, reps=24, warm=None):
     return 1e3 * e0.elapsed_time(e1) / reps
 
 
+def source_hash():
+    """sha1 over the sources a kernel duration depends on (csrc, the host modules): stamped beside a committed rocprof summary by
+    tools/prof.sh, compared by _in_situ_us - a profile of an OLDER tree is not quoted (the GPU box has no .git)."""
+    import glob
+    import hashlib
+    hsh = hashlib.sha1()
+    pats = ("editor_amd/csrc/*.hip", "editor_amd/csrc/*.h", "include/*.h", "editor_amd/*.py", "editor_amd/modeling/*.py")
+    for f in sorted(f for p_ in pats for f in glob.glob(os.path.join(ROOT, p_))):
+        hsh.update(os.path.relpath(f, ROOT).encode())
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def _in_situ_us():
     """{kernel-name prefix: average us} from the newest committed rocprofv3 --kernel-trace --stats summary of the bench command
     with the side stream off (profiles/rNN_bench_kernel_stats_serial.csv): the durations the kernels have INSIDE the step, on
@@ -167,6 +245,9 @@ def _in_situ_us():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_kernel_stats_serial.csv")))
     if not files:
         return None, {}
+    stamp = files[-1][:-4] + ".hash"
+    if not os.path.exists(stamp) or open(stamp).read().strip() != source_hash():
+        return os.path.relpath(files[-1], ROOT) + " (NOT quoted: the profile was taken on a different source tree)", {}
     out = {}
     try:
         for r in csv.DictReader(open(files[-1])):
@@ -317,7 +398,12 @@ def modes_block(args, cfg, cams, own_value, own_eval=None):
             except Exception as e:                       # a mode that fails to run is reported, not hidden
                 entry["value"] = None
                 entry["error"] = type(e).__name__
+        # BASELINE.json north_star: "bit-exactly for index/top-k results and within 1e-3 rel for bf16 features"
+        entry["meets_north_star"] = {"indices": bool(entry["index_bit_identical"]), "features": entry["cls4t_rel_err"] <= 1e-3}
         out[dt] = entry
+    ok = [(out[dt]["value"], dt) for dt in modes if out[dt].get("value") and all(out[dt]["meets_north_star"].values())]
+    out["value_at_parity"] = None if not ok else {"mode": max(ok)[1], "value": max(ok)[0], "what": "fastest mode whose selected-token "
+                                                  "indices are bit-identical to the oracle's AND whose features are within 1e-3"}
     return out
 
 
@@ -816,6 +902,9 @@ def main():
         replay_only = {"value": round(b * args.steps / el2, 2), "ms_per_step": round(1e3 * el2 / args.steps, 3),
                        "what": "same K steps with the inputs resident in HBM and one synchronisation at the end"}
     probe.recording = False
+    situ = None
+    if rank == 0 and world == 1 and not force_ddp and not args.no_replay and args.dtype != "f32":
+        situ = probe.in_situ(step)                        # one more (untimed) eager step, every GEMM launch timed in place
     probe.remove()
     lossv = float(loss.detach())
     eval_block = None
@@ -827,7 +916,15 @@ def main():
         flops = sum(v[0] for v in kinds.values())
         ms = sum(v[1] for v in kinds.values())
         launches = sum(v[2] for v in kinds.values())
-        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else None        # (--no-replay: not measured, not zero)
+        achieved_replay = flops / (ms * 1e-3) / 1e12 if ms > 0 else None  # (--no-replay: not measured, not zero)
+        # `achieved` / `frac` = the family INSIDE the step (launch-by-launch HIP events of one eager step, weight gradients on the main
+        # stream): what the rocprofv3 summary of the same command shows (profiles/rNN_bench_kernel_stats_serial.csv).
+        # The back-to-back replay of the same launches (no other kernel in between: warmer caches) stays beside it as `*_replay`.
+        if situ:
+            s_flops, s_ms = sum(v[0] for v in situ.values()), sum(v[1] for v in situ.values())
+            achieved = s_flops / (s_ms * 1e-3) / 1e12 if s_ms > 0 else None
+        else:
+            s_flops, s_ms, achieved = flops, ms, achieved_replay
         ms_step = 1e3 * elapsed / args.steps
         arch = cfg.MODEL.TRANSFORMER_TYPE.replace("_patch16_224", "").replace("vit_", "ViT-").replace("base", "B").replace("large", "L")
         # `traffic` / `alg_bytes_per_step` are NOT measured in this run: PMC counters need their own rocprofv3 passes
@@ -850,8 +947,15 @@ def main():
                 "kernel": "16-bit GEMM family: gemm_bf16_pp_kernel (256x256x64 ping-pong; fwd, dgrad, and wgrad as one round of "
                           "split-K workgroups + slab reduction), v_mfma_f32_16x16x32_" + ("bf16" if args.dtype == "bf16" else "f16") +
                           ("; forward products as split-precision half pairs (3 MFMA passes per algorithmic FLOP)" if args.dtype.startswith("f16x2") else ""),
-                "launches_per_step": launches, "gemm_ms_per_step": round(ms, 3),
-                "alg_tflop_per_step": round(flops / 1e12, 2),
+                "achieved_source": "in situ: HIP events around every 16-bit GEMM launch of one eager step" if situ else
+                                   "back-to-back replay of the step's recorded GEMM launches",
+                "launches_per_step": sum(v[2] for v in situ.values()) if situ else launches,
+                "gemm_ms_per_step": round(s_ms, 3), "alg_tflop_per_step": round(s_flops / 1e12, 2),
+                "achieved_replay": None if achieved_replay is None else round(achieved_replay, 2),
+                "frac_replay": None if achieved_replay is None else round(achieved_replay / PEAK_TFLOPS, 4),
+                "gemm_ms_per_step_replay": round(ms, 3),
+                "by_kind_in_situ": None if not situ else {k: {"tflops": round(f / (m_ * 1e-3) / 1e12, 1), "ms_per_step": round(m_, 3),
+                                                              "launches": n} for k, (f, m_, n) in situ.items()},
                 "alg_bytes_per_step": None if traffic is None else traffic.get("gemm_alg_bytes_per_step"),
                 "by_kind": {k: {"tflops": round(f / (m_ * 1e-3) / 1e12, 1), "ms_per_step": round(m_, 3), "launches": n}
                             for k, (f, m_, n) in kinds.items()}}
@@ -911,6 +1015,7 @@ def main():
             out["replay_only"] = replay_only
         if world == 1 and not args.no_modes and not force_ddp and args.preset in ("RGBNT201", "RGBNT100", "MSVR310"):
             out["modes"] = modes_block(args, cfg, cams, out["value"], eval_block)
+            out["value_at_parity"] = out["modes"].pop("value_at_parity")
         if world == 1 and not args.no_cpu_baseline and not force_ddp:
             out["cpu_baseline"] = cpu_baseline(model, cfg, cams, b, args.cpu_iters)
             if args.preset == "RGBNT201" and b == 128:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box, via gpurun): tools/final_measure.sh <round-tag>   -> gpurun_out/<tag>_*  (copy what is to be judged into profiles/)
-tag=${1:-r04}
+tag=${1:-r05}
 mkdir -p gpurun_out
 python bench.py 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_line_default.json
 python bench.py --dtype f16x2 --no-cpu-baseline --no-modes 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_line_f16x2.json
@@ -23,6 +23,7 @@ bash tools/prof.sh ${tag} --no-replay --no-h2d --no-modes --no-eval > gpurun_out
 cp gpurun_out/prof_${tag}/kernel_stats.csv gpurun_out/${tag}_bench_kernel_stats.csv
 EDITOR_WGRAD_STREAM=0 bash tools/prof.sh ${tag}s --no-replay --no-h2d --no-modes --no-eval > gpurun_out/${tag}_prof_serial.txt 2>&1
 cp gpurun_out/prof_${tag}s/kernel_stats.csv gpurun_out/${tag}_bench_kernel_stats_serial.csv
+cp gpurun_out/prof_${tag}s/kernel_stats.hash gpurun_out/${tag}_bench_kernel_stats_serial.hash
 EDITOR_WGRAD_STREAM=0 bash tools/prof.sh ${tag}x2 --dtype f16x2 --no-replay --no-h2d --no-modes --no-eval > gpurun_out/${tag}_prof_f16x2.txt 2>&1
 cp gpurun_out/prof_${tag}x2/kernel_stats.csv gpurun_out/${tag}_f16x2_kernel_stats_serial.csv
 bash tools/launch_count.sh ${tag} > /dev/null 2>&1

@@ -7,6 +7,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -
 tail -1 /tmp/bench_$tag.log | cut -c1-1400
 mkdir -p gpurun_out/prof_$tag
 cp /tmp/prof_$tag/${tag}_kernel_stats.csv gpurun_out/prof_$tag/kernel_stats.csv
+python -c "import bench; print(bench.source_hash())" > gpurun_out/prof_$tag/kernel_stats.hash
 python - <<PY
 import csv
 rows=list(csv.DictReader(open("/tmp/prof_$tag/${tag}_kernel_stats.csv")))
