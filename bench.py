@@ -585,6 +585,21 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+def _rank_tails(logdir, nlines=25):
+    """the last lines of every rank's stderr.log under torch.distributed.run's --log-dir, rank by rank"""
+    import glob
+    files = sorted(glob.glob(os.path.join(logdir, "**", "stderr.log"), recursive=True))
+    for f in files:
+        try:
+            tail = open(f, errors="replace").read().splitlines()[-nlines:]
+        except OSError:
+            continue
+        sys.stderr.write(f"---- {os.path.relpath(f, logdir)}\n" + "\n".join(tail) + "\n")
+    if not files:
+        sys.stderr.write(f"(no rank logs under {logdir})\n")
+    sys.stderr.flush()
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves, one process per GPU, exactly as the
     reference is started (train_net.py:45-46,63-64: torch.distributed.launch + NCCL) - re-exec this file under
@@ -604,8 +619,12 @@ def launch_ranks(n, argv):
     if n == 1:
         env["EDITOR_FORCE_DDP"] = "1"
     child_argv = [a for a in argv if a != "--spawn"]
+    import tempfile
+    logdir = tempfile.mkdtemp(prefix="editor_bench_ranks_")
+    # --tee 2: every rank's stderr goes to the console AND to <logdir>/.../stderr.log, so that a failed run can show each rank's
+    # last lines separately; stdout stays a plain pipe (the launcher prefixes teed lines with "[default<rank>]:") (first contact with an 8-GPU node must be diagnosable from the driver's log alone)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(__file__)] + child_argv
+           "--master-port", str(_free_port()), "--log-dir", logdir, "--tee", "2", os.path.abspath(__file__)] + child_argv
     sys.stderr.write("[bench] launching " + " ".join(cmd[1:]) + "\n")
     sys.stderr.flush()
     timeout = float(os.environ.get("EDITOR_BENCH_LAUNCH_TIMEOUT", "3000"))
@@ -616,15 +635,19 @@ def launch_ranks(n, argv):
         import signal
         os.killpg(proc.pid, signal.SIGKILL)                # the launcher AND its ranks (own session), nothing else
         stdout, _ = proc.communicate()
-        sys.stderr.write(f"[bench] the {n}-rank run did not finish within {timeout:.0f} s; killed\n")
+        sys.stderr.write(f"[bench] the {n}-rank run did not finish within {timeout:.0f} s; killed; per-rank stderr tails:\n")
+        _rank_tails(logdir)
         sys.stdout.write(stdout)
         return 124
-    lines = [ln for ln in stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
-    other = [ln for ln in stdout.splitlines() if not (ln.startswith("{") and '"metric"' in ln)]
+    import re
+    all_lines = [re.sub(r"^\[[a-z]+\d+\]:", "", ln) for ln in stdout.splitlines()]      # (a teed stdout would carry the rank prefix)
+    lines = [ln for ln in all_lines if ln.startswith("{") and '"metric"' in ln]
+    other = [ln for ln in all_lines if not (ln.startswith("{") and '"metric"' in ln)]
     if other:
         sys.stderr.write("\n".join(other[-40:]) + "\n")  # RCCL banners etc.: not on stdout, the JSON line is the only line there
     if proc.returncode != 0 or not lines:
-        sys.stderr.write(f"[bench] the {n}-rank run failed (rc={proc.returncode}, {len(lines)} JSON line(s))\n")
+        sys.stderr.write(f"[bench] the {n}-rank run failed (rc={proc.returncode}, {len(lines)} JSON line(s)); per-rank stderr tails:\n")
+        _rank_tails(logdir)
         return proc.returncode or 1
     try:
         j = json.loads(lines[-1])
@@ -704,7 +727,26 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")              # RCCL's own diagnosis of a failed ring on stderr, nothing when it works
+        import datetime
+        t_init = time.perf_counter()
+        try:
+            # 120 s: a rank that never arrives (wrong GPU visibility, a port in use, IPC mode) must fail with a message, not sit
+            # in the store's default half-hour wait
+            dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev,
+                                    timeout=datetime.timedelta(seconds=float(os.environ.get("EDITOR_BENCH_INIT_TIMEOUT", "120"))))
+            probe_t = torch.ones(1, device=dev)
+            dist.all_reduce(probe_t)                              # the first collective builds the ring: fail HERE, with context
+            torch.cuda.synchronize()
+            assert int(probe_t.item()) == world, f"all-reduce of ones over {world} rank(s) gave {probe_t.item()}"
+        except Exception as e:
+            sys.stderr.write(f"[bench] rank {rank}/{world} (GPU {local}, MASTER {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}, "
+                             f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}) could not join the RCCL group "
+                             f"after {time.perf_counter() - t_init:.0f} s: {type(e).__name__}: {e}\n")
+            sys.stderr.flush()
+            raise
+        if rank == 0:
+            sys.stderr.write(f"[bench] RCCL group of {world} rank(s) up in {time.perf_counter() - t_init:.1f} s\n")
 
     from editor_amd import config, losses, synth
     from editor_amd.modeling import make_model
@@ -904,7 +946,13 @@ def main():
     probe.recording = False
     situ = None
     if rank == 0 and world == 1 and not force_ddp and not args.no_replay and args.dtype != "f32":
-        situ = probe.in_situ(step)                        # one more (untimed) eager step, every GEMM launch timed in place
+        if graph is not None:                             # (eager steps of a capturing process stay off the default stream, see above)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                situ = probe.in_situ(step)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            situ = probe.in_situ(step)                    # one more (untimed) eager step, every GEMM launch timed in place
     probe.remove()
     lossv = float(loss.detach())
     eval_block = None
@@ -996,7 +1044,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.preset} {nmod}-modal {arch}/16 {h}x{w}, batch {b}/GPU, fwd+bwd+SGD step, "
                                    f"drop_path 0.1, SFTS+HMA HIP kernels" + (", activation-light blocks" if args.act_light else ""),
-                       "global_batch": world * b, "parallelism": f"dp{world}", "loss": round(lossv, 4),
+                       "global_batch": world * b, "parallelism": f"dp{world}", "loss": round(lossv, 4), "graph": graph is not None,
                        "launch": ("hipGraph replay" + (" incl. RCCL bucket all-reduces (overlapped with backward)" if use_dist else ""))
                        if graph is not None else ("eager" + (", RCCL bucket all-reduces overlapped with backward" if use_dist else "")),
                        "grad_buckets": None if buckets is None else buckets.describe()},

@@ -92,3 +92,25 @@ def test_rank_process_checks_its_world_size(bench, monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "WORLD_SIZE=2" in str(e.value)
+
+
+def test_launcher_failure_shows_every_ranks_stderr_tail(bench, monkeypatch, capsys, tmp_path):
+    """a failed N-rank run prints each rank's last stderr lines (torch.distributed.run --log-dir / --tee 2),
+    and a rank-prefixed JSON line (teed stdout) is still recognised."""
+    import tempfile
+    seen = {}
+    _patch(monkeypatch, bench, 8, "", 1, seen)
+    for r in range(2):
+        d = tmp_path / "run_x" / "attempt_0" / str(r)
+        d.mkdir(parents=True)
+        (d / "stderr.log").write_text("".join("rank %d line %d\n" % (r, i) for i in range(40)))
+    monkeypatch.setattr(tempfile, "mkdtemp", lambda prefix="": str(tmp_path))
+    assert bench.launch_ranks(2, ["--gpus", "2"]) != 0
+    cmd = seen["cmd"]
+    assert cmd[cmd.index("--log-dir") + 1] == str(tmp_path) and cmd[cmd.index("--tee") + 1] == "2"
+    err = capsys.readouterr().err
+    assert "rank 0 line 39" in err and "rank 1 line 39" in err and "rank 0 line 3\n" not in err
+    seen = {}
+    _patch(monkeypatch, bench, 8, "[default0]:" + _line(2) + "\n", 0, seen)
+    assert bench.launch_ranks(2, ["--gpus", "2"]) == 0
+    assert capsys.readouterr().out.strip() == _line(2)
