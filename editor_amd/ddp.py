@@ -353,6 +353,8 @@ class GradBuckets:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             self._tail = (flat, views, live, key)
+            self._tail_bucket = dict(flat=flat, work=None)        # persistent, like the block buckets: its 16-bit wire twin is
+                                                                  # allocated ONCE (a fresh dict per step re-allocated it)
         if capturing and self._tail[3] != key:
             # the captured graph would copy from the EAGER step's tail set: parameters that have since gained / lost a gradient
             # would be exchanged from stale or missing tensors
@@ -362,8 +364,7 @@ class GradBuckets:
         flat, views, live, _ = self._tail
         if live:
             torch._foreach_copy_(views, [p.grad for p in live])
-            tail = dict(flat=flat, work=None)
-            self._launch(tail)
+            self._launch(self._tail_bucket)
         inv = 1.0 / self.world
         if getattr(self, "_comm", None) is not None:
             torch.cuda.current_stream(self._comm.device).wait_stream(self._comm)     # (re-joins the issuing stream: capture)
