@@ -52,6 +52,9 @@ constexpr int TILE_BYTES = 128 * 64 * 2;          // 16 KiB per operand tile per
 #ifndef EDITOR_GEMM_GM
 #define EDITOR_GEMM_GM 4
 #endif
+#ifndef EDITOR_PP_PHASES
+#define EDITOR_PP_PHASES 0      // phases per K-tile of the ping-pong kernel: 4 (16-MFMA clusters), 2 (32-MFMA clusters, round 5), 0 = per
+#endif                          // operand layout as measured (tools/gemm_alt_ab.py): 2 for the weight gradients, 4 for everything else
 
 struct GemmB16Args {
     const bf16_t* A; const bf16_t* B; void* C;
@@ -982,6 +985,10 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
                         mfma16<F16>(fbv[j][s], fa[i][s], acc[mi * 4 + i][nj * 2 + j]);
     };
     auto dma2 = [&](const char* src, const uint32_t (&vo)[2], char* unit) {
+        // The K-tile's source position stays an OPAQUE scalar pair: left visible, loop strength reduction folds it into the per-lane
+        // offsets - eight 64-bit VGPR pointer pairs carried and incremented through the K loop (16 registers, eight v_lshl_add_u64 per
+        // K-tile) and the `off` addressing form - instead of global_load_lds_dwordx4 v_offset32, s[base:base+1].
+        asm volatile("" : "+s"(src));
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + vo[j]),
@@ -1022,7 +1029,7 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
     using c4 = std::integral_constant<int, 4>;
     // FG: live fragments of this wave group (4 in A0 + FG-4 in A1).  (always_inline: an out-of-line copy would take the
     // accumulators by reference, i.e. through scratch memory)
-    auto ktile = [&](int t, auto BUF, auto FG) __attribute__((always_inline)) {
+    auto ktile4 = [&](int t, auto BUF, auto FG) __attribute__((always_inline)) {
         using B = decltype(BUF);
         using L1 = std::integral_constant<int, decltype(FG)::value - 4>;
         // P1
@@ -1055,6 +1062,60 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
         PP_BAR();
         PP_MMA(fb0, c1, c0, L1);
         PP_BAR();
+    };
+    // TWO phases per K-tile (round 5): 32-MFMA clusters, four barrier intervals per K-tile instead of eight.  The four-phase form above
+    // spends ~335 cycles per interval against a 16-MFMA cluster's 256: the other group's fragment reads + lgkmcnt(0) + its two LDS-DMA
+    // issues take longer than the cluster they are meant to hide behind (profiles/r04_gemm_bound_probe.txt: MFMAs + barriers 1.02 us per
+    // K-tile, complete 1.35).  Here a wave runs
+    //   R1: read B0, B1, A0 (16 x ds_read_b128)   DMA A1(t+1)                      | the other group: MFMA A1 x B0, A1 x B1 of its tile
+    //   M1: MFMA A0 x B0, A0 x B1 (32)
+    //   R2: read A1 (8, over A0's registers)       DMA A0(t+2), B0(t+2), B1(t+2)   | the other group: MFMA A0 x B0, A0 x B1
+    //   M2: MFMA A1 x B0, A1 x B1 (32)
+    // with the same units, buffers and register budget (fa is overwritten once M1 is done).  Unit lifetimes (slots = barrier intervals,
+    // group 0 starts tile t at slot 0, group 1 at slot 1): A0 / B0 / B1(t) are read in slots 0 and 1, refilled for t+2 from slot 2 on
+    // (both groups' R2(t)), read again in slot 8; A1(t) is read in slots 2 and 3, refilled from slot 4 on (R1(t+1)), read in slot 10.
+    // A unit's pieces are awaited (own vmcnt, then the barrier) one full phase before group 0 reads it: A1(t) at the end of R1(t),
+    // A0 / B0 / B1(t+1) at the end of R2(t) - always with the newest eight (six for a wave that stages no A1 rows) still in flight.
+    // Every accumulator still receives one MFMA chain per K-tile in the same k order: bit-identical to the four-phase form.
+    // Measured (profiles/r05_gemm_alt_ab.txt, M = 49 536): 2 - 10 % SLOWER than four phases on the forward / dgrad products (k-major
+    // operands: its R2 carries six LDS-DMA issues, ~150 cycles each beside fragment reads, and outlasts the 512-cycle cluster), 3 - 4 %
+    // FASTER on the weight gradients (both operands through ds_read_b64_tr_b16: twice the fragment-read instructions per phase, which
+    // the longer clusters cover) - so the choreography follows the layout.
+    auto ktile2 = [&](int t, auto BUF, auto FG) __attribute__((always_inline)) {
+        using B = decltype(BUF);
+        using L1 = std::integral_constant<int, decltype(FG)::value - 4>;
+        const bool counted = t + 2 < nk;
+        // R1
+        if (!PP_ABL(4)) { read_b(fb0, std::integral_constant<int, UB0>{}, B{}); read_b(fb1, std::integral_constant<int, UB1>{}, B{}); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!PP_ABL(4)) read_a(std::integral_constant<int, UA0>{}, B{}, c4{});
+        if (t + 1 < nk && !PP_ABL(1)) stage_a(t + 1, 1);
+        if (counted) { if (a1_live) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_WAIT_LGKM0(); PP_BAR();
+        // M1
+        PP_MMA(fb0, c0, c0, c4);
+        PP_MMA(fb1, c0, c1, c4);
+        PP_BAR();
+        // R2
+        if (!PP_ABL(4)) read_a(std::integral_constant<int, UA1>{}, B{}, L1{});
+        if (counted && !PP_ABL(1)) {     // (one unit at a time: six 64-bit source addresses computed up front cost 8 more registers)
+            __builtin_amdgcn_sched_barrier(0); stage_a(t + 2, 0);
+            __builtin_amdgcn_sched_barrier(0); stage_b(t + 2, 0);
+            __builtin_amdgcn_sched_barrier(0); stage_b(t + 2, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (counted) { if (a1_live) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_WAIT_LGKM0(); PP_BAR();
+        // M2
+        PP_MMA(fb0, c1, c0, L1);
+        PP_MMA(fb1, c1, c1, L1);
+        PP_BAR();
+    };
+    constexpr bool kTwoPhase = EDITOR_PP_PHASES == 2 || (EDITOR_PP_PHASES == 0 && !A_KMAJOR && !B_KMAJOR);
+    auto ktile = [&](int t, auto BUF, auto FG) __attribute__((always_inline)) {
+        if constexpr (kTwoPhase) ktile2(t, BUF, FG); else ktile4(t, BUF, FG);
     };
 
     if (nk > 0) {

@@ -39,7 +39,22 @@ def use_trace_build():
         lib._fn[name] = fn
 
 
+def use_alt_build():
+    """GEMM_ALT=1: route the two 16-bit GEMM entry points to libeditor_gemm_alt.so (the other K-tile choreography, editor_amd/build.py)."""
+    from editor_amd import _lib, build
+    import ctypes
+    tr = ctypes.CDLL(build.LIB_ALT)
+    lib = _lib.lib()
+    for name in ("editor_gemm_bf16", "editor_gemm_f16"):
+        fn = getattr(tr, name)
+        fn.argtypes = lib.protos[name]
+        fn.restype = ctypes.c_int
+        lib._fn[name] = fn
+
+
 def main():
+    if os.environ.get("GEMM_ALT") == "1":
+        use_alt_build()
     if any(os.environ.get(k) for k in ("EDITOR_GEMM_TRACE", "EDITOR_GEMM_PP", "EDITOR_GEMM_PP_STAGED")):
         use_trace_build()
     m = int(os.environ.get("GEMM_M", 3 * 128 * 129))
