@@ -600,221 +600,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// FUSED backward (dense, unmasked, NT <= 10: the backbone's 129-token sequences).  The two passes above each recompute
-// S, P = exp2(S - lse), dP and dS - at head width 64 that VALU + transcendental work, not the matrix core, is what bounds
-// them.  Here it is done ONCE, in the key-owner form of the DKV pass, and dS reaches the dQ product through LDS:
-//   LDS: Q | dO | K images, lse / delta of every query, a dS chunk [keys][32 queries], a dQ staging tile  = 77 KiB at NT = 10
-//        -> two workgroups per CU (the round-2 version kept the whole dS matrix and V: 136 KiB, one workgroup, 241 vs 231 us)
-//   NT/2 wavefronts, wave w owns key tiles 2w and 2w+1 (K fragments from the K image, V fragments from global);
-//   per pair of query tiles (32 queries):
-//     A  every wave: S = Q K^T, dP = dO V^T (the Q / dO fragments serve both of its key tiles), P, dS; dV^T += dO^T P,
-//        dK^T += Q^T dS; dS (16-bit, the operand the dQ pass would have packed) -> dS chunk rows of its keys
-//     -- barrier --
-//     B  the 8 (query tile, 16 head columns) units of dQ^T = K^T dS^T go round the waves: 5 MFMAs each, K^T through
-//        ds_read_b64_tr_b16 from the K image, dS^T through the same transposed read from the chunk; scaled, packed, parked
-//        in the dQ staging tile
-//     -- barrier --  the 32 finished dQ rows leave as full 128-byte rows
-// Same operands, same instruction sequence per element and the same summation orders as the two-pass form: bit-identical
-// results (tests/test_gpu_kernels.py).  delta = rowsum(dO * O) is computed up front with the dQ pass's own expression.
-// MEASURED AND NOT THE DEFAULT (round 3; T = 129, 4 608 workgroups): 266 us against 222 us for the two passes (the first
-// build, with 18 spilled registers whose reloads sat behind the dQ stores: 308 us).  PMC (tools/attn_pmc.sh): 17 % fewer
-// wave-cycles than the two passes together (1.95e8 vs 2.34e8) but 10 resident waves per CU instead of 12, every pair of
-// query tiles fenced by two barriers, waves waiting 48 % of their cycles and issuing VALU 19 %: with 2.5 waves per SIMD
-// the kernel is bound by exposed LDS / MFMA / exp latency, not by the arithmetic it saves.  The two-pass waves never
-// meet a barrier after the image load.  Kept as the worked-out answer to "fuse it with <= 80 KB of LDS" (VERDICT r2 item 3).
-// ---------------------------------------------------------------------------------------------------------
-#if ATTN_HD == 64                              // (the fused form exists for the backbone's 64-wide heads only)
-constexpr int FB_DS_ROW = 72;                  // bytes per key row of the dS chunk: 32 queries x 2 B + 8 (rows shift by 18 banks)
-constexpr int FB_DQ_ROW = 144;                 // bytes per query row of the dQ staging tile: 64 x 2 B + 16
-template <int NT> constexpr size_t fused_bwd_lds()
-{
-    return (size_t)3 * NT * 16 * ROWB + (size_t)2 * NT * 16 * sizeof(float) + (size_t)NT * 16 * FB_DS_ROW + 32 * FB_DQ_ROW;
-}
-
-template <int NT, bool F16>
-__global__ __launch_bounds__(NT / 2 * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_fused_kernel(AttnArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int Tp = NT * 16, NW = NT / 2, NP = NT / 2;
-    static_assert(NT % 2 == 0 && NT <= 10, "LDS budget (two workgroups per CU) and the final staging area assume NT <= 10");
-    static_assert(NT * 16 * FB_DS_ROW + 32 * FB_DQ_ROW >= NW * STG_BYTES, "dK / dV leave through the dS chunk + dQ tile area");
-    char* qimg = smem;
-    char* doimg = smem + Tp * ROWB;
-    char* kimg = smem + 2 * Tp * ROWB;
-    float* lse_s = reinterpret_cast<float*>(smem + 3 * Tp * ROWB);
-    float* dl_s = lse_s + Tp;
-    char* dsimg = reinterpret_cast<char*>(dl_s + Tp);
-    char* dqstg = dsimg + Tp * FB_DS_ROW;
-    const int D = a.heads * HD;
-    const int b = blockIdx.x / a.heads, hh = blockIdx.x % a.heads;
-    const long ld = 3L * D;
-    const long row0 = (long)b * a.T;
-    const int T = a.T;
-    const bf16_t* qbase = a.qkv + row0 * ld + hh * HD;
-    const bf16_t* dobase = a.dout + row0 * D + hh * HD;
-    load_image(qimg, qbase, ld, T, Tp);
-    load_image(doimg, dobase, D, T, Tp);
-    load_image(kimg, qbase + D, ld, T, Tp);
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int li = lane & 15, lg = lane >> 4;
-    // own side: V fragments of the wave's two key tiles (zeros beyond the sequence end)
-    const int k0 = w * 32;
-    const int ntl = (k0 + 16 < T) ? 2 : 1;                                  // (its second tile may lie wholly beyond the end)
-    short8_t vf[2][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) vf[j][s] = frag_own(qbase + 2 * D, ld, k0 + 16 * j, T, s, lane);
-    // lse and delta of every query (the dQ pass's expression and summation order)
-    {
-        const bf16_t* obase = a.out_fwd + row0 * D + hh * HD;
-        const long row_idx0 = (long)hh * a.Mtot + row0;
-        for (int q0 = w * 16; q0 < Tp; q0 += NW * 16) {
-            const int q = q0 + li;
-            float dl = 0.f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const short8_t dof = frag_own(dobase, D, q0, T, s, lane);
-                const short8_t of = frag_own(obase, D, q0, T, s, lane);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dl += H16<F16>::to_f32((uint16_t)dof[e]) * H16<F16>::to_f32((uint16_t)of[e]);
-            }
-            dl = group_sum(dl);
-            if (lg == 0) {
-                lse_s[q] = q < T ? a.lse[row_idx0 + q] : INFINITY;
-                dl_s[q] = q < T ? dl : 0.f;
-            }
-        }
-    }
-    // dS rows of keys nobody owns (a wholly invalid last tile) must read as zeros in the dQ product
-    for (int i = threadIdx.x; i < Tp * FB_DS_ROW / 8; i += NW * 64) reinterpret_cast<uint2*>(dsimg)[i] = make_uint2(0u, 0u);
-    images_ready();
-
-    const float sc = a.scale * kLog2e;
-    float4_t dv[2][4], dk[2][4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int dt = 0; dt < ND; ++dt) { dv[j][dt] = float4_t{0.f, 0.f, 0.f, 0.f}; dk[j][dt] = dv[j][dt]; }
-    // (K image rows beyond the end are copies of the last row, see load_image: an invalid key's P and dS are forced to zero -
-    //  the wave-uniform `edge` keeps the compare / select off the tiles that cannot hold one)
-    typedef __attribute__((address_space(3))) short4_t* lds_p;
-
-#pragma unroll 1
-    for (int u2 = 0; u2 < NP; ++u2) {
-        // ---- A: key-owner work on query tiles 2 u2, 2 u2 + 1 ---------------------------------------------------------
-        // (one query tile at a time, its Q / dO fragments serving both key tiles; the own K fragments come from the image
-        //  at each use: held across the loop they put the kernel over the 168 registers of three waves per SIMD)
-        uint2 pk[2][2], dsk[2][2];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            short8_t fq[2], fd[2];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                fq[s] = frag_k(qimg, (2 * u2 + half) * 16, s, lane);
-                fd[s] = frag_k(doimg, (2 * u2 + half) * 16, s, lane);
-            }
-            const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * (2 * u2 + half) + 4 * lg);
-            const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 16 * (2 * u2 + half) + 4 * lg);
-            const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (j < ntl) {
-                    const int key = k0 + 16 * j + li;
-                    const bool edge = k0 + 16 * j + 16 > T;                 // wave-uniform
-                    const bool kok = key < T;
-                    float4_t s_ = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        s_ = mfma16<F16>(fq[s], frag_k(kimg, k0 + 16 * j, s, lane), s_);
-                        dp = mfma16<F16>(fd[s], vf[j][s], dp);
-                    }
-                    float pv[4], dsv[4];
-                    if (edge) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float pp = __builtin_amdgcn_exp2f(kok ? s_[r] * sc - lq[r] : -INFINITY);
-                            pv[r] = pp;
-                            dsv[r] = kok ? pp * (dp[r] - dq[r]) : 0.f;
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float pp = __builtin_amdgcn_exp2f(s_[r] * sc - lq[r]);              // lse == +inf -> 0
-                            pv[r] = pp;
-                            dsv[r] = pp * (dp[r] - dq[r]);
-                        }
-                    }
-                    pk[j][half] = pack4<F16>(pv[0], pv[1], pv[2], pv[3]);
-                    dsk[j][half] = pack4<F16>(dsv[0], dsv[1], dsv[2], dsv[3]);
-                    *reinterpret_cast<uint2*>(dsimg + (k0 + 16 * j + li) * FB_DS_ROW + (half * 16 + 4 * lg) * 2) = dsk[j][half];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        short8_t pf[2], df[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (j < ntl) { pf[j] = join(pk[j][0], pk[j][1]); df[j] = join(dsk[j][0], dsk[j][1]); }
-#pragma unroll
-        for (int dt = 0; dt < ND; ++dt) {
-            const short8_t tdo = frag_t(doimg, u2, dt, lane), tq = frag_t(qimg, u2, dt, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if (j < ntl) {
-                    dv[j][dt] = mfma16<F16>(tdo, pf[j], dv[j][dt]);
-                    dk[j][dt] = mfma16<F16>(tq, df[j], dk[j][dt]);
-                }
-            if (dt & 1) __builtin_amdgcn_sched_barrier(0);      // (all eight transposed fragments up front cost 32 registers)
-        }
-        __syncthreads();
-        // ---- B: dQ^T tiles of these 32 queries -----------------------------------------------------------------------
-        // (lane coordinates re-derived from an opaque copy: hoisted out of the pair loop, B's and the row store's per-lane
-        //  offsets stay live through A and spill - and every scratch reload is an s_waitcnt vmcnt(0) behind the dQ stores)
-        int lb = lane;
-        asm volatile("" : "+v"(lb));
-        const int lib = lb & 15, lgb = lb >> 4;
-        for (int unit = w; unit < 8; unit += NW) {
-            const int h = unit >> 2, dt = unit & 3;
-            float4_t o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s2 = 0; s2 < NP; ++s2) {
-                const int r0 = 32 * s2 + 4 * lgb + (lib >> 2);
-                const int colb = (h * 16 + (lib & 3) * 4) * 2;
-                const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(dsimg + r0 * FB_DS_ROW + colb));
-                const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(dsimg + (r0 + 16) * FB_DS_ROW + colb));
-                o = mfma16<F16>(frag_t(kimg, s2, dt, lb), __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), o);
-            }
-            o *= a.scale;
-            *reinterpret_cast<uint2*>(dqstg + (h * 16 + lib) * FB_DQ_ROW + (dt * 16 + 4 * lgb) * 2) = pack4<F16>(o[0], o[1], o[2], o[3]);
-        }
-        __syncthreads();
-        int tb = threadIdx.x;
-        asm volatile("" : "+v"(tb));
-        if (tb < 256) {
-            const int row = tb >> 3, ch = tb & 7;
-            const int q = u2 * 32 + row;
-            if (q < T)
-                *reinterpret_cast<uint4*>(a.dqkv + (row0 + q) * ld + hh * HD + ch * 8) =
-                    *reinterpret_cast<const uint4*>(dqstg + row * FB_DQ_ROW + ch * 16);
-        }
-    }
-    __syncthreads();                                   // (the last dQ rows have been read: the area becomes the output staging)
-    char* stg = dsimg + w * STG_BYTES;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-        if (j < ntl) {
-            bf16_t* kdst = a.dqkv + (row0 + k0 + 16 * j) * ld + D + hh * HD;
-#pragma unroll
-            for (int dt = 0; dt < ND; ++dt) dk[j][dt] *= a.scale;
-            store_tile<F16>(stg, dk[j], kdst, ld, T - (k0 + 16 * j), lane);
-            store_tile<F16>(stg, dv[j], kdst + D, ld, T - (k0 + 16 * j), lane);
-        }
-}
-
-#endif
-
-// ---------------------------------------------------------------------------------------------------------
 // Rollout step (SFTS.py:150-153, row-vector form):  r_out[k] = sum_q r_in[q] * P_l[q,k]  for one layer l, with the
 // probabilities RECOMPUTED from that layer's saved q/k and row log-sum-exps (P[q,k] = exp2(s[q,k] - lse[q]), exactly
 // the values the forward produced) instead of read from a materialised (3B,h,T,T) tensor: the forward then skips its
@@ -879,101 +664,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         if (lg == 0 && key < T) {
             if (final_step) { if (key >= 1) r_out[(long)blockIdx.x * (T - 1) + key - 1] = acc; }
             else r_out[(long)blockIdx.x * T + key] = acc;
-        }
-    }
-}
-
-// The whole rollout (all L layers) as ONE launch (round 4): a workgroup keeps its (sample, head)'s row vector r in LDS and walks
-// the layers last -> first; layer l-1's Q image and log-sum-exps travel (LDS-DMA / registers) while layer l is being multiplied,
-// the wave's first key fragments of the next layer are requested one layer ahead.  Same arithmetic per element and the same
-// summation order as L launches of attn_rollout_step_kernel (bit-identical scores); 12 launches and their tails -> 1.
-constexpr int kMaxRollLayers = 32;
-struct RolloutArgs { const bf16_t* qkv[kMaxRollLayers]; const float* lse[kMaxRollLayers]; int L; };
-
-template <int NT, bool F16>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_rollout_multi_kernel(RolloutArgs ra, int T, int heads, float scale, long Mtot,
-                                                                 float* __restrict__ scores)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int Tp = NT * 16;
-    float* lse_s = reinterpret_cast<float*>(smem + 2 * Tp * ROWB);      // [2][Tp]
-    float* w_s = lse_s + 2 * Tp;                                         // [2][Tp]
-    const int D = heads * HD;
-    const int b = blockIdx.x / heads, hh = blockIdx.x % heads;
-    const long ld = 3L * D;
-    const long row0 = (long)b * T;
-    const int nt = min(NT, ((T + 31) >> 5) << 1);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int li = lane & 15, lg = lane >> 4;
-    const float sc = scale * kLog2e;
-    const int L = ra.L;
-
-    const bf16_t* qb = ra.qkv[L - 1] + row0 * ld + hh * HD;
-    load_image(smem, qb, ld, T, nt * 16);
-    for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
-        lse_s[t] = t < T ? ra.lse[L - 1][(long)hh * Mtot + row0 + t] : INFINITY;
-        w_s[t] = t == 0 ? 1.f : 0.f;                                     // r = e_cls^T
-        w_s[Tp + t] = 0.f;                                               // (pad entries of the other buffer: never written later)
-    }
-    short8_t kn[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) kn[s] = frag_own(qb + D, ld, w * 16, T, s, lane);
-    for (int l = L - 1, cur = 0; l >= 0; --l, cur ^= 1) {
-        images_ready();                                                  // layer l's image (and everything written to LDS) is visible
-        const bf16_t* qcur = ra.qkv[l] + row0 * ld + hh * HD;
-        const bf16_t* qnx = l > 0 ? ra.qkv[l - 1] + row0 * ld + hh * HD : nullptr;
-        float lse_nx[(Tp + 191) / 192];                                  // next layer's log-sum-exps ride in registers
-        if (qnx) {
-            load_image(smem + (cur ^ 1) * (Tp * ROWB), qnx, ld, T, nt * 16);
-#pragma unroll
-            for (int i = 0; i < (Tp + 191) / 192; ++i) {
-                const int t = threadIdx.x + i * blockDim.x;
-                lse_nx[i] = (t < T) ? ra.lse[l - 1][(long)hh * Mtot + row0 + t] : INFINITY;
-            }
-        }
-        const char* qimg_c = smem + cur * (Tp * ROWB);
-        const float* lsec = lse_s + cur * Tp;
-        const float* wc = w_s + cur * Tp;
-        float* wn = w_s + (cur ^ 1) * Tp;
-        for (int k0 = w * 16; k0 < T; k0 += nw * 16) {
-            const int key = k0 + li;
-            short8_t kf[KS];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) kf[s] = kn[s];
-            // the next fragments: this layer's next key tile, or - on the wave's last tile - the next layer's first
-            const bool more = k0 + nw * 16 < T;
-            if (more || qnx) {
-                const bf16_t* src = more ? qcur : qnx;
-                const int r0 = more ? k0 + nw * 16 : w * 16;
-#pragma unroll
-                for (int s = 0; s < KS; ++s) kn[s] = frag_own(src + D, ld, r0, T, s, lane);
-            }
-            float acc = 0.f;
-#pragma unroll 2
-            for (int u = 0; u < nt; ++u) {
-                float4_t s_ = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < KS; ++s)
-                    s_ = mfma16<F16>(frag_k(qimg_c, u * 16, s, lane), kf[s], s_);
-                const float4 l4 = *reinterpret_cast<const float4*>(lsec + 16 * u + 4 * lg);
-                const float4 w4 = *reinterpret_cast<const float4*>(wc + 16 * u + 4 * lg);
-                acc = fmaf(__builtin_amdgcn_exp2f(s_[0] * sc - l4.x), w4.x, acc);
-                acc = fmaf(__builtin_amdgcn_exp2f(s_[1] * sc - l4.y), w4.y, acc);
-                acc = fmaf(__builtin_amdgcn_exp2f(s_[2] * sc - l4.z), w4.z, acc);
-                acc = fmaf(__builtin_amdgcn_exp2f(s_[3] * sc - l4.w), w4.w, acc);
-            }
-            acc = group_sum(acc);
-            if (lg == 0) {
-                if (l == 0) { if (key >= 1 && key < T) scores[(long)blockIdx.x * (T - 1) + key - 1] = acc; }
-                else wn[key] = key < T ? acc : 0.f;                      // (key < Tp: k0 + 15 < nt * 16)
-            }
-        }
-        if (qnx) {
-#pragma unroll
-            for (int i = 0; i < (Tp + 191) / 192; ++i) {
-                const int t = threadIdx.x + i * blockDim.x;
-                if (t < Tp) lse_s[(cur ^ 1) * Tp + t] = lse_nx[i];
-            }
         }
     }
 }
@@ -1199,11 +889,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     }
 }
 
-// two-pass (0, default) or fused (1) backward for the dense 129..160-token sequences: editor_attention_bwd_mode (the library's only
-// process-wide switch; editor_amd/ops.py sets it from EDITOR_ATTN_FUSED_BWD - no environment lookups in here).
-// Measured (MI355X, B = 384 sequences x 12 heads, T = 129, tools/attn_bench.py): two-pass 222 us, fused 266 us - see the kernel's comment.
-int g_fused_bwd = 0;
-
 template <typename K>
 int set_lds(K kern, size_t bytes)
 {
@@ -1253,19 +938,6 @@ int launch_all(const AttnArgs& a_in, int B, int mode, hipStream_t stream)
         EDITOR_LAUNCH_CHECK();
     } else {
         const bool full = !a.cu && !a.mask && (((a.T + 31) >> 5) << 1) >= NT && NT <= 14;
-#if ATTN_HD == 64
-        if constexpr (NT <= 10) {
-            // dense backbone sequences, opt-in (EDITOR_ATTN_FUSED_BWD=1): S / P / dP / dS once, dQ and dK / dV from the same
-            // workgroup; bit-identical to the two-pass form and, as measured, slower
-            if (full && g_fused_bwd && !a.colparts) {
-                auto kf = attn_bwd_fused_kernel<NT, F16>;
-                if ((rc = set_lds(kf, fused_bwd_lds<NT>()))) return rc;
-                hipLaunchKernelGGL(kf, grid, dim3(NT / 2 * 64), fused_bwd_lds<NT>(), stream, a);
-                EDITOR_LAUNCH_CHECK();
-                return 0;
-            }
-        }
-#endif
         if (a.mask) {
             auto k1 = attn_q_pass_kernel<NT, true, false, F16, true>;
             if ((rc = set_lds(k1, img))) return rc;
@@ -1382,35 +1054,6 @@ int rollout_step_h16(const uint16_t* qkv, const float* lse, const float* r_in, i
     return 0;
 }
 
-template <bool F16>
-int rollout_multi_h16(int L, const uint16_t* const* qkv, const float* const* lse, int B, int T, int heads, int hd, float scale,
-                      float* scores, hipStream_t stream)
-{
-    if (hd != HD || T < 2 || B < 1 || L < 1 || L > kMaxRollLayers || !qkv || !lse || !scores) return (int)hipErrorInvalidValue;
-    RolloutArgs ra;
-    memset(&ra, 0, sizeof(ra));
-    ra.L = L;
-    for (int l = 0; l < L; ++l) {
-        if (!qkv[l] || !lse[l]) return (int)hipErrorInvalidValue;
-        ra.qkv[l] = reinterpret_cast<const bf16_t*>(qkv[l]); ra.lse[l] = lse[l];
-    }
-    const int threads = pick_threads(T);
-    const long Mtot = (long)B * T;
-#define ROLLM_CASE(NTV) case NTV: {                                                                                  \
-        auto k = attn_rollout_multi_kernel<NTV, F16>;                                                                    \
-        const size_t lds = (size_t)2 * NTV * 16 * ROWB + (size_t)4 * NTV * 16 * sizeof(float);                          \
-        int rc = set_lds(k, lds); if (rc) return rc;                                                                     \
-        hipLaunchKernelGGL(k, dim3(B * heads), dim3(threads), lds, stream, ra, T, heads, scale, Mtot, scores);           \
-        break; }
-    switch (pick_nt(T)) {
-        ROLLM_CASE(10) ROLLM_CASE(14) ROLLM_CASE(26) ROLLM_CASE(38)
-        default: return (int)hipErrorInvalidValue;
-    }
-#undef ROLLM_CASE
-    EDITOR_LAUNCH_CHECK();
-    return 0;
-}
-
 }  // namespace
 
 // ---- entry points.  This file is compiled once per head width (editor_amd/build.py: -DATTN_HD=32 / 64 / 96); the 64-wide build
@@ -1428,22 +1071,6 @@ int rollout_multi_h16(int L, const uint16_t* const* qkv, const float* const* lse
 #define ATTN_DECL_WIDTHS(name, ...)
 #define ATTN_OTHER_WIDTHS(name, ...) do { } while (0)
 #endif
-
-#define ROLLM_ARGS int L, const uint16_t* const* qkv, const float* const* lse, int B, int T, int heads, int hd, float scale, \
-                   float* scores, hipStream_t stream
-ATTN_DECL_WIDTHS(editor_attn_rollout_multi_bf16, ROLLM_ARGS)
-ATTN_DECL_WIDTHS(editor_attn_rollout_multi_f16, ROLLM_ARGS)
-extern "C" int ATTN_ENTRY(editor_attn_rollout_multi_bf16)(ROLLM_ARGS)
-{
-    ATTN_OTHER_WIDTHS(editor_attn_rollout_multi_bf16, L, qkv, lse, B, T, heads, hd, scale, scores, stream);
-    return rollout_multi_h16<false>(L, qkv, lse, B, T, heads, hd, scale, scores, stream);
-}
-extern "C" int ATTN_ENTRY(editor_attn_rollout_multi_f16)(ROLLM_ARGS)
-{
-    ATTN_OTHER_WIDTHS(editor_attn_rollout_multi_f16, L, qkv, lse, B, T, heads, hd, scale, scores, stream);
-    return rollout_multi_h16<true>(L, qkv, lse, B, T, heads, hd, scale, scores, stream);
-}
-#undef ROLLM_ARGS
 
 #define FWD_ARGS const uint16_t* qkv, int B, int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* out, \
                  float* probs, int ldp, float* lse, const int* cu, long Mtot, hipStream_t stream
@@ -1498,15 +1125,6 @@ extern "C" int ATTN_ENTRY(editor_attention_bwd_colsum_f16)(BWDC_ARGS)
     return attention_bwd_h16<true>(qkv, dout, out, lse, B, T, heads, hd, scale, mask, dqkv, workspace, cu, Mtot, colparts, stream);
 }
 #undef BWDC_ARGS
-
-#if ATTN_HD == 64
-extern "C" int editor_attention_bwd_mode(int fused)
-{
-    const int prev = g_fused_bwd;
-    if (fused >= 0) g_fused_bwd = fused ? 1 : 0;
-    return prev;
-}
-#endif
 
 #define ROLL_ARGS const uint16_t* qkv, const float* lse, const float* r_in, int B, int T, int heads, int hd, float scale, \
                   float* r_out, int final_step, hipStream_t stream

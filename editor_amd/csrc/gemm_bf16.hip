@@ -80,7 +80,6 @@ struct GemmB16Args {
     int linear_ids;                          // ping-pong kernel: `bid` already is the position in the grouped tile order (the
                                              // grouped weight-gradient launch does its own XCD mapping)
     int prefer_pipe;                         // EDITOR_EPI_PIPE128
-    int rev_rows;                            // EDITOR_EPI_REVERSE_ROWS: tile rows taken last-first (ping-pong kernel)
     int stagger;                             // EDITOR_EPI_STAGGER(c): the first round's workgroups start spread over c * 2048 cycles (ping-pong kernel)
     int ablate;                              // debug build only (EDITOR_GEMM_ABLATE, tools/gemm_bound_probe.py): 1 = no LDS-DMA inside the
                                              // K loop, 2 = no MFMAs, 4 = no fragment reads - what each costs, by deletion
@@ -875,11 +874,8 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
     const int grp = GM * g.tiles_n;
     const int gm0 = (wgid / grp) * GM, rem = wgid % grp;
     const int gsz = min(GM, g.tiles_m - gm0);
-    int tile_m = gm0 + rem % gsz;
+    const int tile_m = gm0 + rem % gsz;
     const int tile_n = rem / gsz;
-    // EDITOR_EPI_REVERSE_ROWS: the consumer of a tensor the previous launch has just written walks it from its END - the rows that
-    // are still in the 256 MB Infinity Cache - where the same order as the producer finds the rows it wrote first evicted
-    if (g.rev_rows) tile_m = g.tiles_m - 1 - tile_m;
     const int m0 = tile_m * TH, n0 = tile_n * 256;
     int ktiles = g.K / BK;
     if (g.m_live) {
@@ -1699,10 +1695,8 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
     const int tile_frags = (epilogue >> 12) & 15;                       // EDITOR_EPI_TILE_ROWS(h): h / 16, 0 = full tiles
     if (tile_frags != 0 && tile_frags != 13) return (int)hipErrorInvalidValue;
     const bool prefer_pipe = (epilogue & EDITOR_EPI_PIPE128) != 0 && !want_colsum && !force_pp && tile_frags == 0;
-    const bool rev_rows = (epilogue & EDITOR_EPI_REVERSE_ROWS) != 0;
     const int stagger = ((epilogue >> 17) & 63) * 2048;                 // EDITOR_EPI_STAGGER(c)
-    epilogue &= ~(EDITOR_EPI_COLSUM | EDITOR_EPI_FORCE_PP | EDITOR_EPI_AUX_GRAD | EDITOR_EPI_PIPE128 | 0xF000 | EDITOR_EPI_REVERSE_ROWS |
-                  EDITOR_EPI_STAGGER(63));
+    epilogue &= ~(EDITOR_EPI_COLSUM | EDITOR_EPI_FORCE_PP | EDITOR_EPI_AUX_GRAD | EDITOR_EPI_PIPE128 | 0xF000 | EDITOR_EPI_STAGGER(63));
     if (aux_grad && epilogue != EDITOR_EPI_GELU && epilogue != EDITOR_EPI_GELU_BWD) return (int)hipErrorInvalidValue;
     if (want_colsum && (c_f32 || epilogue == EDITOR_EPI_RESIDUAL || splitk > 1 || !splitk_ws || transA || M < 2048 || N < 512 ||
                         (N & 7) || (ldc & 7) || (ldaux & 7) || (K % BK) || beta != 0.f || m_live))
@@ -1732,7 +1726,7 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
                   slabs ? 0.f : beta, bias, rowscale, splitk, (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux,
                   slabs ? 1 : 0,
                   m_live, transA ? 1 : 0, 0, want_colsum ? splitk_ws : nullptr, nullptr, force_pp ? 1 : 0, aux_grad ? 1 : 0,
-                  tile_frags, nullptr, nullptr, nullptr, 0, prefer_pipe ? 1 : 0, rev_rows ? 1 : 0, stagger};
+                  tile_frags, nullptr, nullptr, nullptr, 0, prefer_pipe ? 1 : 0, stagger};
     if (m_live && (!pipe || (splitk > 1 && !slabs))) return (int)hipErrorInvalidValue;   // live-row form: pipelined path only
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
     int rc;

@@ -295,11 +295,6 @@ class _SubCtx:
         pass
 
 
-# EDITOR_REVERSE_ROWS=1 (A/B switch, round 4): the GEMMs whose row operand is a tensor LARGER than the 256 MB Infinity Cache that the
-# previous launch has just written - fc2 after fc1's GELU output (304 MB at B = 128), fc1's dgrad after fc2's dgrad, the qkv dgrad
-# after the attention backward's dqkv (228 MB) - take their tile rows last-first (ops.EPI_REVERSE_ROWS): they start with the rows
-# that are still cached instead of the ones the producer wrote first.  Same bits (tools/repro_check.py).
-REVERSE_ROWS = ops.EPI_REVERSE_ROWS if os.environ.get("EDITOR_REVERSE_ROWS", "0") == "1" else 0
 # EDITOR_STAGGER_QKV=c (A/B switch, round 5): the qkv forward's first round of workgroups starts spread over c * 2048 cycles
 # (ops.EPI_STAGGER) - the one product the spread helped in tools/stagger_sweep.py (rotating operands: 214 -> 186 us; every other
 # product of the path is flat or slower with it).  In the step, same box, twice each: 42.56 / 42.57 -> 42.31 / 42.34 ms replay-only.
@@ -359,7 +354,7 @@ def _linear_bwd(*args, **kw):
 
 
 def _linear_bwd_gen(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None, gs=1.0, dw_out=None,
-                    db_out=None, dxcs_out=None, w_t=None, defer=None, aux_is_grad=True, rq=None, rev=0):
+                    db_out=None, dxcs_out=None, w_t=None, defer=None, aux_is_grad=True, rq=None):
     """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy) (or the
     caller's, when the kernel that produced dy summed its columns on the way).  dx_colsum: also return colsum(dx) - the
     bias gradient of the layer BELOW - from the dgrad's own epilogue when it can deliver it (else None).
@@ -378,7 +373,7 @@ def _linear_bwd_gen(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=No
     # B = W stored (Kred=n, Nout=k): row-k operand (trans_b = 1); or its k-major copy W^T (Nout=k, Kred=n): trans_b = 0
     wb, ldb, tb = (w_t, n, 0) if w_t is not None else (w_act, k, 1)
     if gelu_pre is None:
-        yield _GemmReq(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, epilogue=rev, m_live=m_live, colsum=dxcs, colsum_scale=inv, tag="dgrad",
+        yield _GemmReq(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, m_live=m_live, colsum=dxcs, colsum_scale=inv, tag="dgrad",
                        rq=rq)
     else:
         ag = ops.EPI_AUX_GRAD if (dy.dtype in ops.HALF_DTYPES and aux_is_grad) else 0   # 16-bit: gelu_pre holds gelu'(pre-activation)
@@ -578,7 +573,7 @@ class TransformerBlockFn(torch.autograd.Function):
         else:
             x2 = torch.empty_like(x2d)
             yield _GemmReq(g, w2, x2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b, rowscale=rowscale_mlp,
-                           epilogue=ops.EPI_RESIDUAL | (REVERSE_ROWS if m_live is None else 0), aux=x1, m_live=m_live)
+                           epilogue=ops.EPI_RESIDUAL, aux=x1, m_live=m_live)
         if light:
             h1 = h2 = g = None                      # recomputed by the backward (n1b / n2b / eps ride along)
         ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
@@ -637,7 +632,7 @@ class TransformerBlockFn(torch.autograd.Function):
         if light is not None:
             h2 = ops.layernorm_fwd(x1, n2w, light[1], light[2], act_dtype, mask, 0, want_stats=False, m_live=m_live)[0]
         dh2, dw1, db1 = yield from _linear_bwd_gen(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs, gs=gs, dw_out=sv[8], db_out=sv[9], w_t=w1t,
-                                    defer=jobs, rq=rq, rev=REVERSE_ROWS if m_live is None else 0)
+                                    defer=jobs, rq=rq)
         fuse_cast = (FUSE_LN_CAST and m_live is None and mask is None and act_dtype in ops.HALF_DTYPES
                      and d % 256 == 0 and d <= 1024)
         if fuse_cast:
@@ -663,7 +658,7 @@ class TransformerBlockFn(torch.autograd.Function):
         if light is not None:
             h1 = ops.layernorm_fwd(x2d, n1w, light[0], light[2], act_dtype, mask, 0, want_stats=False, m_live=m_live)[0]
         dh1, dwq, dbq = yield from _linear_bwd_gen(dqkv, h1, wq, hb_qkv, m_live=m_live, db=dbq, gs=gs, dw_out=sv[2], db_out=sv[3], w_t=wqt,
-                                    defer=jobs, rq=rq, rev=REVERSE_ROWS if m_live is None else 0)
+                                    defer=jobs, rq=rq)
         fb = getattr(ctx, "feeds_box", None)
         ln_done = False
         if jobs and WGRAD_LN and fb is not None and fuse_cast and not deferred:

@@ -55,26 +55,11 @@ def attn_rollout(probs):
     return scores
 
 
-# all layers of the rollout in ONE launch (editor_attn_rollout_multi_*) instead of one per layer: bit-identical, 11 launches fewer,
-# and NOT faster - measured (round 4, same box, twice each) 43.96 / 43.99 ms per step with the per-layer launches against 44.05 /
-# 44.02 with the single one (a workgroup then walks twelve dependent layers with 43 KiB of LDS, four resident per CU instead of
-# seven).  Off by default; EDITOR_ROLLOUT_MULTI=1 switches it on.
-ROLLOUT_MULTI = os.environ.get("EDITOR_ROLLOUT_MULTI", "0") == "1"
-
-
 def attn_rollout_qk(layers, b, t, heads, hd, scale=None):
     """Rollout scores (B, H, T-1) from the per-layer (qkv, lse) pairs of the bf16 backbone, first layer first:
     r = e_cls^T A_{L-1}; r <- r A_l for l = L-2 .. 0, each A_l recomputed on the fly (no probability tensor)."""
     dev = layers[0][0].device
     scores = torch.empty(b, heads, t - 1, dtype=torch.float32, device=dev)
-    if ROLLOUT_MULTI and len(layers) <= 32 and all(len(l_) == 2 for l_ in layers):
-        # one launch for all layers (editor_attn_rollout_multi_*): r stays in LDS, the next layer's operands travel under this one's
-        n = len(layers)
-        qs = (ctypes.c_void_p * n)(*[q.data_ptr() for q, _ in layers])
-        ls = (ctypes.c_void_p * n)(*[l_.data_ptr() for _, l_ in layers])
-        with torch.cuda.device(dev):
-            call(_h16(layers[0][0], "attn_rollout_multi"), n, qs, ls, b, t, heads, hd, float(scale or hd ** -0.5), scores)
-        return scores
     bufs = [torch.empty(b * heads, t, dtype=torch.float32, device=dev) for _ in range(2)]
     r_in = None
     for i, layer in enumerate(reversed(layers)):
@@ -412,8 +397,6 @@ EPI_NONE, EPI_RESIDUAL, EPI_GELU, EPI_GELU_BWD = 0, 1, 2, 3
 EPI_COLSUM = 0x100
 EPI_AUX_GRAD = 0x400          # with EPI_GELU / EPI_GELU_BWD (16-bit): aux = gelu'(pre-activation) instead of the pre-activation
 EPI_FORCE_PP = 0x200          # run the 256x256 ping-pong kernel whatever the shape heuristic says (tests)
-EPI_REVERSE_ROWS = 0x10000    # ping-pong kernel: tile rows last-first (the consumer of a just-written tensor larger than the
-                              # 256 MB Infinity Cache starts with the rows that are still in it)
 def EPI_STAGGER(c):
     """OR-able (ping-pong kernel, > 256 tiles): the first round's workgroups start spread over c * 2048 shader cycles
     (include/editor_hip.h) - the CUs leave lockstep, HBM-bound epilogues run beside the other CUs' K loops.  Same bits."""
@@ -422,9 +405,6 @@ def EPI_STAGGER(c):
 
 EPI_PIPE128 = 0x800           # prefer the 256x128 three-stage kernel (few token rows; gemm_tile_plan below)
 SHORT_TILES = os.environ.get("EDITOR_SHORT_TILES", "1") != "0"      # gemm_tile_rows below (measurement switch)
-# expected live share of a compacted launch's rows for the tile plan below; 0 = off, the default: measured (round 4, same box, twice
-# each) 43.50 / 43.35 ms off against 43.73 / 43.65 ms with 0.5 - the 256 x 128 kernel's lower rate costs more than the idle CUs
-LIVE_FRAC = float(os.environ.get("EDITOR_LIVE_FRAC", "0"))
 
 
 def EPI_TILE_ROWS(h):
@@ -517,15 +497,6 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
                 th, epilogue = 256, int(epilogue) | EPI_PIPE128
             elif th != 256:
                 epilogue = int(epilogue) | EPI_TILE_ROWS(th)
-        elif (LIVE_FRAC > 0.0 and m_live is not None and not trans_a and not trans_b and splitk == 1 and beta == 0.0 and m >= 2048
-                and n >= 512 and colsum is None and not (int(epilogue) & (0xF000 | EPI_FORCE_PP))):
-            # compacted HMA head: the launch is sized for the worst case (every token kept) but only *m_live rows are live (a
-            # device scalar; workgroups of dead tiles exit at once) - about half of them (52 - 67 kept tokens of 128, SURVEY.md
-            # Appendix C).  Plan the tiles for THAT many rows: a per-modality block's 768-wide products are ~90 live 256-wide
-            # tiles on 256 CUs
-            _, narrow = gemm_tile_plan(max(256, int(m * LIVE_FRAC)), n)
-            if narrow:
-                epilogue = int(epilogue) | EPI_PIPE128
         if colsum is not None:
             # colsum (n) fp32 <- column sums of the rounded output (bias gradient of the layer this gradient feeds):
             # per-tile-row partials from the GEMM epilogue, folded in a fixed order
@@ -796,13 +767,6 @@ def attention_fwd(qkv, b, t, heads, hd, mask=None, probs=None, want_lse=True, cu
     return out, lse
 
 
-_ATTN_MODE_ENV = [False]
-
-
-def attention_bwd_mode(fused=-1):
-    """0 (default) / 1: two-pass / fused backward for dense 129..160-token sequences (bit-identical; A/B switch); < 0: query.
-    Returns the previous setting (include/editor_hip.h: editor_attention_bwd_mode)."""
-    return int(_lib.lib().cdll.editor_attention_bwd_mode(int(fused)))
 
 
 ATTN_BWD_COLSUM = os.environ.get("EDITOR_ATTN_COLSUM", "1") == "1"
@@ -832,10 +796,6 @@ def attention_bwd(qkv, dout, b, t, heads, hd, mask=None, saved=None, out=None, c
         #  or the split-precision forward of a non-64-wide head, attention_fwd_split - handed back)
         dqkv = attention_bwd(qkv.float(), dout.float(), b, t, heads, hd, mask, saved, None, None, scale).to(qkv.dtype)
     else:
-        if not _ATTN_MODE_ENV[0]:                       # EDITOR_ATTN_FUSED_BWD=1: the fused backward (A/B measurements), once
-            _ATTN_MODE_ENV[0] = True
-            if os.environ.get("EDITOR_ATTN_FUSED_BWD", "0") == "1":
-                attention_bwd_mode(1)
         dqkv = _packed_alloc(rows, qkv.shape[1], qkv.dtype, qkv.device, cu)
         ws = torch.empty(heads * rows, dtype=torch.float32, device=qkv.device)
         if colsum is None:

@@ -46,10 +46,6 @@ typedef struct ihipStream_t* editor_stream_t;   /* == hipStream_t */
 #define EDITOR_EPI_PIPE128 0x800 /* OR-able: prefer the 256x128 three-stage kernel over the 256x256 ping-pong kernel (few token rows:
                                   * twice the tiles fill more of the 256 CUs; the caller's tile-count heuristic decides,
                                   * editor_amd.ops.gemm).  Ignored with EDITOR_EPI_COLSUM / _FORCE_PP / _TILE_ROWS. */
-#define EDITOR_EPI_REVERSE_ROWS 0x10000 /* OR-able (256x256 ping-pong kernel; ignored by the others): output tile rows are taken
-                                  * last-first - for the consumer of a tensor larger than the Infinity Cache that the previous
-                                  * launch has just written (fc2 after fc1's GELU output, fc1's dgrad after fc2's).  Same
-                                  * results bit for bit (every tile is computed as before). */
 #define EDITOR_EPI_STAGGER(c) (((c) & 63) << 17) /* OR-able (256x256 ping-pong kernel, more than 256 tiles; ignored otherwise): the
                                   * first round's workgroups start spread over c * 2048 shader cycles, so that the CUs leave
                                   * lockstep and one CU's HBM-bound epilogue runs beside the others' K loops.  Same results bit
@@ -290,13 +286,6 @@ int editor_attention_fwd_f32(const float* qkv, int B, int T, int heads, int hd, 
 int editor_attention_bwd_f32(const float* qkv, const float* dout, const float* probs, int B, int T, int heads, int hd,
                              float scale, float* dqkv, float* workspace, editor_stream_t stream);
 
-/* The whole rollout in ONE launch (round 4): qkv / lse are HOST arrays of L device pointers, first layer first (layer l's packed
- * qkv (B*T, 3*heads*64) and forward lse (heads*B*T)); scores (B*heads, T-1) <- the CLS->patch row of A_{L-1} ... A_0 per head.
- * Same arithmetic and summation order as L calls of editor_attn_rollout_step_* (bit-identical); L <= 32. */
-int editor_attn_rollout_multi_bf16(int L, const uint16_t* const* qkv, const float* const* lse, int B, int T, int heads, int hd,
-                                   float scale, float* scores, editor_stream_t stream);
-int editor_attn_rollout_multi_f16(int L, const uint16_t* const* qkv, const float* const* lse, int B, int T, int heads, int hd,
-                                  float scale, float* scores, editor_stream_t stream);
 /* One step of the attention rollout (SFTS.py:150-153) WITHOUT materialised probabilities: r_out[bh][k] =
  * sum_q r_in[bh][q] * P_l[q,k], P_l recomputed from layer l's packed qkv (B*T, 3*heads*64) and the forward's lse
  * (heads*B*T).  r_in NULL = one-hot CLS row (first step, last layer).  final_step: r_out is (B*heads, T-1) and receives
@@ -353,12 +342,6 @@ int editor_attention_fwd_f16(const uint16_t* qkv, int B, int T, int heads, int h
 int editor_attention_bwd_f16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, int B,
                              int T, int heads, int hd, float scale, const uint8_t* mask, uint16_t* dqkv,
                              float* workspace, const int* cu, long Mtot, editor_stream_t stream);
-/* Backward form for dense unmasked sequences of 129..160 tokens (the backbone's): 0 (default) = the two-pass form every
- * shape uses, 1 = fused (S, P, dP, dS computed once; dQ and dK / dV from one workgroup, dS handed over through LDS).
- * Bit-identical results; the fused form measured slower (266 vs 222 us at T = 129) and exists for A/B measurements (the
- * Python host sets it from EDITOR_ATTN_FUSED_BWD=1; the library itself reads no environment).  Process-wide; fused < 0:
- * query only.  Returns the previous setting. */
-int editor_attention_bwd_mode(int fused);
 
 /* ---- compacted (variable-length) HMA: packing plan and row movement (csrc/compact.hip) ------------------ */
 /* index (B,N) uint8 -> cu (B+1): exclusive prefix sum of L_b = 1 + #selected; tok (>= cu[B] ints): token id (0 = cls,

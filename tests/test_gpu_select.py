@@ -162,22 +162,6 @@ def test_rollout_recomputed_from_qk_matches_materialised(t):
     k = 2
     same = (got.topk(k, dim=-1).indices.sort(-1).values == ref.topk(k, dim=-1).indices.sort(-1).values).all(-1)
     assert same.float().mean().item() > 0.98                      # selections agree except on near-ties
-    # round 4: all layers in ONE launch (editor_attn_rollout_multi_*; an option, EDITOR_ROLLOUT_MULTI=1) == one launch per layer,
-    # bit for bit (bf16 and f16 operands, L = 5 / 3 / 1)
-    import editor_amd.ops as ops_mod
-
-    def multi(p_):
-        old = ops_mod.ROLLOUT_MULTI
-        try:
-            ops_mod.ROLLOUT_MULTI = True
-            return ops.attn_rollout_qk(p_, b, t, heads, hd)
-        finally:
-            ops_mod.ROLLOUT_MULTI = old
-    assert not ops_mod.ROLLOUT_MULTI
-    assert torch.equal(got, multi(pairs))
-    f16 = [(q.float().half(), l_) for q, l_ in pairs[:3]]
-    assert torch.equal(ops.attn_rollout_qk(f16, b, t, heads, hd), multi(f16))
-    assert torch.equal(ops.attn_rollout_qk(pairs[:1], b, t, heads, hd), multi(pairs[:1]))
 
 
 @pytest.mark.gpu

@@ -22,10 +22,6 @@ print("rollout step      %.1f us" % bench(lambda: ops.attn_rollout_qk([(qkv, lse
 for tt in (193,):
     q2 = (torch.randn(b * tt, 3 * heads * hd, device='cuda') * 0.5).bfloat16()
     print("T=%d fwd no probs %.1f us" % (tt, bench(lambda: ops.attention_fwd(q2, b, tt, heads, hd, None, None))))
-for mode, name in ((0, "two-pass"), (1, "fused")):
-    ops.attention_bwd_mode(mode)
-    print("bwd %-8s        %.1f us" % (name, bench(lambda: ops.attention_bwd(qkv, do, b, t, heads, hd, None, lse, o))))
-ops.attention_bwd_mode(0)
 # round 4: the fused kernels at the factory's other head widths (same 768 = heads x hd columns, B = 384 sequences of 129 tokens)
 # against the exact-f32 kernels between two casts they used to take (ops.attention_fwd's fallback for other widths)
 for heads2, hd2 in ((8, 96), (24, 32)):
