@@ -224,7 +224,9 @@ __global__ void __launch_bounds__(256) rerank_final_kernel(const uint16_t* __res
         const float frac = h2f(f2h(tf / den));
         const float jac = h2f(f2h(1.f - frac));
         const float jw = h2f(f2h(jac * h2f(w16)));
-        out[(long)i * G + (g - Q)] = __fadd_rn(jw, __fmul_rn(od[(long)i * N + g], lam));     // (two roundings, as numpy: no fma)
+        float scaled = od[(long)i * N + g] * lam;
+        asm volatile("" : "+v"(scaled));                         // two roundings, as numpy: keeps hipcc's default contraction from fusing
+        out[(long)i * G + (g - Q)] = jw + scaled;                // the product into the sum (an fma differs in the last bit on 18 % of entries)
     }
 }
 
