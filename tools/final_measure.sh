@@ -24,24 +24,17 @@ cp gpurun_out/prof_${tag}/kernel_stats.csv gpurun_out/${tag}_bench_kernel_stats.
 EDITOR_WGRAD_STREAM=0 bash tools/prof.sh ${tag}s --no-replay --no-h2d --no-modes --no-eval > gpurun_out/${tag}_prof_serial.txt 2>&1
 cp gpurun_out/prof_${tag}s/kernel_stats.csv gpurun_out/${tag}_bench_kernel_stats_serial.csv
 cp gpurun_out/prof_${tag}s/kernel_stats.hash gpurun_out/${tag}_bench_kernel_stats_serial.hash
-EDITOR_WGRAD_STREAM=0 bash tools/prof.sh ${tag}x2 --dtype f16x2 --no-replay --no-h2d --no-modes --no-eval > gpurun_out/${tag}_prof_f16x2.txt 2>&1
-cp gpurun_out/prof_${tag}x2/kernel_stats.csv gpurun_out/${tag}_f16x2_kernel_stats_serial.csv
+EDITOR_WGRAD_STREAM=0 bash tools/prof.sh ${tag}x2 --dtype f16x2s --no-replay --no-h2d --no-modes --no-eval > gpurun_out/${tag}_prof_f16x2s.txt 2>&1
+cp gpurun_out/prof_${tag}x2/kernel_stats.csv gpurun_out/${tag}_f16x2s_kernel_stats_serial.csv
+EDITOR_WGRAD_STREAM=0 bash tools/prof.sh ${tag}h --dtype f16 --no-replay --no-h2d --no-modes --no-eval > gpurun_out/${tag}_prof_f16.txt 2>&1
+cp gpurun_out/prof_${tag}h/kernel_stats.csv gpurun_out/${tag}_f16_kernel_stats_serial.csv
+bash tools/pmc_mfma.sh > gpurun_out/${tag}_pmc_mfma.txt 2>&1
+python tools/stagger_sweep.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_stagger_sweep.txt
 bash tools/launch_count.sh ${tag} > /dev/null 2>&1
 python tools/select_time.py > gpurun_out/${tag}_select_time.txt 2>&1
-python tools/residual_pricing.py > gpurun_out/${tag}_residual_pricing.txt 2>&1
 TAG=${tag} bash tools/pmc_traffic.sh > gpurun_out/${tag}_pmc_traffic.log 2>&1
 GEMM_EPI=1 GEMM_SPLIT=1 python tools/gemm_bench.py > gpurun_out/${tag}_gemm_bench.txt 2>&1
-python tools/clock_probe.py > gpurun_out/${tag}_clock_probe.txt 2>&1
 python tools/attn_bench.py > gpurun_out/${tag}_attn_bench.txt 2>&1
-python tools/blas_reference.py > gpurun_out/${tag}_blas_reference.txt 2>&1
-# what bounds the GEMM's K loop (round 4): per-K-tile cost at the step's conditions, by deletion, the four-wave tile, tile phases, rounds
-python -m editor_amd.build --trace > /dev/null 2>&1
-python tools/gemm_bound_probe.py --ablate 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_gemm_bound_probe.txt
-(python tools/gemm_w4_probe.py; python tools/gemm_w4_probe.py --ablate) 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_gemm_w4_probe.txt
-python tools/gemm_tile_ends.py 2>&1 >/dev/null | grep -v amdgpu.ids > gpurun_out/${tag}_gemm_tile_ends.txt
-python tools/gemm_round_gap.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_gemm_round_gap.txt
-python tools/cu_mask_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_cu_mask_probe.txt
-python tools/torch_backbone_reference.py > gpurun_out/${tag}_torch_backbone_reference.txt 2>&1
 head -c 700 gpurun_out/${tag}_bench_line_default.json; echo
 for f in f16x2 f16x2s f16 rgbnt100 msvr310 synth4l b16 b32 b64 spawn1 spawn1_wire16; do head -c 330 gpurun_out/${tag}_bench_line_$f.json; echo; done
 tail -4 gpurun_out/${tag}_repro_check.txt
