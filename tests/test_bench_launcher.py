@@ -114,3 +114,37 @@ def test_launcher_failure_shows_every_ranks_stderr_tail(bench, monkeypatch, caps
     _patch(monkeypatch, bench, 8, "[default0]:" + _line(2) + "\n", 0, seen)
     assert bench.launch_ranks(2, ["--gpus", "2"]) == 0
     assert capsys.readouterr().out.strip() == _line(2)
+
+
+def test_committed_profile_is_quoted_only_for_the_tree_it_was_taken_on(bench, monkeypatch, tmp_path):
+    """bench.py's `in_situ_*` figures come from the newest profiles/rNN_bench_kernel_stats_serial.csv ONLY when the
+    source hash stamped beside it (tools/prof.sh -> .hash) equals the running tree's; otherwise nothing is quoted and the line says why."""
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r07_bench_kernel_stats_serial.csv").write_text(
+        '"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+        '"void (anonymous namespace)::layernorm_fwd_kernel<x>(a)",10,1000,35500.0,1,1,1,1\n')
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "source_hash", lambda: "aaaa")
+    src, situ = bench._in_situ_us()                       # no stamp at all
+    assert situ == {} and "NOT quoted" in src
+    (prof / "r07_bench_kernel_stats_serial.hash").write_text("bbbb\n")
+    src, situ = bench._in_situ_us()                       # stamp of another tree
+    assert situ == {} and "NOT quoted" in src
+    (prof / "r07_bench_kernel_stats_serial.hash").write_text("aaaa\n")
+    src, situ = bench._in_situ_us()
+    assert src.endswith("r07_bench_kernel_stats_serial.csv") and abs(situ["layernorm_fwd_kernel<x>(a)"] - 35.5) < 1e-9
+
+
+def test_source_hash_moves_with_a_kernel_source(bench, monkeypatch, tmp_path):
+    import shutil
+    root = tmp_path / "r"
+    for d in ("editor_amd/csrc", "include", "editor_amd/modeling"):
+        (root / d).mkdir(parents=True)
+    (root / "editor_amd/csrc/a.hip").write_text("kernel 1")
+    (root / "include/x.h").write_text("h")
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    h0 = bench.source_hash()
+    assert h0 == bench.source_hash() and len(h0) == 16
+    (root / "editor_amd/csrc/a.hip").write_text("kernel 2")
+    assert bench.source_hash() != h0
