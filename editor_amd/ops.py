@@ -857,15 +857,29 @@ def gather_rows(x2d, src, live=None, live_mul=1, live_stride=0):
     return out
 
 
+# debug: the row-movement backwards below leave rows NO consumer reads unwritten (fill "none" / "tail", the live-row pool
+# backward) - correct only while that contract holds.  EDITOR_POISON_UNWRITTEN=1 (or ops.POISON_UNWRITTEN = True) fills those buffers
+# with NaN first, so a consumer that does read an unwritten row shows up as a non-finite / different gradient
+# (tests/test_gpu_model.py::test_unwritten_gradient_rows_are_never_read).
+POISON_UNWRITTEN = os.environ.get("EDITOR_POISON_UNWRITTEN", "0") == "1"
+
+
+def _unwritten(rows, d, device):
+    if POISON_UNWRITTEN:
+        return torch.full((rows, d), float("nan"), dtype=torch.float32, device=device)
+    return torch.empty(rows, d, dtype=torch.float32, device=device)
+
+
 def scatter_rows(dy2d, src, rows_out, fill="all", live=None, seg_rows=0):
     """dx[src[r]] = dy[r].  fill: "all" = dx zero-filled first (rows no index names are 0); "none" = no fill at all - ONLY for a
     consumer that never reads those rows; "tail" = only the pad rows [live, roundup64(live)) of every `seg_rows`-row segment are
     zeroed (live: device int32 scalar) - what the live-row kernels read beyond the live extent."""
     d = dy2d.shape[1]
-    dx = torch.empty(rows_out, d, dtype=torch.float32, device=dy2d.device)
     if fill == "all":
+        dx = torch.empty(rows_out, d, dtype=torch.float32, device=dy2d.device)
         call("editor_scatter_rows", dy2d, src, src.numel(), d, rows_out, dx)
         return dx
+    dx = _unwritten(rows_out, d, dy2d.device)
     call("editor_scatter_rows_nofill", dy2d, src, src.numel(), d, dx)
     if fill == "tail":
         seg = int(seg_rows) or rows_out
@@ -884,7 +898,7 @@ def pool_packed_fwd(x2d, cu, b, nmod):
 
 def pool_packed_bwd(dout, num, cu, b, nmod, rows, live=None):
     if live is not None:                      # live: device scalar = nmod * cu[b] live rows; no 152 MB zero fill
-        dx = torch.empty(rows, dout.shape[-1] // 2, dtype=torch.float32, device=dout.device)
+        dx = _unwritten(rows, dout.shape[-1] // 2, dout.device)
         call("editor_pool_packed_bwd_nofill", dout, num, cu, b, nmod, dout.shape[-1] // 2, dx)
         call("editor_zero_tail_rows", dx, dx.shape[1] * 4, rows, live)
         return dx

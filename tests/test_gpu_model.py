@@ -338,6 +338,38 @@ def test_hma_compact_equals_dense_bf16():
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_unwritten_gradient_rows_are_never_read(dtype):
+    """the compacted HMA head's row-movement backwards (scatter with fill "none" / "tail", the live-row pool backward) and the
+    live-row GEMMs leave the rows nobody reads UNWRITTEN.  With those buffers pre-filled with NaN (ops.POISON_UNWRITTEN) every parameter
+    gradient of a training step must stay finite and bit-identical to the unpoisoned run - a consumer that read an unwritten row (a bias
+    column sum over all rows, a second reader of the gather's gradient) would show up here."""
+    import editor_amd.ops as ops_mod
+    seed, batch = 33, 8
+    img, label, cam, view = _cuda_batch(*synth.make_batch(seed + 1, batch, 256, 128, 4, instances=4))
+    grads = {}
+    old = ops_mod.POISON_UNWRITTEN
+    try:
+        for poison in (False, True):
+            ops_mod.POISON_UNWRITTEN = poison
+            m, cfg, c, cams = _model("RGBNT201", seed, dtype, drop_path=0.0)
+            m.train()
+            out = m(img, label=label, cam_label=cam, view_label=view, writer=_Writer(), epoch=1)
+            total = out[-1]
+            for i, o in enumerate(out[:-1]):
+                total = total + (o * synth.uniform(5, "proj/%d" % i, tuple(o.shape)).cuda()).mean()
+            total.backward()
+            torch.cuda.synchronize()
+            assert "plan" in m.last_aux                      # the compacted head ran
+            grads[poison] = {k: p.grad.detach().float().cpu() for k, p in m.named_parameters() if p.grad is not None}
+    finally:
+        ops_mod.POISON_UNWRITTEN = old
+    assert grads[False].keys() == grads[True].keys() and len(grads[True]) > 150
+    for k, g in grads[True].items():
+        assert torch.isfinite(g).all(), k
+        assert torch.equal(g, grads[False][k]), k
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_eval_16bit_384x128_config4(dtype):
     """BASELINE.json config 4 geometry (384x128 -> 192 patches, T = 193, joint HMA block of up to 579 tokens) in the 16-bit
     modes, compacted HMA, reference selection teacher-forced."""
