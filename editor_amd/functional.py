@@ -608,6 +608,11 @@ class TransformerBlockFn(torch.autograd.Function):
         wqt, wpt, w1t, w2t = ((act_weight_t(w, act_dtype) for w in (qkvw, projw, fc1w, fc2w)) if kmaj else (None,) * 4)
         dx2 = dx2.contiguous().view(m, d)
         light = ctx.light
+        if a is None:
+            # the forward ran with the grad mode off (FWD_GRAD False: fc1 then writes no gelu' tensor) - a backward through it would
+            # silently drop gelu' from the fc2 dgrad; it cannot happen through EDITOR.forward, which restores the flag
+            raise RuntimeError("TransformerBlockFn.backward: this block's forward saved no GELU derivative (it ran under "
+                               "functional.set_model_options(grad_enabled=False)); re-run the forward with gradients enabled")
         if light is not None:
             # activation-light block: the GELU output for the fc2 weight gradient from the saved pre-activation (the fc2 dgrad
             # epilogue evaluates gelu' from it as well); the LayerNorm outputs right before their weight gradients need them

@@ -322,9 +322,13 @@ class EDITOR(nn.Module):
         self.split_rollout_recompute = bool(getattr(cfg.MODEL, "SPLIT_ROLLOUT_RECOMPUTE",
                                                     os.environ.get("EDITOR_SPLIT_ROLLOUT") == "1"))
         self.teacher_index = None            # optional (B,N) bool: force the SFTS selection (bf16 protocol)
+        # optional (nmod, depth, 2, B) 0/1: force the stochastic-depth keep masks (parity tests against the oracle / the reference's
+        # recorded torch.rand draws: [modality, block, branch (0 attention, 1 MLP), sample], vit_pytorch.py:64-68,217-218)
+        self.teacher_drop_keep = None
         self.grad_buckets = None             # editor_amd.ddp.GradBuckets once enable_grad_buckets() was called
         self._drop_rates_dev = None
         self._drop_state = None
+        self.last_drop_scales = None
         self.last_aux = {}
 
     # -- checkpoint compatibility (make_model.py:144-148) ---------------------------------------
@@ -400,10 +404,19 @@ class EDITOR(nn.Module):
         if self.training and max(base.drop_rates) > 0.0:                       # vit_pytorch.py:52-69: one launch for all
             if self._drop_rates_dev is None or self._drop_rates_dev.device != dev:
                 self._drop_rates_dev = torch.tensor(base.drop_rates, dtype=torch.float32, device=dev)
-            if self._drop_state is None or self._drop_state.device != dev:      # device-resident RNG counter
-                seed0 = (int(torch.initial_seed()) * 1000003) & 0x3FFFFFFFFFFFFFFF
-                self._drop_state = torch.full((1,), seed0, dtype=torch.int64, device=dev)
-            scales = ops.droppath_scales_dev(self._drop_rates_dev, btot, t, self._drop_state)
+            if self.teacher_drop_keep is not None:
+                keep = self.teacher_drop_keep.to(dev).float()                   # (nmod, depth, 2, B)
+                if tuple(keep.shape) != (len(imgs), base.depth, 2, btot // len(imgs)):
+                    raise ValueError("teacher_drop_keep must be (nmod, depth, 2, B)")
+                keep = keep.permute(1, 2, 0, 3).reshape(base.depth, 2, btot)    # the modalities are stacked on the batch axis
+                per_sample = keep / (1.0 - self._drop_rates_dev).view(-1, 1, 1) # what droppath_kernel writes: floor(kp + u) / kp
+                scales = per_sample.unsqueeze(-1).expand(-1, -1, -1, t).reshape(base.depth, 2, btot * t).contiguous()
+            else:
+                if self._drop_state is None or self._drop_state.device != dev:  # device-resident RNG counter
+                    seed0 = (int(torch.initial_seed()) * 1000003) & 0x3FFFFFFFFFFFFFFF
+                    self._drop_state = torch.full((1,), seed0, dtype=torch.int64, device=dev)
+                scales = ops.droppath_scales_dev(self._drop_rates_dev, btot, t, self._drop_state)
+            self.last_drop_scales = scales             # (depth, 2, nmod*B*T) per-row branch scales of this forward (tests read them)
         pend_branch = pend_rs = None                 # BRANCH16: the previous block's (fc2 branch, drop-path scales); x is then its x1
         for i, blk in enumerate(base.blocks):
             rs_a = rs_m = None
@@ -512,7 +525,15 @@ class EDITOR(nn.Module):
 
     # -- forward (make_model.py:150-258) ----------------------------------------------------------
     def forward(self, x, cam_label=None, label=None, view_label=None, img_path=None, mode=1, writer=None, epoch=None):
+        # the grad mode is an option of THIS forward's nodes only: restored afterwards, so that autograd nodes applied outside
+        # EDITOR.forward (tests, library users) never inherit a no-grad forward's "save nothing" setting
         fn.set_model_options(self.grad_scale_f16, self.act_light, torch.is_grad_enabled())
+        try:
+            return self._forward(x, cam_label, label, view_label, img_path, mode, writer, epoch)
+        finally:
+            fn.set_model_options(grad_enabled=True)
+
+    def _forward(self, x, cam_label=None, label=None, view_label=None, img_path=None, mode=1, writer=None, epoch=None):
         mods = [x[m_[0]].contiguous() for m_ in self.modalities]             # make_model.py:153-155
         rgb = mods[0]
         nmod = self.nmod

@@ -146,16 +146,20 @@ def _ln(x, sd, prefix, eps):
 
 
 def _drop_path(x, keep_mask, keep_prob):
-    """drop_path with a teacher-forced per-sample keep mask (vit_pytorch.py:52-69)."""
+    """drop_path with a teacher-forced per-sample keep mask (vit_pytorch.py:52-69): `x.div(keep_prob) * random_tensor`,
+    random_tensor = floor(keep_prob + U[0,1)) of shape (B,1,1) - here handed in as the 0/1 mask the draw produced."""
     if keep_mask is None:
         return x
-    return x / keep_prob * keep_mask.view(-1, 1, 1)
+    return x.div(keep_prob) * keep_mask.view(-1, 1, 1)
 
 
 def vit_block(x, sd, p, heads, eps=1e-6, keep=None, keep_prob=1.0, qk_scale=None):
-    """Block.forward(get_att=True) (vit_pytorch.py:215-220) with Attention (:184-198), Mlp (:139-145)."""
+    """Block.forward(get_att=True) (vit_pytorch.py:215-220) with Attention (:184-198), Mlp (:139-145).
+    keep: None or a (2, B) pair of 0/1 masks - the reference calls self.drop_path TWICE per block (:217 attention branch,
+    :218 MLP branch), each call drawing its own torch.rand((B,1,1))."""
     b, t, d = x.shape
     hd = d // heads
+    keep_a, keep_m = (None, None) if keep is None else (keep[0], keep[1])
     h = _ln(x, sd, p + ".norm1", eps)
     qkv = F.linear(h, sd[p + ".attn.qkv.weight"], sd.get(p + ".attn.qkv.bias"))
     qkv = qkv.reshape(b, t, 3, heads, hd).permute(2, 0, 3, 1, 4)
@@ -164,18 +168,19 @@ def vit_block(x, sd, p, heads, eps=1e-6, keep=None, keep_prob=1.0, qk_scale=None
     attn = attn.softmax(dim=-1)
     o = (attn @ v).transpose(1, 2).reshape(b, t, d)
     o = F.linear(o, sd[p + ".attn.proj.weight"], sd.get(p + ".attn.proj.bias"))
-    x = x + _drop_path(o, keep, keep_prob)
+    x = x + _drop_path(o, keep_a, keep_prob)
     h = _ln(x, sd, p + ".norm2", eps)
     h = F.linear(h, sd[p + ".mlp.fc1.weight"], sd.get(p + ".mlp.fc1.bias"))
     h = F.gelu(h)                                            # nn.GELU() default = exact erf
     h = F.linear(h, sd[p + ".mlp.fc2.weight"], sd.get(p + ".mlp.fc2.bias"))
-    x = x + _drop_path(h, keep, keep_prob)
+    x = x + _drop_path(h, keep_m, keep_prob)
     return x, attn
 
 
 def vit_forward(sd, img, cam, heads=12, sie_coef=3.0, prefix="BACKBONE.base", drop_keep=None,
                 drop_rates=None, qk_scale=None):
-    """Trans.forward (vit_pytorch.py:623-644).  drop_keep: optional (depth, B) 0/1 keep masks."""
+    """Trans.forward (vit_pytorch.py:623-644).  drop_keep: optional (depth, 2, B) 0/1 keep masks - [layer, branch
+    (0 = attention, 1 = MLP), sample]; a block whose rate is 0 holds nn.Identity (:209) and draws nothing."""
     w = sd[prefix + ".patch_embed.proj.weight"]
     x = F.conv2d(img, w, sd[prefix + ".patch_embed.proj.bias"], stride=w.shape[-1])
     x = x.flatten(2).transpose(1, 2)
@@ -191,7 +196,7 @@ def vit_forward(sd, img, cam, heads=12, sie_coef=3.0, prefix="BACKBONE.base", dr
     for i in range(depth):
         keep, kp = None, 1.0
         if drop_keep is not None and drop_rates is not None and drop_rates[i] > 0:
-            keep, kp = drop_keep[i].to(x.dtype), 1.0 - drop_rates[i]
+            keep, kp = drop_keep[i].to(x.dtype), 1 - drop_rates[i]       # vit_pytorch.py:64: keep_prob = 1 - drop_prob (python floats)
         x, a = vit_block(x, sd, f"{prefix}.blocks.{i}", heads, 1e-6, keep, kp, qk_scale)
         attns.append(a)
     return _ln(x, sd, prefix + ".norm", 1e-6), attns
@@ -322,7 +327,9 @@ def editor_forward(sd, x, cam, label=None, training=False, al=1, head_keep=2, fr
                    teacher_index=None, return_aux=False, modalities=MODALITIES3, qk_scale=None):
     """EDITOR.forward (make_model.py:150-258).  `sd` maps state-dict names to tensors (leaf
     tensors requiring grad for a backward run; BN running stats / OCFR centres are mutated).
-    teacher_index: optional (B,N) bool to force the SFTS selection (bf16 protocol)."""
+    teacher_index: optional (B,N) bool to force the SFTS selection (bf16 protocol).
+    drop_keep: optional (nmod, depth, 2, B) 0/1 stochastic-depth keep masks with drop_rates (depth) - the backbone runs once
+    per modality (make_model.py:158-160), every run draws its own masks, two per block (vit_pytorch.py:217-218)."""
     imgs = [x[m[0]] for m in modalities]
     nmod = len(imgs)
     aux = {}

@@ -89,9 +89,30 @@ def f2_f3_eval(preset="RGBNT201", seed=21, batch=4, tag="vitb"):
     save(f"f3_eval_{tag}", cls4t=cls4t, mask_fre=mask_fre, seed=seed, batch=batch, preset=preset, **rec)
 
 
-def f4_f5_train(preset, seed, batch, instances, tag, al=None):
-    """F4 full train tuple + loss parts + OCFR centre rows; F5 selected grads after one backward."""
-    over = dict(drop_path=0.0)
+class RecordRand:
+    """Records every torch.rand draw made while active (the reference's drop_path, vit_pytorch.py:66, is the only caller on
+    the forward path: `keep_prob + torch.rand((B,1,1))` once per block branch with a non-zero rate)."""
+
+    def __enter__(self):
+        self.draws, self._orig = [], torch.rand
+
+        def rand(*a, **k):
+            r = self._orig(*a, **k)
+            self.draws.append(r.detach().clone())
+            return r
+        torch.rand = rand
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self._orig
+
+
+def f4_f5_train(preset, seed, batch, instances, tag, al=None, drop_path=0.0):
+    """F4 full train tuple + loss parts + OCFR centre rows; F5 selected grads after one backward.
+    drop_path > 0: the reference's own stochastic depth, its torch.rand draws recorded in call order
+    (modality RGB, NI, TI - make_model.py:158-160 - x blocks 1..depth-1 x [attention branch, MLP branch], vit_pytorch.py:217-218)
+    and stored as the 0/1 keep masks `drop_keep` (3, depth, 2, B) they binarise to (block 0 has rate 0 -> nn.Identity, ones)."""
+    over = dict(drop_path=drop_path)
     if al is not None:
         over["al"] = al
     m, cfg, c, cams = build(preset, seed, **over)
@@ -102,7 +123,26 @@ def f4_f5_train(preset, seed, batch, instances, tag, al=None):
     m.SFTS.register_forward_hook(lambda mod, i, o: parts.__setitem__("loss_bcc", o[-1].detach().clone()))
     m.FUSE_block.register_forward_hook(lambda mod, i, o: parts.__setitem__("loss_ocfr", o[1].detach().clone()))
     wr = ref_shims.Writer()
-    out = m(img, label=label, cam_label=cam, view_label=view, img_path=None, writer=wr, epoch=1)
+    torch.manual_seed(1000 + seed)
+    with RecordRand() as rr:
+        out = m(img, label=label, cam_label=cam, view_label=view, img_path=None, writer=wr, epoch=1)
+    keep = {}
+    if drop_path > 0:
+        base = m.BACKBONE.base
+        depth = len(base.blocks)
+        rates = [blk.drop_path.drop_prob if hasattr(blk.drop_path, "drop_prob") else 0.0 for blk in base.blocks]
+        live = [i for i, r in enumerate(rates) if r > 0]
+        assert len(rr.draws) == 3 * len(live) * 2 and all(tuple(d.shape) == (batch, 1, 1) for d in rr.draws), len(rr.draws)
+        dk = torch.ones(3, depth, 2, batch)
+        it = iter(rr.draws)
+        for mod in range(3):
+            for i in live:
+                for br in range(2):
+                    dk[mod, i, br] = ((1 - rates[i]) + next(it)).floor().view(-1)      # vit_pytorch.py:64-67
+        assert 0 < (dk == 0).sum() < dk.numel() // 4
+        keep = {"drop_keep": dk.to(torch.uint8), "drop_rates": np.asarray(rates, dtype=np.float64)}
+    else:
+        assert not rr.draws
     sys.path.insert(0, os.path.join(ROOT))
     from oracle.editor_ref import projection_loss
     loss = projection_loss(out)
@@ -136,7 +176,7 @@ def f4_f5_train(preset, seed, batch, instances, tag, al=None):
            for t in ("RGB", "NIR", "TIR")}
     bn = {"bn_mean": m.FUSE_BN.running_mean[:64], "bn_var": m.FUSE_BN.running_var[:64]}
     save(f"f4_train_{tag}", loss=loss, num_count=wr.scalars["num_count"], seed=seed, batch=batch,
-         instances=instances, preset=preset, al=cfg.MODEL.AL, **rec, **parts, **grads, **cen, **bn)
+         instances=instances, preset=preset, al=cfg.MODEL.AL, **rec, **parts, **grads, **cen, **bn, **keep)
 
 
 def f6_blocks(seed=41):
@@ -165,6 +205,9 @@ if __name__ == "__main__":
     if "f4" in which:
         f4_f5_train("RGBNT201", 31, 16, 8, "vitb_al1")
         f4_f5_train("RGBNT100", 33, 16, 8, "vitb_al0")
+    if "f4dp" in which:                               # stochastic depth ON (the benchmarked workload's DROP_PATH = 0.1), B = 32
+        f4_f5_train("RGBNT100", 37, 32, 16, "vitb_al0_dp01", drop_path=0.1)
+        f4_f5_train("RGBNT201", 39, 16, 8, "vitb_al1_dp01", drop_path=0.1)
     if "f4c4" in which:                               # BASELINE config 4 geometry: 384x128 (T = 193), AL = 0, train
         f4_f5_train("MSVR310", 35, 16, 8, "vitb_384x128")
     if "f6" in which:

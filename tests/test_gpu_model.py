@@ -52,11 +52,18 @@ def test_eval_parity_f32(tag, preset):
     assert rel_err(cls4t.cpu(), g["cls4t"]) < 1e-3
 
 
-@pytest.mark.parametrize("tag,preset", [("vitb_al1", "RGBNT201"), ("vitb_al0", "RGBNT100"), ("vitb_384x128", "MSVR310")])
+@pytest.mark.parametrize("tag,preset", [("vitb_al1", "RGBNT201"), ("vitb_al0", "RGBNT100"), ("vitb_384x128", "MSVR310"),
+                                        ("vitb_al0_dp01", "RGBNT100"), ("vitb_al1_dp01", "RGBNT201")])
 def test_train_parity_f32(tag, preset, oracle):
+    """*_dp01: the REFERENCE's own training step with DROP_PATH = 0.1 (B = 32 / 16); its recorded torch.rand keep masks are
+    teacher-forced into the step (EDITOR.teacher_drop_keep), everything else - outputs, losses, gradients - must follow."""
     g = load_golden("f4_train_" + tag)
     seed, batch, inst = int(g["seed"]), int(g["batch"]), int(g["instances"])
-    m, cfg, c, cams = _model(preset, seed, "f32", drop_path=0.0)
+    dp = 0.1 if tag.endswith("dp01") else 0.0
+    m, cfg, c, cams = _model(preset, seed, "f32", drop_path=dp)
+    if dp:
+        assert m.BACKBONE.base.drop_rates == [float(r) for r in g["drop_rates"]]
+        m.teacher_drop_keep = t(g["drop_keep"])
     m.train()
     h, w = cfg.INPUT.SIZE_TRAIN
     img, label, cam, view = _cuda_batch(*synth.make_batch(seed + 1, batch, h, w, cams, instances=inst))

@@ -46,11 +46,22 @@ def test_f3_eval(oracle, tag, preset):
     assert rel_err(cls4t, g["cls4t"]) < 1e-5
 
 
-@pytest.mark.parametrize("tag,preset", [("vitb_al1", "RGBNT201"), ("vitb_al0", "RGBNT100")])
+@pytest.mark.parametrize("tag,preset", [("vitb_al1", "RGBNT201"), ("vitb_al0", "RGBNT100"),
+                                        ("vitb_al0_dp01", "RGBNT100"), ("vitb_al1_dp01", "RGBNT201")])
 def test_f4_train_and_grads(oracle, tag, preset):
+    """*_dp01: the reference run with DROP_PATH = 0.1 (the benchmarked workload's setting); the fixture holds the keep masks
+    its torch.rand draws binarised to (two per block and modality, vit_pytorch.py:217-218) - this pins the oracle's
+    stochastic-depth restatement (per-branch masks, x.div(keep_prob) * mask) to the reference's own output and gradients."""
     g = load_golden("f4_train_" + tag)
     seed, batch, inst = int(g["seed"]), int(g["batch"]), int(g["instances"])
-    sd, cfg, c, cams = _state_dict(preset, seed, drop_path=0.0)
+    dp = 0.1 if tag.endswith("dp01") else 0.0
+    sd, cfg, c, cams = _state_dict(preset, seed, drop_path=dp)
+    drop = {}
+    if dp:
+        rates = [x.item() for x in torch.linspace(0, dp, 12)]                 # vit_pytorch.py:511
+        assert rates == [float(r) for r in g["drop_rates"]]
+        drop = dict(drop_keep=torch.from_numpy(g["drop_keep"]).float(), drop_rates=rates)
+        assert tuple(drop["drop_keep"].shape) == (3, 12, 2, batch)
     leaves = {}
     for k, v in sd.items():
         if v.is_floating_point() and "centers" not in k and "running" not in k and not k.startswith("FREQ"):
@@ -58,7 +69,7 @@ def test_f4_train_and_grads(oracle, tag, preset):
             leaves[k] = v
     h, w = cfg.INPUT.SIZE_TRAIN
     img, label, cam, view = synth.make_batch(seed + 1, batch, h, w, cams, instances=inst)
-    out, aux = oracle.editor_forward(sd, img, cam, label=label, training=True, al=int(g["al"]), return_aux=True)
+    out, aux = oracle.editor_forward(sd, img, cam, label=label, training=True, al=int(g["al"]), return_aux=True, **drop)
     for i, o in enumerate(out):
         assert rel_err(o, g["out%d" % i]) < 1e-5, i
     assert rel_err(aux["loss_bcc"], g["loss_bcc"]) < 1e-5
