@@ -83,6 +83,9 @@ struct GemmB16Args {
     int stagger;                             // EDITOR_EPI_STAGGER(c): the first round's workgroups start spread over c * 2048 cycles (ping-pong kernel)
     int ablate;                              // debug build only (EDITOR_GEMM_ABLATE, tools/gemm_bound_probe.py): 1 = no LDS-DMA inside the
                                              // K loop, 2 = no MFMAs, 4 = no fragment reads - what each costs, by deletion
+    const int* rowmap;                       // EDITOR_EPI_RESIDUAL, fp32 C (editor_gemm_h16_rows): output row m lands in row rowmap[m] of
+                                             // C / aux / rowscale - the product ran on COMPACTED token rows (stochastic-depth: live samples
+                                             // first, editor_droppath_plan) and its residual epilogue scatters them back
 };
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: remember it per device index, so a
@@ -427,8 +430,10 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
 #pragma unroll
             for (int it = 0; it < ITERS / 2; ++it) {
                 const int c = threadIdx.x + (half * (ITERS / 2) + it) * NTHREADS;
-                const int m = min(m0 + c / GPR, g.M - 1), n = min(n0 + (c % GPR) * 8, g.N - 8);
+                int m = min(m0 + c / GPR, g.M - 1);
+                const int n = min(n0 + (c % GPR) * 8, g.N - 8);
                 if (EPI == EDITOR_EPI_RESIDUAL) {
+                    if (g.rowmap) m = g.rowmap[m];
                     const float* r = reinterpret_cast<const float*>(g.aux) + (long)m * g.ldaux + n;
                     ra[it] = *reinterpret_cast<const float4*>(r); rb[it] = *reinterpret_cast<const float4*>(r + 4);
                 } else {
@@ -447,8 +452,10 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
         for (int it = 0; it < ITERS / 2; ++it) {
             const int c = threadIdx.x + (half * (ITERS / 2) + it) * NTHREADS;
             const int row = c / GPR, cg = c % GPR;
-            const int m = m0 + row, n = n0 + cg * 8;
+            int m = m0 + row;
+            const int n = n0 + cg * 8;
             if (m >= mlim || n >= g.N) continue;                 // N is a multiple of 8 on this path (checked on the host)
+            if (EPI == EDITOR_EPI_RESIDUAL && g.rowmap) m = g.rowmap[m];     // (compacted rows: scatter back, see GemmB16Args)
             float x[8] = {lo[it].x, lo[it].y, lo[it].z, lo[it].w, hi[it].x, hi[it].y, hi[it].z, hi[it].w};
             const float rs = g.rowscale ? g.rowscale[m] : 1.f;
             float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -868,21 +875,38 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
     constexpr int UA0 = 0, UA1 = UNIT, UB0 = 2 * UNIT, UB1 = 3 * UNIT;
     constexpr int GM = EDITOR_GEMM_GM;                          // tile rows per group (measured: tools/gm_sweep.sh)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int wgid = g.linear_ids ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int grp = GM * g.tiles_n;
-    const int gm0 = (wgid / grp) * GM, rem = wgid % grp;
-    const int gsz = min(GM, g.tiles_m - gm0);
-    const int tile_m = gm0 + rem % gsz;
-    const int tile_n = rem / gsz;
-    const int m0 = tile_m * TH, n0 = tile_n * 256;
+    // live rows (device scalar): the launch is sized for M, only the tiles of the first *m_live rows do work.  The tile order is built
+    // over the LIVE tile rows - the first tiles_m_live * tiles_n workgroups of the launch take them, spread over the XCDs like a launch
+    // of that size, the rest exit - not over all of them with the dead ones skipped: the XCD-contiguous ranges below would leave every
+    // dead tile on the last XCDs and the others with their full share (measured, round 6: 5 % fewer live tiles, same launch time).
+    int tiles_m = g.tiles_m;
     int ktiles = g.K / BK;
     if (g.m_live) {
         const int live = *g.m_live;
         if (g.live_is_k) ktiles = min(ktiles, (live + BK - 1) / BK);
-        else if (m0 >= live) return;
+        else if (!g.linear_ids) tiles_m = min(tiles_m, (live + TH - 1) / TH);
     }
+    const int nwg = tiles_m * g.tiles_n;
+    if (!g.linear_ids && bid >= nwg) {
+        // a workgroup beyond the live tiles: nothing to compute; the dead tile rows' column-sum partials are part of the fold, so
+        // these workgroups zero them ((g.tiles_m - tiles_m) * N floats, a few KiB)
+        if (g.colsum) {
+            const long n_dead = (long)(g.tiles_m - tiles_m) * g.N;
+            const long first = (long)tiles_m * g.N;
+            for (long e = (long)(bid - nwg) * 512 + threadIdx.x; e < n_dead; e += (long)(g.tiles_m * g.tiles_n - nwg) * 512)
+                g.colsum[first + e] = 0.f;
+        }
+        return;
+    }
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wgid = g.linear_ids ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int grp = GM * g.tiles_n;
+    const int gm0 = (wgid / grp) * GM, rem = wgid % grp;
+    const int gsz = min(GM, tiles_m - gm0);
+    const int tile_m = gm0 + rem % gsz;
+    const int tile_n = rem / gsz;
+    const int m0 = tile_m * TH, n0 = tile_n * 256;
+    if (g.m_live && !g.live_is_k && g.linear_ids && m0 >= *g.m_live) return;     // (grouped launches: static tile ranges per problem)
     // EDITOR_EPI_STAGGER: every tile of a launch takes the same time, so the 256 CUs run in LOCKSTEP - all in their K loops (matrix
     // cores busy, HBM idle), then all in their epilogues (HBM saturated: every epilogue kind measures ~12 B per clock and CU = the
     // chip's HBM rate, matrix cores idle).  The first round's workgroups (one per CU) therefore start spread over `stagger` cycles,
@@ -1678,7 +1702,8 @@ int launch_pipe(const GemmB16Args& g, hipStream_t stream)
 template <bool F16>
 int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda,
     long ldb, long ldc, int transA, int transB, float alpha, float beta, const float* bias, const float* rowscale,
-    int splitk, int epilogue, void* aux, long ldaux, float* splitk_ws, const int* m_live, hipStream_t stream)
+    int splitk, int epilogue, void* aux, long ldaux, float* splitk_ws, const int* m_live, hipStream_t stream,
+    const int* rowmap = nullptr)
 {
     if (M <= 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
     // 16-byte vector accesses: leading dimensions and the contiguous extents must be multiples of 8 bf16
@@ -1699,8 +1724,13 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
     epilogue &= ~(EDITOR_EPI_COLSUM | EDITOR_EPI_FORCE_PP | EDITOR_EPI_AUX_GRAD | EDITOR_EPI_PIPE128 | 0xF000 | EDITOR_EPI_STAGGER(63));
     if (aux_grad && epilogue != EDITOR_EPI_GELU && epilogue != EDITOR_EPI_GELU_BWD) return (int)hipErrorInvalidValue;
     if (want_colsum && (c_f32 || epilogue == EDITOR_EPI_RESIDUAL || splitk > 1 || !splitk_ws || transA || M < 2048 || N < 512 ||
-                        (N & 7) || (ldc & 7) || (ldaux & 7) || (K % BK) || beta != 0.f || m_live))
+                        (N & 7) || (ldc & 7) || (ldaux & 7) || (K % BK) || beta != 0.f))
         return (int)hipErrorInvalidValue;                        // the column sums exist in the one-pass 256x256 epilogue only
+    // (with m_live: the tiles beyond the live rows zero their partial row, the rows of the last live tile beyond *m_live are
+    //  the caller's zero rows by contract - stochastic-depth compaction, editor_droppath_plan)
+    if (rowmap && (!c_f32 || (epilogue & 0xFF) != EDITOR_EPI_RESIDUAL || transA || transB || splitk > 1 || (N & 7) || (ldc & 7) ||
+                   (ldaux & 7) || (K % BK) || beta != 0.f || M < 256 || N < 256))
+        return (int)hipErrorInvalidValue;                        // row scatter: the staged fp32 residual epilogue of the 256x256 kernel
     // (aux may be NULL for EDITOR_EPI_GELU: a no-grad forward - model.eval() / do_inference - saves nothing for a backward)
     if (epilogue != EDITOR_EPI_NONE && ((!aux && epilogue != EDITOR_EPI_GELU) || (ldaux & 3) || splitk > 1)) return (int)hipErrorInvalidValue;
     if (splitk < 1) splitk = 1;
@@ -1726,7 +1756,8 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
                   slabs ? 0.f : beta, bias, rowscale, splitk, (M + BM - 1) / BM, (N + BN - 1) / BN, epilogue, aux, ldaux,
                   slabs ? 1 : 0,
                   m_live, transA ? 1 : 0, 0, want_colsum ? splitk_ws : nullptr, nullptr, force_pp ? 1 : 0, aux_grad ? 1 : 0,
-                  tile_frags, nullptr, nullptr, nullptr, 0, prefer_pipe ? 1 : 0, stagger};
+                  tile_frags, nullptr, nullptr, nullptr, 0, prefer_pipe ? 1 : 0, stagger, 0, rowmap};
+    if (rowmap) g.force_pp = 1;
     if (m_live && (!pipe || (splitk > 1 && !slabs))) return (int)hipErrorInvalidValue;   // live-row form: pipelined path only
     const int sel = (transA ? 0 : 4) | (transB ? 0 : 2) | (c_f32 ? 1 : 0);
     int rc;
@@ -1799,7 +1830,8 @@ int gemm_f16x2(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi,
 // ws: splitk * sum_i N_i K_i floats of slabs; fixed-order reduction per problem afterwards (deterministic).
 template <bool F16>
 int gemm_wgrad_group(int count, const uint16_t* const* dy, const uint16_t* const* x, float* const* dw, const int* N, const int* K,
-                     int M, float alpha, int splitk, float* ws, const int* m_live, hipStream_t stream, const LnRoleArgs* ln = nullptr)
+                     int M, float alpha, int splitk, float* ws, const int* m_live, hipStream_t stream, const LnRoleArgs* ln = nullptr,
+                     const int* const* m_live_each = nullptr)
 {
     if (count < 1 || count > kMaxGroup || M < 64 || (M % 64) || splitk < 1 || !ws) return (int)hipErrorInvalidValue;
     GemmGroupArgs ga;
@@ -1817,7 +1849,7 @@ int gemm_wgrad_group(int count, const uint16_t* const* dy, const uint16_t* const
         // output (N_i, K_i); "A" = dy stored (Kred = M, N_i) row-k, "B" = x stored (Kred = M, K_i) row-k
         GemmB16Args g{(const bf16_t*)dy[i], (const bf16_t*)x[i], (void*)slab[i], N[i], K[i], M, (long)N[i], (long)K[i], (long)K[i],
                       alpha, 0.f, nullptr, nullptr, splitk, N[i] / 256, K[i] / 256, EDITOR_EPI_NONE, nullptr, (long)K[i], 1,
-                      m_live, 1, 1, nullptr, nullptr, 1, 0, 0, nullptr, nullptr, nullptr, 1};
+                      m_live_each ? m_live_each[i] : m_live, 1, 1, nullptr, nullptr, 1, 0, 0, nullptr, nullptr, nullptr, 1};
         ga.p[i] = g;
         ga.start[i] = tiles;
         tiles += g.tiles_m * g.tiles_n;
@@ -1995,6 +2027,17 @@ extern "C" int editor_gemm_wgrad_group(int dtype, int count, const uint16_t* con
     return (int)hipErrorInvalidValue;
 }
 
+// editor_gemm_wgrad_group with a live-row count PER PROBLEM (m_live: host array of `count` device scalars, NULL entries = all M rows):
+// a block whose MLP branch ran on compacted rows (stochastic depth, editor_droppath_plan) next to its dense attention branch
+extern "C" int editor_gemm_wgrad_group_live(int dtype, int count, const uint16_t* const* dy, const uint16_t* const* x, float* const* dw,
+    const int* N, const int* K, int M, float alpha, int splitk, float* ws, const int* const* m_live, hipStream_t stream)
+{
+    if (!m_live) return (int)hipErrorInvalidValue;
+    if (dtype == 2) return gemm_wgrad_group<true>(count, dy, x, dw, N, K, M, alpha, splitk, ws, nullptr, stream, nullptr, m_live);
+    if (dtype == 1) return gemm_wgrad_group<false>(count, dy, x, dw, N, K, M, alpha, splitk, ws, nullptr, stream, nullptr, m_live);
+    return (int)hipErrorInvalidValue;
+}
+
 extern "C" int editor_gemm_wgrad_group_ln(int dtype, int count, const uint16_t* const* dy, const uint16_t* const* x, float* const* dw,
     const int* N, const int* K, int M, float alpha, int splitk, float* ws,
     const uint16_t* ln_dy, float ln_dy_scale, const float* ln_x, const float* gamma, const float* mean, const float* rstd, long ln_M,
@@ -2037,4 +2080,17 @@ extern "C" int editor_gemm_f16(const uint16_t* A, const uint16_t* B, void* C, in
 {
     return gemm_h16<true>(A, B, C, c_f32, M, N, K, lda, ldb, ldc, transA, transB, alpha, beta, bias, rowscale, splitk, epilogue,
                           aux, ldaux, splitk_ws, m_live, stream);
+}
+
+// editor_gemm_bf16 / _f16 (dtype 1 / 2) with an output ROW MAP (EDITOR_EPI_RESIDUAL, fp32 C, both operands k-major): see GemmB16Args::rowmap
+extern "C" int editor_gemm_h16_rows(int dtype, const uint16_t* A, const uint16_t* B, void* C, int M, int N, int K, long lda, long ldb,
+    long ldc, float alpha, const float* bias, const float* rowscale, int epilogue, void* aux, long ldaux, const int* m_live,
+    const int* rowmap, hipStream_t stream)
+{
+    if (!rowmap) return (int)hipErrorInvalidValue;
+    if (dtype == 2) return gemm_h16<true>(A, B, C, 1, M, N, K, lda, ldb, ldc, 0, 0, alpha, 0.f, bias, rowscale, 1, epilogue, aux, ldaux,
+                                          nullptr, m_live, stream, rowmap);
+    if (dtype == 1) return gemm_h16<false>(A, B, C, 1, M, N, K, lda, ldb, ldc, 0, 0, alpha, 0.f, bias, rowscale, 1, epilogue, aux, ldaux,
+                                           nullptr, m_live, stream, rowmap);
+    return (int)hipErrorInvalidValue;
 }

@@ -113,6 +113,62 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// LayerNorm forward onto COMPACTED rows (round 6: stochastic depth, vit_pytorch.py:52-69,218): a branch whose drop-path draw
+// is 0 for a sample contributes x + 0 - its LayerNorm / fc1 / fc2 rows need not be computed.  editor_droppath_plan orders the
+// token rows of a (block, branch) live samples first; this kernel writes row r's output to row perm[r] of y, so that the
+// products that follow run on the live prefix (m_live) only.  A dead row (rowscale[r] == 0) writes ZEROS to its slot (rows
+// [live, ...) of y are zero by contract: the partly live last tile and the weight gradient's last reduction tile read them) and
+// copies its x row to copy_out - the block output of a dropped sample is its input (the fc2 epilogue scatters the live rows
+// only).  mean / rstd stay indexed by the original row.  Same per-row arithmetic as layernorm_fwd_kernel.  D % 256 == 0.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_perm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, long M, int D, T* __restrict__ y, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out, const int* __restrict__ perm, const float* __restrict__ rowscale, float* __restrict__ copy_out)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 8;
+    const float* xr = x + row * D;
+    const bool dead = rowscale[row] == 0.f;
+    float4 v[kMaxV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+        v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    T* yr = y + (long)perm[row] * D;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+        const int c0 = (i * 64 + lane) * 4;
+        if (dead) {
+            Vec4<T>::st(yr + c0, make_float4(0.f, 0.f, 0.f, 0.f));
+            *reinterpret_cast<float4*>(copy_out + row * D + c0) = v[i];
+            continue;
+        }
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c0);
+        const float4 bt = *reinterpret_cast<const float4*>(beta + c0);
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * g.x + bt.x;
+        o.y = (v[i].y - mean) * rstd * g.y + bt.y;
+        o.z = (v[i].z - mean) * rstd * g.z + bt.z;
+        o.w = (v[i].w - mean) * rstd * g.w + bt.w;
+        Vec4<T>::st(yr + c0, o);
+    }
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Residual add + LayerNorm forward in one pass (round 4, bf16 mode):  x_out = x + rowscale[row] * branch,  y = LN(x_out).
 // `branch` is the 16-bit output of the projection / fc2 product written with the PLAIN epilogue: the residual add leaves the
 // GEMM's fp32 epilogue - 512 KiB of HBM-miss traffic per 256 x 256 tile at the ~10 B/clk a CU that is owned by one workgroup can
@@ -182,12 +238,17 @@ __device__ __forceinline__ float round_like(float v, f16_t) { return f16_to_f32(
 // ------------------------------------------------------------------------------------------------
 // NV = D / 256 (float4 column groups per lane) and CAST (the second output) are compile-time: with worst-case-sized arrays
 // and the cast accumulators always present the kernel needed 150 registers (3 waves per SIMD) instead of <= 128.
-template <typename T, int NV, bool CAST, bool RAGGED = false>       // RAGGED: NV = ceil(D / 256), last group guarded (see the forward)
+// PERM (round 6, stochastic-depth compaction - see layernorm_fwd_perm_kernel): dy may live on compacted rows (row r's gradient at row
+// dy_perm[r]; a row whose slot is >= *dy_live belongs to a dropped sample: its gradient is zero and is NOT read - the products
+// behind it skipped those tiles), and the cast output may go to compacted rows of the consumer branch (cast_perm[r]; a dropped
+// row writes the zero its row scale makes of it).  A separate instantiation: the dense path keeps its code.
+template <typename T, int NV, bool CAST, bool RAGGED = false, bool PERM = false>       // RAGGED: NV = ceil(D / 256), last group guarded (see the forward)
 __global__ __launch_bounds__(256, NV <= 3 ? 4 : 3) void layernorm_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ mean_in, const float* __restrict__ rstd_in, long M, int D,
     const uint8_t* __restrict__ rowmask, int mask_period, const float* __restrict__ dx_in, float* __restrict__ dx_out,
     float* __restrict__ partials, const int* __restrict__ m_live, float dy_scale, T* __restrict__ cast_out,
-    const float* __restrict__ cast_rowscale, float cast_scale, float* __restrict__ cast_partials)
+    const float* __restrict__ cast_rowscale, float cast_scale, float* __restrict__ cast_partials,
+    const int* __restrict__ dy_perm = nullptr, const int* __restrict__ dy_live = nullptr, const int* __restrict__ cast_perm = nullptr)
 {
     __shared__ float red[4][2][1024];
     if (m_live) M = min(M, (long)((*m_live + 63) & ~63));
@@ -199,8 +260,14 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 3) void layernorm_bwd_kernel(con
         if (CAST) ccs[i] = dg[i];
         g[i] = (!RAGGED || (i * 64 + lane) * 4 < D) ? *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4) : dg[i];
     }
+    const long dlive = (PERM && dy_live) ? (long)*dy_live : 0L;
     for (long row = (long)blockIdx.x * 4 + w; row < M; row += (long)gridDim.x * 4) {
-        const bool keep = !(rowmask && !rowmask[mask_period ? row % mask_period : row]);
+        bool keep = !(rowmask && !rowmask[mask_period ? row % mask_period : row]);
+        long drow = row, crow = row;
+        if constexpr (PERM) {
+            if (dy_perm) { drow = dy_perm[row]; keep = drow < dlive; }
+            if (cast_perm) crow = cast_perm[row];
+        }
         const float mean = mean_in[row], rstd = rstd_in[row];
         float4 xh[NV], d[NV];
         float s1 = 0.f, s2 = 0.f;
@@ -209,7 +276,7 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 3) void layernorm_bwd_kernel(con
             const int c0 = (i * 64 + lane) * 4;
             if (RAGGED && c0 >= D) { xh[i] = make_float4(0.f, 0.f, 0.f, 0.f); d[i] = xh[i]; continue; }   // (adds zeros to every sum)
             const float4 xv = *reinterpret_cast<const float4*>(x + row * D + c0);
-            d[i] = keep ? Vec4<T>::ld(dy + row * D + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            d[i] = keep ? Vec4<T>::ld(dy + drow * D + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
             d[i].x *= dy_scale; d[i].y *= dy_scale; d[i].z *= dy_scale; d[i].w *= dy_scale;   // (loss-scaled f16 gradients)
             xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
             dg[i].x += d[i].x * xh[i].x; dg[i].y += d[i].y * xh[i].y; dg[i].z += d[i].z * xh[i].z; dg[i].w += d[i].w * xh[i].w;
@@ -237,7 +304,7 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 3) void layernorm_bwd_kernel(con
             if constexpr (CAST) {
                 const float r = (cast_rowscale ? cast_rowscale[row] : 1.f) * cast_scale;
                 o.x *= r; o.y *= r; o.z *= r; o.w *= r;
-                Vec4<T>::st(cast_out + row * D + c0, o);
+                Vec4<T>::st(cast_out + crow * D + c0, o);
                 ccs[i].x += round_like(o.x, T{}); ccs[i].y += round_like(o.y, T{});
                 ccs[i].z += round_like(o.z, T{}); ccs[i].w += round_like(o.w, T{});
             }
@@ -378,7 +445,7 @@ __global__ void cast_rows_kernel(const float* __restrict__ in, const float* __re
 // per-block partial rows -> reduce_rows_kernel (fixed order).  D a multiple of 256, D <= 256 * kMaxV.
 template <typename TO>
 __global__ __launch_bounds__(256) void cast_rows_colsum_kernel(const float* __restrict__ in, const float* __restrict__ rowscale,
-    long M, int D, TO* __restrict__ out, float* __restrict__ partials, float scale)
+    long M, int D, TO* __restrict__ out, float* __restrict__ partials, float scale, const int* __restrict__ perm = nullptr)
 {
     __shared__ float red[4][256 * kMaxV];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -388,12 +455,13 @@ __global__ __launch_bounds__(256) void cast_rows_colsum_kernel(const float* __re
     for (int i = 0; i < kMaxV; ++i) cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long row = (long)blockIdx.x * 4 + w; row < M; row += (long)gridDim.x * 4) {
         const float r = (rowscale ? rowscale[row] : 1.f) * scale;
+        const long orow = perm ? (long)perm[row] : row;          // (compacted consumer rows, see layernorm_fwd_perm_kernel)
 #pragma unroll
         for (int i = 0; i < kMaxV; ++i) if (i < nv) {
             const int c0 = (i * 64 + lane) * 4;
             float4 v = *reinterpret_cast<const float4*>(in + row * D + c0);
             v.x *= r; v.y *= r; v.z *= r; v.w *= r;
-            Vec4<TO>::st(out + row * D + c0, v);
+            Vec4<TO>::st(out + orow * D + c0, v);
             cs[i].x += round_like(v.x, TO{}); cs[i].y += round_like(v.y, TO{});
             cs[i].z += round_like(v.z, TO{}); cs[i].w += round_like(v.w, TO{});
         }
@@ -746,7 +814,8 @@ namespace {
 int layernorm_bwd_impl(const void* dy, int dy_bf16, float dy_scale, const float* x, const float* gamma, const float* mean,
     const float* rstd, long M, int D, const uint8_t* rowmask, int mask_period, const float* dx_in, float* dx_out,
     float* dgamma, float* dbeta, float* workspace, int ws_rows, const int* m_live, void* cast_out, const float* cast_rowscale,
-    float cast_scale, float* cast_colsum, float cast_colsum_scale, hipStream_t stream, int* nparts = nullptr)
+    float cast_scale, float* cast_colsum, float cast_colsum_scale, hipStream_t stream, int* nparts = nullptr,
+    const int* dy_perm = nullptr, const int* dy_live = nullptr, const int* cast_perm = nullptr)
 {
     // nparts != NULL: the "_parts" form - the partial rows stay in the workspace ([P][2][D] at its start, the cast output's column
     // sums [P][D] behind ws_rows*2*D floats), *nparts = P, and the caller folds them (editor_reduce_rows_multi)
@@ -758,6 +827,19 @@ int layernorm_bwd_impl(const void* dy, int dy_bf16, float dy_scale, const float*
 #define LN_BWD_LAUNCH(NVv, CASTv) DISPATCH_T(dy_bf16, hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NVv, CASTv>), dim3((unsigned)blocks), \
         dim3(256), 0, stream, (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out,                            \
         dgamma ? workspace : nullptr, m_live, dy_scale, (TT*)cast_out, cast_rowscale, cast_scale, cast_partials))
+    if (dy_perm || cast_perm) {          // compacted rows (stochastic depth): the cast form on dense 16-bit rows, D = 768 / 1024
+        if (!cast_out || (dy_perm && !dy_live)) return (int)hipErrorInvalidValue;
+#define LN_BWD_PERM(NVv) DISPATCH_T(dy_bf16, hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NVv, true, false, true>), dim3((unsigned)blocks), \
+        dim3(256), 0, stream, (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out,                            \
+        dgamma ? workspace : nullptr, m_live, dy_scale, (TT*)cast_out, cast_rowscale, cast_scale, cast_partials, dy_perm, dy_live, cast_perm))
+        switch (D >> 8) {
+            case 1: LN_BWD_PERM(1); break;
+            case 2: LN_BWD_PERM(2); break;
+            case 3: LN_BWD_PERM(3); break;
+            default: LN_BWD_PERM(4); break;
+        }
+#undef LN_BWD_PERM
+    } else
     if (D % 256) {                       // ragged width (384): guarded instantiations, no cast output
 #define LN_BWD_RAGGED(NVv) DISPATCH_T(dy_bf16, hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NVv, false, true>), dim3((unsigned)blocks), \
         dim3(256), 0, stream, (const TT*)dy, x, gamma, mean, rstd, M, D, rowmask, mask_period, dx_in, dx_out,                            \
@@ -909,6 +991,31 @@ extern "C" int editor_layernorm_bwd_cast_parts(const void* dy, int dy_bf16, floa
                               1.f, stream, nparts);
 }
 
+// editor_layernorm_bwd_cast_parts on COMPACTED rows (stochastic depth, editor_droppath_plan): dy_perm / dy_live - dy lives on the
+// compacted rows of this LayerNorm's branch (NULL: dense); cast_perm - the cast output goes to the compacted rows of the branch
+// that consumes it (NULL: dense).
+extern "C" int editor_layernorm_bwd_cast_perm_parts(const void* dy, int dy_bf16, float dy_scale, const float* x, const float* gamma,
+    const float* mean, const float* rstd, long M, int D, const float* dx_in, float* dx_out, float* workspace, int ws_rows,
+    void* cast_out, const float* cast_rowscale, float cast_scale, int want_colsum, const int* dy_perm, const int* dy_live,
+    const int* cast_perm, int* nparts, hipStream_t stream)
+{
+    if (!cast_out || !nparts || !workspace || (!dy_perm && !cast_perm)) return (int)hipErrorInvalidValue;
+    return layernorm_bwd_impl(dy, dy_bf16, dy_scale, x, gamma, mean, rstd, M, D, nullptr, 0, dx_in, dx_out, workspace, workspace + D,
+                              workspace, ws_rows, nullptr, cast_out, cast_rowscale, cast_scale, want_colsum ? workspace : nullptr,
+                              1.f, stream, nparts, dy_perm, dy_live, cast_perm);
+}
+
+extern "C" int editor_layernorm_fwd_perm(const float* x, const float* gamma, const float* beta, float eps, long M, int D, void* y,
+    int y_bf16, float* mean, float* rstd, const int* perm, const float* rowscale, float* copy_out, hipStream_t stream)
+{
+    if ((D & 255) || D > 256 * kMaxV || M <= 0 || !perm || !rowscale || !copy_out || !mean || !rstd || y_bf16 == 0)
+        return (int)hipErrorInvalidValue;
+    DISPATCH_T(y_bf16, hipLaunchKernelGGL(layernorm_fwd_perm_kernel<TT>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream,
+               x, gamma, beta, eps, M, D, (TT*)y, mean, rstd, perm, rowscale, copy_out));
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int editor_reduce_rows_multi(int count, const float* const* partials, const int* P, const long* ncol, float* const* out,
                                         const float* scale, hipStream_t stream)
 {
@@ -987,6 +1094,20 @@ extern "C" int editor_cast_rows(const float* in, const float* rowscale, long M, 
     DISPATCH_T(out_bf16, hipLaunchKernelGGL(cast_rows_kernel<TT>, dim3(grid_for(M * (D / 4))), dim3(256), 0, stream,
                in, rowscale, M, D, (TT*)out, m_live, scale));
     EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_cast_rows_colsum_perm_parts(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16,
+                                                  float* workspace, int ws_rows, float scale, const int* perm, int* nparts,
+                                                  hipStream_t stream)
+{
+    if ((D & 255) || D > 256 * kMaxV || ws_rows < 1 || !nparts || !workspace || !perm) return (int)hipErrorInvalidValue;
+    long blocks = (M + 3) / 4;
+    if (blocks > ws_rows) blocks = ws_rows;
+    DISPATCH_T(out_bf16, hipLaunchKernelGGL(cast_rows_colsum_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, stream,
+               in, rowscale, M, D, (TT*)out, workspace, scale, perm));
+    EDITOR_LAUNCH_CHECK();
+    *nparts = (int)blocks;
     return 0;
 }
 

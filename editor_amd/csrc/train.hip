@@ -222,6 +222,39 @@ __global__ void droppath_dev_kernel(const float* __restrict__ rates, int L, long
 }
 __global__ void advance_state_kernel(long* state) { state[0] += 1; }
 
+// Stochastic-depth COMPACTION plan (round 6): for every (block, branch) the token rows ordered live samples first - a sample
+// whose draw is 0 contributes nothing to the branch (vit_pytorch.py:66-68: x.div(keep_prob) * 0) and gets no gradient through
+// it, so the branch's LayerNorm / products / their backward run on the live prefix only.  One workgroup per (block, branch):
+//   perm[r]  = slot of token row r in the compacted order (live samples keep their relative order, dropped samples follow)
+//   inv[c]   = token row of slot c;   live = number of live ROWS (live samples x T).
+// Derived from the scales tensor itself (scale == 0 <=> dropped), so teacher-forced masks take the same path.
+__global__ __launch_bounds__(256) void droppath_plan_kernel(const float* __restrict__ scales, long B, int T, int* __restrict__ perm,
+                                                            int* __restrict__ inv, int* __restrict__ live)
+{
+    extern __shared__ int slot[];                              // [B] compacted sample position
+    const long u = blockIdx.x;                                 // (block, branch) unit
+    const float* sc = scales + u * B * T;
+    for (long s = threadIdx.x; s < B; s += blockDim.x) slot[s] = sc[s * T] != 0.f ? 1 : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {                                    // B is a few hundred samples: a serial scan is microseconds
+        int nl = 0;
+        for (long s = 0; s < B; ++s) nl += slot[s];
+        int pl = 0, pd = nl;
+        for (long s = 0; s < B; ++s) { const int k = slot[s]; slot[s] = k ? pl++ : pd++; }
+        live[u] = nl * T;
+    }
+    __syncthreads();
+    int* pu = perm + u * B * T;
+    int* iu = inv + u * B * T;
+    for (long e = threadIdx.x; e < B * T; e += blockDim.x) {
+        const long s = e / T;
+        const int tok = (int)(e - s * T);
+        const int c = slot[s] * T + tok;
+        pu[e] = c;
+        iu[c] = (int)e;
+    }
+}
+
 }  // namespace
 
 extern "C" int editor_sgd_multi(float* const* p_ptrs, const float* const* g_ptrs, float* const* m_ptrs,
@@ -288,6 +321,15 @@ extern "C" int editor_droppath_scales(const float* rates, int L, long B, int T, 
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(droppath_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rates, L, B, T, (uint64_t)seed, scales);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_droppath_plan(const float* scales, int L, long B, int T, int* perm, int* inv, int* live, hipStream_t stream)
+{
+    if (L < 1 || B < 1 || T < 1 || B > 12288 || B * T > 0x7FFFFFFFL || !scales || !perm || !inv || !live) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(droppath_plan_kernel, dim3((unsigned)(L * 2)), dim3(256), (size_t)B * sizeof(int), stream, scales, B, T, perm,
+                       inv, live);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

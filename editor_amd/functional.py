@@ -314,11 +314,12 @@ _CAST_SLOT = [None]
 
 
 class _CastBox:
-    __slots__ = ("out", "m", "dtype", "rowscale", "has_bias", "gs", "cs_out", "handoff")
+    __slots__ = ("out", "m", "dtype", "rowscale", "has_bias", "gs", "cs_out", "handoff", "perm")
 
-    def __init__(self, out, m, dtype, rowscale, has_bias, gs, cs_out):
+    def __init__(self, out, m, dtype, rowscale, has_bias, gs, cs_out, perm=None):
         self.out, self.m, self.dtype = weakref.ref(out), m, dtype      # (the tensor OBJECT the node returns: an address can be re-used)
         self.rowscale, self.has_bias, self.gs, self.cs_out = rowscale, has_bias, gs, cs_out
+        self.perm = perm            # stochastic-depth plan of the consumer's MLP branch: the 16-bit copy goes to its compacted rows
         self.handoff = None
 
     def put(self, dx, dy16, dbias):
@@ -334,7 +335,7 @@ class _CastBox:
         return h[1], h[2]
 
 
-def _cast_boxes(ctx, x, out, m, d, act_dtype, mask, cu, m_live, rowscale_mlp, has_fc2_bias, sink, plain):
+def _cast_boxes(ctx, x, out, m, d, act_dtype, mask, cu, m_live, rowscale_mlp, has_fc2_bias, sink, plain, perm=None):
     """forward side of HANDOFF_CAST: ctx.feeds_box = the box of the block whose output `x` is; ctx.box = this block's own."""
     prev, _CAST_SLOT[0] = _CAST_SLOT[0], None
     ctx.feeds_box = ctx.box = None
@@ -344,7 +345,7 @@ def _cast_boxes(ctx, x, out, m, d, act_dtype, mask, cu, m_live, rowscale_mlp, ha
     if prev is not None and prev.out() is x and prev.m == m and prev.dtype == act_dtype:
         ctx.feeds_box = prev
     ctx.box = _CAST_SLOT[0] = _CastBox(out, m, act_dtype, rowscale_mlp, has_fc2_bias, grad_scale(act_dtype),
-                                       sink.views[11] if sink is not None else None)
+                                       sink.views[11] if sink is not None else None, perm)
 
 
 
@@ -354,7 +355,7 @@ def _linear_bwd(*args, **kw):
 
 
 def _linear_bwd_gen(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=None, dx_colsum=None, gs=1.0, dw_out=None,
-                    db_out=None, dxcs_out=None, w_t=None, defer=None, aux_is_grad=True, rq=None):
+                    db_out=None, dxcs_out=None, w_t=None, defer=None, aux_is_grad=True, rq=None, live_dense=False):
     """dx = dy W (optionally * gelu'(gelu_pre), fused epilogue) ; dW = dy^T x (fp32) ; db = colsum(dy) (or the
     caller's, when the kernel that produced dy summed its columns on the way).  dx_colsum: also return colsum(dx) - the
     bias gradient of the layer BELOW - from the dgrad's own epilogue when it can deliver it (else None).
@@ -368,17 +369,18 @@ def _linear_bwd_gen(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=No
     dy_ready = torch.cuda.current_stream(dy.device).record_event() if use_side else None   # BEFORE the dgrad launch
     dx = torch.empty(m, k, dtype=x2d.dtype, device=dy.device)
     dxcs = None
-    if dx_colsum and ops.gemm_colsum_ok(m, k, n, dx.dtype, 0, 1, m_live):
+    # live_dense: *m_live is the live prefix of stochastic-depth-compacted rows (ops.droppath_plan; rows behind it are zero in dy)
+    if dx_colsum and ops.gemm_colsum_ok(m, k, n, dx.dtype, 0, 1, m_live, live_dense):
         dxcs = dxcs_out if dxcs_out is not None else torch.empty(k, dtype=torch.float32, device=dy.device)
     # B = W stored (Kred=n, Nout=k): row-k operand (trans_b = 1); or its k-major copy W^T (Nout=k, Kred=n): trans_b = 0
     wb, ldb, tb = (w_t, n, 0) if w_t is not None else (w_act, k, 1)
     if gelu_pre is None:
         yield _GemmReq(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, m_live=m_live, colsum=dxcs, colsum_scale=inv, tag="dgrad",
-                       rq=rq)
+                       rq=rq, live_dense=live_dense)
     else:
         ag = ops.EPI_AUX_GRAD if (dy.dtype in ops.HALF_DTYPES and aux_is_grad) else 0   # 16-bit: gelu_pre holds gelu'(pre-activation)
         yield _GemmReq(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, epilogue=ops.EPI_GELU_BWD | ag, aux=gelu_pre, m_live=m_live,
-                       colsum=dxcs, colsum_scale=inv, tag="dgrad", rq=rq)
+                       colsum=dxcs, colsum_scale=inv, tag="dgrad", rq=rq, live_dense=live_dense)
     dw = dw_out if dw_out is not None else torch.empty(n, k, dtype=torch.float32, device=dy.device)
     if need_bias and db is None:
         db = db_out if db_out is not None else torch.empty(n, dtype=torch.float32, device=dy.device)
@@ -392,7 +394,7 @@ def _linear_bwd_gen(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=No
     sk, skf = _splitk_for(n, k, m)
     if defer is not None:
         # the weight gradient joins the block's grouped launch (issued by the caller once the last dy exists)
-        defer.append((dy, x2d, dw))
+        defer.append((dy, x2d, dw, m_live) if live_dense else (dy, x2d, dw))
         if need_colsum:
             ops.colsum(dy, out=db, scale=inv, rq=rq)
     elif use_side:
@@ -438,6 +440,17 @@ def _splitk_for(n_out, k_out, m_red, cus=256):
     return best, 0
 
 
+DROP_SKIP = os.environ.get("EDITOR_DROP_SKIP", "1") != "0"      # A/B switch: stochastic-depth compaction of the MLP branch
+
+
+def _plan_ok(act_dtype, m, d, hidden, cu, mask, m_live, branch16, defer_out, pend_branch, rowscale_mlp):
+    """Can this block run its MLP branch on the stochastic-depth-compacted rows?  The plain dense 16-bit block whose backward takes
+    the grouped weight gradients, the deferred reductions and the fused LayerNorm casts (every condition backward_gen re-derives)."""
+    return (DROP_SKIP and rowscale_mlp is not None and act_dtype in ops.HALF_DTYPES and cu is None and mask is None and m_live is None
+            and not branch16 and not defer_out and pend_branch is None and not ACT_LIGHT and GROUP_WGRAD and DEFER_REDUCE
+            and FUSE_LN_CAST and m >= 2048 and m % 64 == 0 and d % 256 == 0 and d <= 1024 and hidden % 256 == 0)
+
+
 class TransformerBlockFn(torch.autograd.Function):
     """Block.forward(get_att=True) (vit_pytorch.py:215-220) and the masked blocks of BlockMask.forward
     (vit_pytorch.py:311-317,327-328 with AttentionMask :240-258 / MlpMasked :158-168).
@@ -458,7 +471,7 @@ class TransformerBlockFn(torch.autograd.Function):
     @staticmethod
     def forward_gen(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, mask, probs_out,
                     heads, eps, act_dtype, rowscale_attn, rowscale_mlp, cu=None, max_t=None, m_live=None, qk_scale=None,
-                    sink=None, pend_branch=None, pend_rs=None, defer_out=False, branch16=False):
+                    sink=None, pend_branch=None, pend_rs=None, defer_out=False, branch16=False, drop_plan=None):
         # (a generator: the four large products of the plain 16-bit path are YIELDED as launch requests, see _drive / _drive_group)
         # branch16 (cfg.MODEL.BRANCH16; bf16 backbone blocks): the projection and fc2 products write their 16-bit branch output with
         # the plain epilogue and the residual add happens inside the LayerNorm that follows (ops.resid_add_layernorm_fwd) - the
@@ -481,6 +494,13 @@ class TransformerBlockFn(torch.autograd.Function):
         if (branch16 or defer_out or pend_branch is not None) and (act_dtype not in ops.HALF_DTYPES or cu is not None
                                                                    or mask is not None or m_live is not None or d % 256):
             raise RuntimeError("branch16 blocks: dense 16-bit rows only")
+        # drop_plan = (perm, inv, live) of THIS block's MLP branch (ops.droppath_plan; round 6): the samples whose stochastic-depth
+        # draw dropped the branch (rowscale_mlp == 0: x2 = x1 + 0, no gradient through it - vit_pytorch.py:66-68,218) are not
+        # computed: LayerNorm-2 writes the live samples' rows compacted, fc1 / fc2 and the whole MLP backward run on that prefix
+        # (`live` rows, a device scalar: tiles beyond it exit), the fc2 epilogue scatters back.  Same bits for every live row.
+        plan = drop_plan if _plan_ok(act_dtype, m, d, fc1w.shape[0], cu, mask, m_live, branch16, defer_out, pend_branch,
+                                     rowscale_mlp) else None
+        ctx.plan = plan
         head_done = split_all = False
         if act_dtype in (F16X2, F16X2H):
             # split-precision forward: every product on half PAIRS (three MFMA passes, fp32-class), the exact softmax / GELU
@@ -554,7 +574,11 @@ class TransformerBlockFn(torch.autograd.Function):
             x1 = torch.empty_like(x2d)              # x1 = x + rs * (ao Wp^T + b): residual add in the GEMM epilogue
             yield _GemmReq(ao, wp, x1, m, d, d, d, d, d, 0, 0, bias=projb, rowscale=rowscale_attn,
                            epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)
-            h2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, eps, act_dtype, mask, 0, m_live=m_live)
+            if plan is not None:
+                x2 = torch.empty_like(x2d)          # (dropped rows: LayerNorm-2 copies x1 there; live rows: the fc2 epilogue)
+                h2, mean2, rstd2 = ops.layernorm_fwd_perm(x1, n2w, n2b, eps, act_dtype, plan[0], rowscale_mlp, x2)
+            else:
+                h2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, eps, act_dtype, mask, 0, m_live=m_live)
         hidden = w1.shape[0]
         # (a no-grad forward - model.eval() under torch.no_grad(), engine/processor.py:217-270 - saves nothing for a backward: the
         #  16-bit fc1 epilogue then writes ONE output instead of two, 304 MB per layer less at B = 128)
@@ -565,11 +589,16 @@ class TransformerBlockFn(torch.autograd.Function):
         # epilogue instead of an erfc + exponential per element); the f32 parity kernels keep the pre-activation
         light = ACT_LIGHT and act_dtype in ops.HALF_DTYPES
         ag = ops.EPI_AUX_GRAD if (act_dtype in ops.HALF_DTYPES and not light) else 0     # light: `a` keeps the pre-activation
-        yield _GemmReq(h2, w1, g, m, hidden, d, d, d, hidden, 0, 0, bias=fc1b, epilogue=ops.EPI_GELU | ag, aux=a, m_live=m_live)
+        live = plan[2] if plan is not None else m_live
+        yield _GemmReq(h2, w1, g, m, hidden, d, d, d, hidden, 0, 0, bias=fc1b, epilogue=ops.EPI_GELU | ag, aux=a, m_live=live,
+                       live_dense=plan is not None)
         br2 = None
         if defer_out:                               # (x1, fc2 branch): the consumer's LayerNorm adds them
             br2 = torch.empty(m, d, dtype=act_dtype, device=x.device)
             ops.gemm(g, w2, br2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b)
+        elif plan is not None:
+            yield _GemmReq(g, w2, x2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b, rowscale=rowscale_mlp,
+                           epilogue=ops.EPI_RESIDUAL, aux=x1, m_live=live, live_dense=True, rowmap=plan[1])
         else:
             x2 = torch.empty_like(x2d)
             yield _GemmReq(g, w2, x2, m, d, hidden, hidden, hidden, d, 0, 0, bias=fc2b, rowscale=rowscale_mlp,
@@ -589,7 +618,7 @@ class TransformerBlockFn(torch.autograd.Function):
             return x1.view(x.shape), br2
         out = x2.view(x.shape)
         _cast_boxes(ctx, x, out, m, d, act_dtype, mask, cu, m_live, rowscale_mlp, fc2b is not None, sink,
-                    pend_branch is None and not branch16)
+                    pend_branch is None and not branch16, plan[0] if plan is not None else None)
         return out
 
     @staticmethod
@@ -626,18 +655,25 @@ class TransformerBlockFn(torch.autograd.Function):
         rq = ops.ReduceQueue(dx2.device, _GROUP_SLOT[0], _GROUP_SLOT[1]) if (DEFER_REDUCE and jobs is not None) else None
         # ---- MLP branch:  x2 = x1 + rs * fc2(gelu(fc1(LN2(x1))))
         box = getattr(ctx, "box", None)
+        plan = getattr(ctx, "plan", None)            # stochastic-depth compaction of this block's MLP branch (see forward_gen)
+        if plan is not None and (rq is None or jobs is None):
+            raise RuntimeError("stochastic-depth compaction needs the grouped weight gradients + deferred reductions (its forward check)")
+        live_mlp = plan[2] if plan is not None else m_live
         handed = box.take(dx2) if box is not None else None
         if handed is not None:
-            dy, dbias = handed                       # left by the next block's LayerNorm-1 backward (HANDOFF_CAST)
+            dy, dbias = handed                       # left by the next block's LayerNorm-1 backward (HANDOFF_CAST; on plan[0]'s rows)
+        elif plan is not None:
+            dy, dbias = ops.cast_rows_colsum(dx2, rs_mlp, act_dtype, gs, sv[11], rq=rq, perm=plan[0])
         else:
             dy, dbias = _scaled_cast_colsum(dx2, rs_mlp, act_dtype, m_live, hb_fc2, gs, cs_out=sv[11], rq=rq)
-        da, dw2, db2, da_cs = yield from _linear_bwd_gen(dy, g, w2, hb_fc2, gelu_pre=a, m_live=m_live, db=dbias,
+        da, dw2, db2, da_cs = yield from _linear_bwd_gen(dy, g, w2, hb_fc2, gelu_pre=a, m_live=live_mlp, db=dbias,
                                           dx_colsum=hb_fc1, gs=gs, dw_out=sv[10], db_out=sv[11],
-                                          dxcs_out=sv[9], w_t=w2t, defer=jobs, aux_is_grad=light is None, rq=rq)   # da = (dy W2) * gelu'(a)
+                                          dxcs_out=sv[9], w_t=w2t, defer=jobs, aux_is_grad=light is None, rq=rq,
+                                          live_dense=plan is not None)   # da = (dy W2) * gelu'(a)
         if light is not None:
             h2 = ops.layernorm_fwd(x1, n2w, light[1], light[2], act_dtype, mask, 0, want_stats=False, m_live=m_live)[0]
-        dh2, dw1, db1 = yield from _linear_bwd_gen(da, h2, w1, hb_fc1, m_live=m_live, db=da_cs, gs=gs, dw_out=sv[8], db_out=sv[9], w_t=w1t,
-                                    defer=jobs, rq=rq)
+        dh2, dw1, db1 = yield from _linear_bwd_gen(da, h2, w1, hb_fc1, m_live=live_mlp, db=da_cs, gs=gs, dw_out=sv[8], db_out=sv[9], w_t=w1t,
+                                    defer=jobs, rq=rq, live_dense=plan is not None)
         fuse_cast = (FUSE_LN_CAST and m_live is None and mask is None and act_dtype in ops.HALF_DTYPES
                      and d % 256 == 0 and d <= 1024)
         if fuse_cast:
@@ -645,7 +681,8 @@ class TransformerBlockFn(torch.autograd.Function):
             # gradient) that the attention branch's backward starts from: no second pass over dx1
             dx1, dn2w, dn2b, dy, dbias = ops.layernorm_bwd_cast(
                 dh2, x1, n2w, mean2, rstd2, dx2, rs_attn, gs, dy_scale=1.0 / gs,
-                dgb_out=sink.ln_pair(6) if sink is not None else None, want_colsum=hb_proj, cs_out=sv[5], rq=rq)
+                dgb_out=sink.ln_pair(6) if sink is not None else None, want_colsum=hb_proj, cs_out=sv[5], rq=rq,
+                dy_perm=plan[0] if plan is not None else None, dy_live=plan[2] if plan is not None else None)
         else:
             dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w, mean2, rstd2, mask, 0, dx_in=dx2, m_live=m_live,
                                                 dy_scale=1.0 / gs, dgb_out=sink.ln_pair(6) if sink is not None else None, rq=rq)
@@ -666,7 +703,7 @@ class TransformerBlockFn(torch.autograd.Function):
                                     defer=jobs, rq=rq)
         fb = getattr(ctx, "feeds_box", None)
         ln_done = False
-        if jobs and WGRAD_LN and fb is not None and fuse_cast and not deferred:
+        if jobs and WGRAD_LN and fb is not None and fuse_cast and not deferred and plan is None and fb.perm is None:
             # (opt-in, round 4) the block's four weight gradients AND LayerNorm-1's backward as two ROLES of one launch on this stream:
             # the memory-bound rows on a quarter of the CUs beside the tiles on the rest (ops.gemm_wgrad_group_ln)
             dx, dn1w, dn1b, dy_below, db_below = ops.gemm_wgrad_group_ln(
@@ -684,8 +721,10 @@ class TransformerBlockFn(torch.autograd.Function):
             # ... and hands the block BELOW the start of its backward (see HANDOFF_CAST): its drop-path row scale, its bias-gradient slot
             dx, dn1w, dn1b, dy_below, db_below = ops.layernorm_bwd_cast(
                 dh1, x2d, n1w, mean1, rstd1, dx1, fb.rowscale, fb.gs, dy_scale=1.0 / gs,
-                dgb_out=sink.ln_pair(0) if sink is not None else None, want_colsum=fb.has_bias, cs_out=fb.cs_out, rq=rq)
-            fb.put(dx, dy_below, db_below)
+                dgb_out=sink.ln_pair(0) if sink is not None else None, want_colsum=fb.has_bias, cs_out=fb.cs_out, rq=rq,
+                cast_perm=fb.perm if rq is not None else None)
+            if fb.perm is None or rq is not None:
+                fb.put(dx, dy_below, db_below)       # (a compacted consumer without the parts form: it casts for itself)
         else:
             dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2d, n1w, mean1, rstd1, mask, 0, dx_in=dx1, m_live=m_live,
                                                dy_scale=1.0 / gs, dgb_out=sink.ln_pair(0) if sink is not None else None, rq=rq)
@@ -699,7 +738,7 @@ class TransformerBlockFn(torch.autograd.Function):
             # the bucket's all-reduce start now, under the rest of the backward
             grads = tuple(None if v is not None else g_ for g_, v in zip(grads, sv))
             sink.done()
-        return (dx.view(xshape),) + grads + (None,) * 17
+        return (dx.view(xshape),) + grads + (None,) * 18
 
 
 GROUP_BLOCKS = os.environ.get("EDITOR_GROUP_BLOCKS", "1") != "0"      # A/B switch: GroupedBlocksFn for the HMA modality blocks

@@ -318,6 +318,9 @@ class EDITOR(nn.Module):
         b16_default = os.environ.get("EDITOR_BRANCH16") == "1" and self.act_dtype == torch.bfloat16 and not self.split_fwd
         self.branch16 = bool(getattr(cfg.MODEL, "BRANCH16", b16_default)) and self.act_dtype in (torch.bfloat16, torch.float16) \
             and not self.split_fwd and not self.bb_attn_f32 and dim % 256 == 0
+        # cfg.MODEL.DROP_SKIP (default on; EDITOR_DROP_SKIP=0 for A/B runs): stochastic depth skips what it multiplies by zero - the
+        # MLP branch of a block runs on the samples its draw kept (functional.TransformerBlockFn drop_plan); same bits per live row
+        self.drop_skip = bool(getattr(cfg.MODEL, "DROP_SKIP", os.environ.get("EDITOR_DROP_SKIP", "1") != "0"))
         self.rollout_probs = bool(getattr(cfg.MODEL, "ROLLOUT_PROBS", False))
         self.split_rollout_recompute = bool(getattr(cfg.MODEL, "SPLIT_ROLLOUT_RECOMPUTE",
                                                     os.environ.get("EDITOR_SPLIT_ROLLOUT") == "1"))
@@ -400,7 +403,7 @@ class EDITOR(nn.Module):
         ldp = t if (self.act_dtype == torch.float32 or self.bb_attn_f32) else (t + 3) // 4 * 4
         probs = [] if recompute else torch.empty(base.depth, btot, base.heads, t, ldp, dtype=torch.float32,
                                                  device=dev)
-        scales = None
+        scales = plans = None
         if self.training and max(base.drop_rates) > 0.0:                       # vit_pytorch.py:52-69: one launch for all
             if self._drop_rates_dev is None or self._drop_rates_dev.device != dev:
                 self._drop_rates_dev = torch.tensor(base.drop_rates, dtype=torch.float32, device=dev)
@@ -417,18 +420,24 @@ class EDITOR(nn.Module):
                     self._drop_state = torch.full((1,), seed0, dtype=torch.int64, device=dev)
                 scales = ops.droppath_scales_dev(self._drop_rates_dev, btot, t, self._drop_state)
             self.last_drop_scales = scales             # (depth, 2, nmod*B*T) per-row branch scales of this forward (tests read them)
+            if self.drop_skip and self.act_dtype in ops.HALF_DTYPES and not self.split_fwd and not self.branch16:
+                # round 6: the samples a branch's draw dropped are not computed (functional.TransformerBlockFn `drop_plan`):
+                # token rows of every (block, branch) ordered live samples first, one small launch for the whole backbone
+                plans = ops.droppath_plan(scales, base.depth, btot, t)
         pend_branch = pend_rs = None                 # BRANCH16: the previous block's (fc2 branch, drop-path scales); x is then its x1
         for i, blk in enumerate(base.blocks):
-            rs_a = rs_m = None
+            rs_a = rs_m = plan = None
             if scales is not None and base.drop_rates[i] > 0.0:
                 rs_a, rs_m = scales[i, 0], scales[i, 1]
+                if plans is not None:
+                    plan = (plans[0][i, 1], plans[1][i, 1], plans[2][i, 1:2])       # MLP branch: (perm, inv, live rows)
             last = i == len(base.blocks) - 1
             defer = self.branch16 and not last        # (the last block adds its own fc2 branch: the final norm takes plain rows)
             out = fn.TransformerBlockFn.apply(x, *_block_args(blk.norm1, blk.attn, blk.norm2, blk.mlp), None,
                                               probs if recompute else probs[i], base.heads, 1e-6,
                                               self.fn_dtype_last if last else self.fn_dtype, rs_a, rs_m,
                                               None, None, None, base.qk_scale, self._sink("backbone.%d" % i),
-                                              pend_branch, pend_rs, defer, self.branch16)
+                                              pend_branch, pend_rs, defer, self.branch16, plan)
             if defer:
                 x, pend_branch = out
                 pend_rs = rs_m

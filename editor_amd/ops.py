@@ -193,6 +193,17 @@ def layernorm_fwd(x2d, gamma, beta, eps, out_dtype, rowmask=None, mask_period=0,
     return y, mean, rstd
 
 
+def layernorm_fwd_perm(x2d, gamma, beta, eps, out_dtype, perm, rowscale, copy_out):
+    """layernorm_fwd onto COMPACTED rows (stochastic-depth skipping, droppath_plan): row r's 16-bit output at row perm[r] of y;
+    a dropped row (rowscale[r] == 0) leaves zeros there and copies its x row into copy_out.  -> y, mean, rstd (original rows)."""
+    m, d = x2d.shape
+    y = torch.empty(m, d, dtype=out_dtype, device=x2d.device)
+    mean = torch.empty(m, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(m, dtype=torch.float32, device=x2d.device)
+    call("editor_layernorm_fwd_perm", x2d, gamma, beta, float(eps), m, d, y, _is_bf16(y), mean, rstd, perm, rowscale, copy_out)
+    return y, mean, rstd
+
+
 def resid_add_layernorm_fwd(x2d, branch, rowscale, gamma, beta, eps):
     """x_out = x + rowscale[:, None] * branch (branch: 16-bit, plain-epilogue output of the projection / fc2 product), y = LN(x_out)
     in branch's dtype -> (x_out fp32, y, mean, rstd).  Dense rows, D a multiple of 256 (cfg.MODEL.BRANCH16)."""
@@ -231,10 +242,27 @@ def layernorm_bwd(dy, x2d, gamma, mean, rstd, rowmask=None, mask_period=0, dx_in
 
 
 def layernorm_bwd_cast(dy, x2d, gamma, mean, rstd, dx_in, rowscale, scale=1.0, dy_scale=1.0, dgb_out=None, want_colsum=True,
-                       cs_out=None, rq=None):
+                       cs_out=None, rq=None, dy_perm=None, dy_live=None, cast_perm=None):
     """layernorm_bwd (dense 16-bit rows) that also hands out what cast_rows_colsum(dx, rowscale, dy.dtype, scale) would:
-    -> dx, dgamma, dbeta, dx16, colsum(dx16) / scale (None unless want_colsum)."""
+    -> dx, dgamma, dbeta, dx16, colsum(dx16) / scale (None unless want_colsum).
+    dy_perm / dy_live: dy sits on the compacted rows of a stochastic-depth plan (slots >= *dy_live: dropped rows, gradient zero);
+    cast_perm: dx16 is written onto the compacted rows of the branch that consumes it (droppath_plan)."""
     m, d = x2d.shape
+    if dy_perm is not None or cast_perm is not None:
+        if rq is None:
+            raise RuntimeError("layernorm_bwd_cast on compacted rows: the deferred-reduction (parts) form only")
+        dx = torch.empty(m, d, dtype=torch.float32, device=x2d.device)
+        dgb = dgb_out if dgb_out is not None else torch.empty(2, d, dtype=torch.float32, device=x2d.device)
+        dx16 = torch.empty(m, d, dtype=dy.dtype, device=x2d.device)
+        cs = (cs_out if cs_out is not None else torch.empty(d, dtype=torch.float32, device=x2d.device)) if want_colsum else None
+        ws = rq.region(WS_ROWS * 3 * d)
+        npart = ctypes.c_int(0)
+        call("editor_layernorm_bwd_cast_perm_parts", dy, _is_bf16(dy), float(dy_scale), x2d, gamma, mean, rstd, m, d, dx_in, dx, ws,
+             WS_ROWS, dx16, rowscale, float(scale), 1 if want_colsum else 0, dy_perm, dy_live, cast_perm, ctypes.byref(npart))
+        rq.add(ws, npart.value, 2 * d, dgb, 1.0)
+        if want_colsum:
+            rq.add(ws[WS_ROWS * 2 * d:], npart.value, d, cs, 1.0 / float(scale))
+        return dx, dgb[0], dgb[1], dx16, cs
     dx = torch.empty(m, d, dtype=torch.float32, device=x2d.device)
     dgb = dgb_out if dgb_out is not None else torch.empty(2, d, dtype=torch.float32, device=x2d.device)
     dx16 = torch.empty(m, d, dtype=dy.dtype, device=x2d.device)
@@ -308,12 +336,21 @@ def cast_rows(x2d, rowscale, dtype, m_live=None, scale=1.0):
     return out
 
 
-def cast_rows_colsum(x2d, rowscale, dtype, scale=1.0, cs_out=None, rq=None):
-    """cast_rows + the column sums of its output (bias gradient, with the scale removed again) in the same pass."""
+def cast_rows_colsum(x2d, rowscale, dtype, scale=1.0, cs_out=None, rq=None, perm=None):
+    """cast_rows + the column sums of its output (bias gradient, with the scale removed again) in the same pass.
+    perm: row r of the result goes to row perm[r] (compacted consumer rows, droppath_plan)."""
     m, d = x2d.shape
     out = torch.empty(m, d, dtype=dtype, device=x2d.device)
     cs = cs_out if cs_out is not None else torch.empty(d, dtype=torch.float32, device=x2d.device)
     ws = rq.region(WS_ROWS * d) if rq is not None else None
+    if perm is not None:
+        if ws is None:
+            raise RuntimeError("cast_rows_colsum onto compacted rows: the deferred-reduction (parts) form only")
+        npart = ctypes.c_int(0)
+        call("editor_cast_rows_colsum_perm_parts", x2d, rowscale, m, d, out, _is_bf16(out), ws, WS_ROWS, float(scale), perm,
+             ctypes.byref(npart))
+        rq.add(ws, npart.value, d, cs, 1.0 / float(scale))
+        return out, cs
     if ws is not None:
         npart = ctypes.c_int(0)
         call("editor_cast_rows_colsum_parts", x2d, rowscale, m, d, out, _is_bf16(out), ws, WS_ROWS, float(scale), ctypes.byref(npart))
@@ -443,15 +480,17 @@ def gemm_tile_plan(m, n, cus=256):
     return th, cost_pipe < 0.97 * cost_pp
 
 
-def gemm_colsum_ok(m, n, k, c_dtype, trans_a, splitk, m_live):
-    """Can the 16-bit GEMM also deliver the column sums of its (16-bit) output?  (one-pass 256x256 epilogue only)"""
-    return (c_dtype in HALF_DTYPES and not trans_a and splitk == 1 and m_live is None and m >= 2048 and n >= 512
+def gemm_colsum_ok(m, n, k, c_dtype, trans_a, splitk, m_live, live_dense=False):
+    """Can the 16-bit GEMM also deliver the column sums of its (16-bit) output?  (one-pass 256x256 epilogue only)
+    live_dense: m_live counts the live prefix of stochastic-depth-compacted rows whose tail rows are ZERO (droppath_plan) - the
+    skipped tiles zero their partial rows; the compacted HMA head's live rows (unwritten tails) do not qualify."""
+    return (c_dtype in HALF_DTYPES and not trans_a and splitk == 1 and (m_live is None or live_dense) and m >= 2048 and n >= 512
             and n % 8 == 0 and k % 64 == 0)
 
 
 def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=0.0, bias=None, rowscale=None,
          splitk=1, a_off=0, b_off=0, c_off=0, epilogue=0, aux=None, m_live=None, colsum=None, colsum_scale=1.0, tag=None,
-         rq=None):
+         rq=None, live_dense=False, rowmap=None):
     """c = alpha * op(a) op(b) (+bias) (+beta*c) (*rowscale); dtype picks the kernel family.  tag: free-form label
     ("dgrad", ...) for measurement wrappers (bench.py's probe); not used here.
     (fp32 -> exact-f32 MFMA, bf16 -> bf16 MFMA with fp32 accumulate; c may be fp32 for bf16 inputs)."""
@@ -490,7 +529,7 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
                  b_off=b_off + k0 * ldb, c_off=c_off)
             return
         th = ((int(epilogue) >> 12) & 15) * 16 or 256            # explicit EPI_TILE_ROWS, else the shape heuristic
-        if (SHORT_TILES and not trans_a and not trans_b and splitk == 1 and beta == 0.0 and m_live is None and m >= 2048
+        if (SHORT_TILES and not trans_a and not trans_b and splitk == 1 and beta == 0.0 and (m_live is None or live_dense) and m >= 2048
                 and n >= 512 and n % 8 == 0 and ldc % 8 == 0 and k % 64 == 0 and not (int(epilogue) & 0xF000)):
             th, narrow = gemm_tile_plan(m, n)
             if narrow and colsum is None and not (int(epilogue) & EPI_FORCE_PP):
@@ -500,7 +539,7 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
         if colsum is not None:
             # colsum (n) fp32 <- column sums of the rounded output (bias gradient of the layer this gradient feeds):
             # per-tile-row partials from the GEMM epilogue, folded in a fixed order
-            assert gemm_colsum_ok(m, n, k, c.dtype, trans_a, splitk, m_live) and ldc == n
+            assert gemm_colsum_ok(m, n, k, c.dtype, trans_a, splitk, m_live, live_dense) and ldc == n and rowmap is None
             tiles_m = (m + th - 1) // th
             part = rq.region(tiles_m * n) if rq is not None else None
             deferred = part is not None
@@ -508,11 +547,18 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, trans_a=0, trans_b=0, alpha=1.0, beta=
                 part = workspace(a.device, tiles_m * n)
             call(entry, _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), 0, m, n, k, lda, ldb, ldc,
                  int(trans_a), int(trans_b), float(alpha), float(beta), bias, rowscale, 1, int(epilogue) | EPI_COLSUM, aux,
-                 n, part, None)
+                 n, part, m_live)
             if deferred:
                 rq.add(part, tiles_m, n, colsum, float(colsum_scale))
             else:
                 call("editor_reduce_rows", part, tiles_m, n, colsum, 0, float(colsum_scale))
+            return
+        if rowmap is not None:
+            # compacted rows scattered back by the fp32 residual epilogue (stochastic-depth skipping: editor_gemm_h16_rows)
+            assert c.dtype == torch.float32 and not trans_a and not trans_b and splitk == 1 and beta == 0.0
+            assert a_off == b_off == c_off == 0 and (int(epilogue) & 0xFF) == EPI_RESIDUAL
+            call("editor_gemm_h16_rows", _DT_CODE[a.dtype], a, b, c, m, n, k, lda, ldb, ldc, float(alpha), bias, rowscale,
+                 int(epilogue), aux, n, m_live, rowmap)
             return
         call(entry, _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), 1 if c.dtype == torch.float32 else 0,
              m, n, k, lda, ldb, ldc, int(trans_a), int(trans_b), float(alpha), float(beta), bias, rowscale, int(splitk),
@@ -662,9 +708,13 @@ def gemm_group(reqs):
 
 
 def gemm_wgrad_group(jobs, m, alpha=1.0, m_live=None):
-    """jobs: list of (dy (m, n_i), x (m, k_i), dw (n_i, k_i) fp32) of ONE block -> one launch (editor_gemm_wgrad_group)."""
+    """jobs: list of (dy (m, n_i), x (m, k_i), dw (n_i, k_i) fp32[, live_i]) of ONE block -> one launch (editor_gemm_wgrad_group).
+    live_i (optional 4th entry): device scalar, live token rows of THAT problem (rows beyond are zero) - a block whose MLP branch
+    ran on stochastic-depth-compacted rows next to its dense attention branch (editor_gemm_wgrad_group_live)."""
     import ctypes
     cnt = len(jobs)
+    lives = [j[3] if len(j) > 3 else None for j in jobs]
+    jobs = [j[:3] for j in jobs]
     dt = _DT_CODE[jobs[0][0].dtype]
     ns = [j[0].shape[1] for j in jobs]
     ks = [j[1].shape[1] for j in jobs]
@@ -675,6 +725,12 @@ def gemm_wgrad_group(jobs, m, alpha=1.0, m_live=None):
     ia = lambda v: (ctypes.c_int * cnt)(*v)
     for dy, x, dw in jobs:
         assert dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous() and dy.shape[0] == m == x.shape[0]
+    if any(l_ is not None for l_ in lives):
+        assert m_live is None
+        la = (ctypes.c_void_p * cnt)(*[None if l_ is None else l_.data_ptr() for l_ in lives])
+        call("editor_gemm_wgrad_group_live", dt, cnt, arr([j[0] for j in jobs]), arr([j[1] for j in jobs]), arr([j[2] for j in jobs]),
+             ia(ns), ia(ks), m, float(alpha), sk, ws, la)
+        return
     call("editor_gemm_wgrad_group", dt, cnt, arr([j[0] for j in jobs]), arr([j[1] for j in jobs]), arr([j[2] for j in jobs]),
          ia(ns), ia(ks), m, float(alpha), sk, ws, m_live)
 
@@ -697,6 +753,7 @@ def gemm_wgrad_group_ln(jobs, m, alpha, dy, x2d, gamma, mean, rstd, dx_in, rowsc
     ws = workspace(jobs[0][0].device, sk * sum(n * k for n, k in zip(ns, ks)))
     arr = lambda ts: (ctypes.c_void_p * cnt)(*[t.data_ptr() for t in ts])
     ia = lambda v: (ctypes.c_int * cnt)(*v)
+    assert all(len(j) == 3 for j in jobs)                    # (no per-problem live counts in the role form)
     for jdy, jx, jdw in jobs:
         assert jdy.is_contiguous() and jx.is_contiguous() and jdw.is_contiguous() and jdy.shape[0] == m == jx.shape[0]
     rows, d = x2d.shape
@@ -1001,6 +1058,16 @@ def droppath_scales_dev(rates, b, t, state):
     out = torch.empty(l, 2, b * t, dtype=torch.float32, device=rates.device)
     call("editor_droppath_scales_dev", rates, l, b, t, state, out)
     return out
+
+
+def droppath_plan(scales, l, b, t):
+    """Stochastic-depth compaction plan of a scales tensor (l, 2, b*t): -> perm (l,2,b*t) int32 (token row -> slot, live samples
+    first), inv (l,2,b*t) (slot -> token row), live (l,2) int32 (live rows).  include/editor_hip.h: editor_droppath_plan."""
+    perm = torch.empty(l, 2, b * t, dtype=torch.int32, device=scales.device)
+    inv = torch.empty_like(perm)
+    live = torch.empty(l, 2, dtype=torch.int32, device=scales.device)
+    call("editor_droppath_plan", scales, l, b, t, perm, inv, live)
+    return perm, inv, live
 
 
 def droppath_scales(rates, b, t, seed):

@@ -529,6 +529,42 @@ int editor_droppath_scales(const float* rates, int L, long B, int T, long seed, 
  * hipGraph of the training step draws fresh masks on every replay */
 int editor_droppath_scales_dev(const float* rates, int L, long B, int T, long* state, float* scales, editor_stream_t stream);
 
+/* ---- stochastic-depth compaction (round 6) --------------------------------------------------------------------------------
+ * The reference evaluates every residual branch and multiplies dropped samples by 0 (vit_pytorch.py:66-68, two draws per block,
+ * :217-218).  A dropped (sample, block, branch) contributes x + 0 and receives no gradient through the branch, so the MLP branch
+ * (LayerNorm-2, fc1, GELU, fc2 and their backward) runs on the LIVE samples' token rows only: same bits for every live row,
+ * exact x for the dropped ones.
+ * editor_droppath_plan: from scales (L,2,B*T) (editor_droppath_scales*; scale == 0 <=> dropped) -> for each of the L*2 (block,
+ * branch) units  perm (L,2,B*T) int32: slot of token row r in the compacted order (live samples first, order kept; dropped
+ * samples behind them), inv (L,2,B*T): token row of slot c, live (L,2): live ROWS = live samples * T. */
+int editor_droppath_plan(const float* scales, int L, long B, int T, int* perm, int* inv, int* live, editor_stream_t stream);
+/* editor_layernorm_fwd (16-bit y, D % 256 == 0) writing row r's output to row perm[r] of y; a dropped row (rowscale[r] == 0) writes
+ * zeros there and copies its x row to copy_out (the block output of a dropped sample is its input).  mean / rstd: original rows. */
+int editor_layernorm_fwd_perm(const float* x, const float* gamma, const float* beta, float eps, long M, int D, void* y, int y_bf16,
+                              float* mean, float* rstd, const int* perm, const float* rowscale, float* copy_out,
+                              editor_stream_t stream);
+/* editor_layernorm_bwd_cast_parts with dy on compacted rows (dy_perm: row -> slot, dy_live: device scalar - slots >= *dy_live are
+ * dropped rows whose gradient is zero and is not read; both NULL: dense dy) and / or the cast output written to the compacted rows
+ * of its consumer branch (cast_perm; NULL: dense). */
+int editor_layernorm_bwd_cast_perm_parts(const void* dy, int dy_bf16, float dy_scale, const float* x, const float* gamma,
+                                         const float* mean, const float* rstd, long M, int D, const float* dx_in, float* dx_out,
+                                         float* workspace, int ws_rows, void* cast_out, const float* cast_rowscale,
+                                         float cast_scale, int want_colsum, const int* dy_perm, const int* dy_live,
+                                         const int* cast_perm, int* nparts, editor_stream_t stream);
+/* editor_cast_rows_colsum_parts writing row r to row perm[r] of out */
+int editor_cast_rows_colsum_perm_parts(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16,
+                                       float* workspace, int ws_rows, float scale, const int* perm, int* nparts,
+                                       editor_stream_t stream);
+/* editor_gemm_bf16 / _f16 (dtype 1 / 2; A (M,K), B (N,K) k-major, fp32 C, EDITOR_EPI_RESIDUAL) on compacted rows: output row m is
+ * scattered to row rowmap[m] of C, reading aux and rowscale there (rowmap = inv of editor_droppath_plan); m_live as editor_gemm_bf16. */
+int editor_gemm_h16_rows(int dtype, const uint16_t* A, const uint16_t* B, void* C, int M, int N, int K, long lda, long ldb, long ldc,
+                         float alpha, const float* bias, const float* rowscale, int epilogue, void* aux, long ldaux,
+                         const int* m_live, const int* rowmap, editor_stream_t stream);
+/* editor_gemm_wgrad_group with one live-row count PER problem (host array of `count` device scalars; NULL entry = all M rows) */
+int editor_gemm_wgrad_group_live(int dtype, int count, const uint16_t* const* dy, const uint16_t* const* x, float* const* dw,
+                                 const int* N, const int* K, int M, float alpha, int splitk, float* ws,
+                                 const int* const* m_live, editor_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

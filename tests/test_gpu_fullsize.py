@@ -208,6 +208,15 @@ def oracle_train_c3_dp(oracle):
     return _oracle_train_c3(oracle, 0.1)
 
 
+def _mined_pairs(feat, label):
+    """batch-hard mining of TripletLoss (layers/triplet_loss.py:84-85): per anchor the index of its farthest positive and of its
+    nearest negative, from fp32 distances of `feat`."""
+    f = feat.detach().float().cpu()
+    dist = torch.cdist(f, f)
+    same = label.view(-1, 1).eq(label.view(1, -1))
+    return dist.masked_fill(~same, -1.0).argmax(1), dist.masked_fill(same, float("inf")).argmin(1)
+
+
 def _train_step_b128_vs_oracle(dtype, o):
     from editor_amd import losses
     img, label, cam, view = o["batch"]
@@ -249,6 +258,14 @@ def _train_step_b128_vs_oracle(dtype, o):
     print(dtype, "B=128 train step (drop_path %.1f): loss rel err %.2e, worst output %.2e, worst gradient %.2e (%s)" %
           (dp, lerr, oerr, gerr[worst], worst))
     print(dtype, "   per-parameter gradient rel err:", {k.replace("BACKBONE.base.", ""): float("%.2e" % v) for k, v in gerr.items()})
+    # The loss mines ONE hardest positive / negative per anchor (triplet_loss.py:84-85): a discrete choice.  Where the product's
+    # 16-bit features order two near-tied candidates differently from the oracle's, that anchor's gradient flows through another
+    # sample - the loss moves by the (tiny) margin difference, but every gradient upstream of that pair shifts together.  Count them.
+    flips = 0
+    for i in range(1, 9, 2):
+        (pa, na), (pb, nb) = _mined_pairs(out[i], label), _mined_pairs(o["out"][i], label)
+        flips += int((pa != pb).sum() + (na != nb).sum())
+    print(dtype, "   hard-mining choices that differ from the oracle's (of %d): %d" % (8 * B, flips))
     assert lerr < TOL[dtype]["loss"]
     assert oerr < 10 * TOL[dtype]["cls4t"]       # all 9 outputs (scores, per-modality cls features, aux loss); cls4t itself is held to TOL in the eval tests
     # The patch-embedding weight gradient is ILL-CONDITIONED on this synthetic data: dW = sum_rows dx_row * pixels_row
@@ -258,8 +275,14 @@ def _train_step_b128_vs_oracle(dtype, o):
     pe = "BACKBONE.base.patch_embed.proj.weight"
     rest = {k: v for k, v in gerr.items() if k != pe}
     worst = max(rest, key=rest.get)
-    assert rest[worst] < TOL[dtype]["grad"], (worst, rest[worst])
-    assert gerr[pe] < TOL[dtype].get("grad_pe", TOL[dtype]["grad"]), gerr[pe]
+    # with mined pairs that differ (above) the bound is the flipped pairs' share of the gradient, not rounding: x 2.5 (measured with
+    # drop-path 0.1: f16 1.7e-2 on the HMA head's weights with every backbone gradient at 2e-3 .. 5e-3; bf16 4.2e-2) - the parameters the
+    # triplet term does NOT reach (classifier heads: CE only) must stay inside the plain bound either way
+    slack = 2.5 if flips else 1.0
+    assert rest[worst] < slack * TOL[dtype]["grad"], (worst, rest[worst], flips)
+    for k in ("FUSE_HEAD.weight", "BACKBONE_HEAD.weight"):
+        assert gerr[k] < TOL[dtype]["grad"], (k, gerr[k])
+    assert gerr[pe] < slack * TOL[dtype].get("grad_pe", TOL[dtype]["grad"]), gerr[pe]
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f16x2", "f16x2s", "f16", "bf16"])
