@@ -68,6 +68,8 @@ class _GemmProbe:
         self.calls = []
         self.recording = False
         self.timing = None          # list while ONE eager step is timed launch by launch, in place (in_situ below)
+        self.entry_timing = None    # list of (C-ABI entry name, e0, e1) while every library call of an eager step is timed in place
+        self.entries = {}           # entry name -> (ms per step, calls per step): the non-GEMM kernels INSIDE the step, this run
 
     def _timed(self, kind, work, fn):
         """fn() between two HIP events on the CURRENT stream (= the stream the launch goes to: the wrappers run inside whatever
@@ -190,8 +192,23 @@ class _GemmProbe:
         The operands are the step's own, in the cache state the step leaves them in - the figure the rocprofv3 kernel-trace summary
         of the same command must agree with."""
         from editor_amd import functional as fn
+        from editor_amd import ops
         side, fn.WGRAD_SIDE_STREAM = fn.WGRAD_SIDE_STREAM, False
         runs = []
+        orig_call = ops.call
+        probe = self
+
+        def timed_call(name, *a):
+            # every C-ABI entry of the library, bracketed like the GEMM launches: the durations the memory-bound kernels have INSIDE
+            # this run's step (VERDICT r5 item 8: not a committed builder CSV).  An entry = its launches (attention_bwd: both passes).
+            if probe.entry_timing is None:
+                return orig_call(name, *a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig_call(name, *a)
+            e1.record()
+            probe.entry_timing.append((name, e0, e1))
+            return r
         try:
             step_fn()                       # untimed: the eager step's allocations come out of the caching allocator afterwards (after a
             torch.cuda.synchronize()        # hipGraph capture the ordinary pool is empty: a starved GPU puts host latency between the events)
@@ -200,9 +217,26 @@ class _GemmProbe:
                 step_fn()
                 torch.cuda.synchronize()
                 runs.append(self.timing)
+            self.timing = None
+            ops.call = timed_call
+            ent_runs = []
+            for _ in range(2):
+                self.entry_timing = []
+                step_fn()
+                torch.cuda.synchronize()
+                ent_runs.append(self.entry_timing)
+            self.entry_timing = None
+            acc = {}
+            for run in ent_runs:
+                for name, e0, e1 in run:
+                    ms, n = acc.get(name, (0.0, 0))
+                    acc[name] = (ms + e0.elapsed_time(e1), n + 1)
+            self.entries = {k: (ms / len(ent_runs), n / len(ent_runs)) for k, (ms, n) in acc.items()}
         finally:
+            ops.call = orig_call
             fn.WGRAD_SIDE_STREAM = side
             self.timing = None
+            self.entry_timing = None
         by_kind = {}
         if len(runs) == 2 and len(runs[0]) == len(runs[1]):
             for (kind, work, e0, e1), (_, _, f0, f1) in zip(*runs):             # per launch: the mean of its two timings
@@ -280,7 +314,7 @@ def _in_situ_us():
     return os.path.relpath(files[-1], ROOT), out
 
 
-def hbm_kernels(model, img, b, act_dtype):
+def hbm_kernels(model, img, b, act_dtype, entries=None):
     """The memory-bound kernels of the path (north_star: "achieved HBM GB/s for the memory-bound select/gather"), each
     timed live on this GPU with HIP events on its real operand shapes; algorithmic bytes per launch from SURVEY.md 8(d).
     Every kernel rotates over `sets` independent operand sets whose footprint exceeds 512 MB, so the figure is HBM, not the
@@ -294,17 +328,29 @@ def hbm_kernels(model, img, b, act_dtype):
     m = nmod * b * t
     mods = [v for v in img.values()]
     out = []
+    # in_situ_*: the same kernel INSIDE the step.  This run's own figures (entries: C-ABI entry -> (ms per step, calls per step), HIP
+    # events around every library call of two eager steps, _GemmProbe.in_situ) when available; else the committed rocprofv3 CSV.
     src, situ = _in_situ_us()
+    if entries:
+        src, situ = "this run: HIP events around every library call of two eager steps (weight gradients on the main stream)", {}
 
     def nsets_for(footprint):
         return max(3, int(600e6 // max(footprint, 1)) + 1)
 
-    def add(name, alg_bytes, fn, nsets, match, situ_bytes=None, situ_note=None):
+    def add(name, alg_bytes, fn, nsets, match, situ_bytes=None, situ_note=None, entry=None, entry_calls=None):
         us = _event_us(fn, nsets)
         gbs = alg_bytes / us / 1e3
         ent = {"kernel": name, "alg_bytes": int(alg_bytes), "us": round(us, 1), "GB/s": round(gbs, 0),
                "frac": round(gbs / PEAK_HBM_GBS, 3), "sets": nsets}
         hit = [v for k, v in situ.items() if all(tok in k for tok in match)]
+        if entries and entry:
+            # the entry's launches of full size (entry_calls per step: the backbone's; the HMA head's few small ones ride along in
+            # the total - a slight over-estimate of the per-launch time)
+            tot = [(ms, n) for k, (ms, n) in entries.items() if (k == entry[:-1] if entry.endswith("$") else k.startswith(entry))]
+            if tot:
+                ms_, n_ = sum(t_[0] for t_ in tot), sum(t_[1] for t_ in tot)
+                hit = [1e3 * ms_ / (entry_calls or n_)]
+                ent["in_situ_calls_per_step"] = round(n_, 1)
         if hit:
             ent["in_situ_us"] = round(max(hit), 1)
             ent["in_situ_frac"] = round((situ_bytes or alg_bytes) / max(hit) / 1e3 / PEAK_HBM_GBS, 3)
@@ -316,13 +362,14 @@ def hbm_kernels(model, img, b, act_dtype):
     n = nsets_for(nmod * px)
     imgs = [[v.clone() for v in mods] for _ in range(n)]
     add("freq_counts4_kernel (Haar DWT -> mean -> IDWT -> positive count)", nmod * px,
-        lambda i: ops.freq_counts(imgs[i][0], imgs[i][1], imgs[i][2], imgs[i][3] if nmod > 3 else None), n, ("freq_counts",))
+        lambda i: ops.freq_counts(imgs[i][0], imgs[i][1], imgs[i][2], imgs[i][3] if nmod > 3 else None), n, ("freq_counts",),
+        entry="editor_freq_counts")
     del imgs
     n = nsets_for(2 * nmod * b * t * d * 4)
     feats = [torch.randn(nmod, b, t, d, device=dev) for _ in range(n)]
     index = (torch.rand(b, t - 1, device=dev) > 0.5).to(torch.uint8)
     add("sfts_apply_kernel (mask apply + BCC partial sums)", 2 * feats[0].numel() * 4, lambda i: ops.sfts_apply(feats[i], index, True),
-        n, ("sfts_apply_kernel",))
+        n, ("sfts_apply_kernel",), entry="editor_sfts_apply$")
     del feats
     g = torch.ones(d, device=dev)
     bb = torch.zeros(d, device=dev)
@@ -331,15 +378,18 @@ def hbm_kernels(model, img, b, act_dtype):
         qkvs = [(torch.randn(m, 3 * d, device=dev) * 0.5).to(act_dtype) for _ in range(n)]
         lses = [ops.attention_fwd(q, nmod * b, t, heads, d // heads)[1] for q in qkvs]
         add("attn_rollout_step_kernel (one layer: q,k + lse in, r out)", m * 2 * d * 2 + 2 * heads * m * 4,
-            lambda i: ops.attn_rollout_qk([(qkvs[i], lses[i])], nmod * b, t, heads, d // heads), n, ("attn_rollout_step_kernel",))
+            lambda i: ops.attn_rollout_qk([(qkvs[i], lses[i])], nmod * b, t, heads, d // heads), n, ("attn_rollout_step_kernel",),
+            entry="editor_attn_rollout_step")
         add("attn_q_pass_kernel fwd (qkv in, o out)", m * 4 * d * 2,
-            lambda i: ops.attention_fwd(qkvs[i], nmod * b, t, heads, d // heads), n, ("attn_q_pass_kernel", "false, true, false, false"))
+            lambda i: ops.attention_fwd(qkvs[i], nmod * b, t, heads, d // heads), n, ("attn_q_pass_kernel", "false, true, false, false"),
+            entry="editor_attention_fwd", entry_calls=base.depth)
         del qkvs, lses
     esz = 4 if act_dtype == torch.float32 else 2
     n = nsets_for(m * d * (4 + esz))
     xs = [torch.randn(m, d, device=dev) for _ in range(n)]
     add("layernorm_fwd_kernel", m * d * (4 + esz), lambda i: ops.layernorm_fwd(xs[i], g, bb, 1e-6, act_dtype), n,
-        ("layernorm_fwd_kernel", "unsigned short" if esz == 2 else "float"))
+        ("layernorm_fwd_kernel", "unsigned short" if esz == 2 else "float"), entry="editor_layernorm_fwd",
+        entry_calls=2 * base.depth + 1)
     n = 3
     xs = xs[:n]
     ys, means, rstds = zip(*[ops.layernorm_fwd(x, g, bb, 1e-6, act_dtype) for x in xs])
@@ -349,7 +399,8 @@ def hbm_kernels(model, img, b, act_dtype):
         ("layernorm_bwd_kernel", "unsigned short, 3, true" if esz == 2 else "float"),
         situ_bytes=m * d * (esz + 4 + 4 + 4 + esz) if esz == 2 else None,
         situ_note="in the step the M = 3*B*T launches are the CAST form (also writes the 16-bit copy of dx: + M*D*2 bytes); the plain "
-                  "instantiation of the profile is the compacted HMA head's small launches" if esz == 2 else None)
+                  "instantiation of the profile is the compacted HMA head's small launches" if esz == 2 else None,
+        entry="editor_layernorm_bwd_cast" if esz == 2 else "editor_layernorm_bwd", entry_calls=2 * base.depth - 1 if esz == 2 else None)
     return out, src
 
 
@@ -1075,11 +1126,16 @@ def main():
                 roof["sclk_mhz_during_step"] = round(mhz[0], 0)
                 roof["sclk_mhz_min_max_0p5ms"] = None if mhz[1] is None else [round(mhz[1][0], 0), round(mhz[1][1], 0)]
         if not args.no_replay:
-            roof["hbm_kernels"], roof["hbm_kernels_in_situ_source"] = hbm_kernels(model, img, b, model.act_dtype)
+            roof["hbm_kernels"], roof["hbm_kernels_in_situ_source"] = hbm_kernels(model, img, b, model.act_dtype, probe.entries)
+            if probe.entries:               # the step's non-GEMM time by library entry, this run (ms per step, calls per step)
+                other = {k: v for k, v in probe.entries.items() if not k.startswith("editor_gemm")}
+                roof["non_gemm_in_situ"] = {"ms_per_step": round(sum(v[0] for v in other.values()), 3),
+                                            "top": {k: [round(v[0], 3), round(v[1], 1)] for k, v in
+                                                    sorted(other.items(), key=lambda kv: -kv[1][0])[:14]}}
             roof["hbm_kernels_note"] = ("us / frac: this run, HIP events, every kernel rotating over `sets` operand sets > 512 MB (HBM, not the "
-                                        "256 MB Infinity Cache); in_situ_*: the same kernel's average duration inside the step, from the committed "
-                                        "rocprofv3 profile - there its operands were written by the previous kernel and are partly cache-resident "
-                                        "(a fraction above 1 is that, not a faster HBM)")
+                                        "256 MB Infinity Cache); in_situ_*: the same kernel's average duration inside the step (source: "
+                                        "hbm_kernels_in_situ_source) - there its operands were written by the previous kernel and are partly "
+                                        "cache-resident (a fraction above 1 is that, not a faster HBM)")
         out = {
             "metric": "tri-modal images/sec fwd+bwd @ B=128 ViT-B",
             "value": round(world * b * args.steps / elapsed, 2),

@@ -105,6 +105,20 @@ int ensure_lds(int bytes)
     return 0;
 }
 
+// compute units of the current device (cached per device index): the stagger below is laid out for 256 CUs in 8 XCDs
+inline int device_cus()
+{
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
 // exact-erf GELU in fp32 (split-precision forward: the activation is evaluated on the UNROUNDED pre-activation, as
 // nn.GELU does on the reference's fp32 CPU path, vit_pytorch.py:139-145)
 __device__ __forceinline__ float gelu_exact(float a) { return 0.5f * a * (1.f + erff(a * 0.70710678118654752f)); }
@@ -418,6 +432,10 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
     const bool add_bias = g.bias && split == 0;
     float* Cf = C_F32 ? reinterpret_cast<float*>(g.C) + (g.splitk > 1 ? (long)split * g.M * g.ldc : 0L) : nullptr;
     bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+    // row scatter (compacted rows): only the LIVE rows are written - the rows of the last live tile behind *m_live belong to dropped
+    // samples, whose output rows the producer of the compacted operand has already filled (and whose A rows may lie beyond the tiles
+    // the product before this one computed: with a different tile height there, 0 * garbage would be NaN)
+    if (EPI == EDITOR_EPI_RESIDUAL && g.rowmap && g.m_live) mlim = min(mlim, *g.m_live);
     // branch-free body per epilogue kind, all LDS reads of a half issued before the first use
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -1632,6 +1650,9 @@ int launch_pp_t(GemmB16Args g, hipStream_t stream)
     // measured: the LDS-staged epilogue (full-line 16-byte stores) beats the direct one on every layout here
     // (fwd N=2304,K=768: 701 vs 530 TFLOP/s; dgrad 974 vs 905)
     g.pp_staged = 1;
+    // EDITOR_EPI_STAGGER's phase table ((bid >> 3) & 31 over the first 256 workgroups, one per CU) is MI355X's 256 CUs in 8 XCDs: on a
+    // part with another CU count the spin would only delay workgroups - there the launch runs without it (same bits)
+    if (g.stagger && device_cus() != 256) g.stagger = 0;
 #ifdef EDITOR_DEBUG_TRACE
     // Debug build only (libeditor_debug.so, tools/gemm_bench.py): experiment switches and the per-workgroup phase
     // timeline.  The product library has no environment lookups, allocations or synchronisation in its entry points.

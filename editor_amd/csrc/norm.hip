@@ -148,14 +148,19 @@ __global__ __launch_bounds__(256) void layernorm_fwd_perm_kernel(const float* __
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
     T* yr = y + (long)perm[row] * D;
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    if (dead) {                                       // (wave-uniform: one wave per row)
+#pragma unroll
+        for (int i = 0; i < kMaxV; ++i) if (i < nv) {
+            const int c0 = (i * 64 + lane) * 4;
+            Vec4<T>::st(yr + c0, make_float4(0.f, 0.f, 0.f, 0.f));
+            *reinterpret_cast<float4*>(copy_out + row * D + c0) = v[i];
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < kMaxV; ++i) if (i < nv) {
         const int c0 = (i * 64 + lane) * 4;
-        if (dead) {
-            Vec4<T>::st(yr + c0, make_float4(0.f, 0.f, 0.f, 0.f));
-            *reinterpret_cast<float4*>(copy_out + row * D + c0) = v[i];
-            continue;
-        }
         const float4 g = *reinterpret_cast<const float4*>(gamma + c0);
         const float4 bt = *reinterpret_cast<const float4*>(beta + c0);
         float4 o;
@@ -165,7 +170,6 @@ __global__ __launch_bounds__(256) void layernorm_fwd_perm_kernel(const float* __
         o.w = (v[i].w - mean) * rstd * g.w + bt.w;
         Vec4<T>::st(yr + c0, o);
     }
-    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 
 // ------------------------------------------------------------------------------------------------

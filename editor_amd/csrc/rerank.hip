@@ -232,11 +232,15 @@ __global__ void __launch_bounds__(256) rerank_final_kernel(const uint16_t* __res
 
 }  // namespace
 
+// every stage indexes the N = Q + G images through grid.y (rows) somewhere in the pipeline (rank sort, expand, final): one limit for
+// all entry points, checked before anything is launched
+constexpr int kMaxImages = 65535;
+
 extern "C" {
 
 int editor_rerank_normalise(const float* dist, int N, float* colmax, float* od, editor_stream_t stream)
 {
-    if (N <= 0 || !dist || !colmax || !od) return (int)hipErrorInvalidValue;
+    if (N <= 0 || N > kMaxImages || !dist || !colmax || !od) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     colmax_kernel<<<(N + 255) / 256, 256, 0, st>>>(dist, N, colmax);
     transpose_div_kernel<<<dim3((N + 31) / 32, (N + 31) / 32), 256, 0, st>>>(dist, colmax, N, od);
@@ -247,7 +251,7 @@ int editor_rerank_normalise(const float* dist, int N, float* colmax, float* od, 
 int editor_rerank_weights(const float* od, const int* rank, int N, int k1, int k1_half, uint16_t* V, editor_stream_t stream)
 {
     // (k + 1 entries of a ranking are looked at; every image has at least that many neighbours)
-    if (N <= 0 || k1 < 1 || k1 + 1 > kMaxK1 || k1_half < 0 || k1_half + 1 > kMaxHalf || k1 + 1 > N || N > 131072)
+    if (N <= 0 || k1 < 1 || k1 + 1 > kMaxK1 || k1_half < 0 || k1_half + 1 > kMaxHalf || k1 + 1 > N || N > kMaxImages || !od || !rank || !V)
         return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(V, 0, (size_t)N * N * sizeof(uint16_t), st);
@@ -260,7 +264,7 @@ int editor_rerank_weights(const float* od, const int* rank, int N, int k1, int k
 
 int editor_rerank_expand(const uint16_t* V, const int* rank, int N, int k2, uint16_t* Vq, editor_stream_t stream)
 {
-    if (N <= 0 || k2 < 1 || k2 > N) return (int)hipErrorInvalidValue;
+    if (N <= 0 || N > kMaxImages || k2 < 1 || k2 > N || !V || !rank || !Vq) return (int)hipErrorInvalidValue;
     rerank_expand_kernel<<<dim3((N + 255) / 256, N), 256, 0, (hipStream_t)stream>>>(V, rank, N, k2, Vq);
     EDITOR_LAUNCH_CHECK();
     return 0;
@@ -269,7 +273,7 @@ int editor_rerank_expand(const uint16_t* V, const int* rank, int N, int k2, uint
 int editor_rerank_final(const uint16_t* V, uint16_t* Vt, const float* od, int N, int Q, int one_minus_lambda_f16_bits,
                         float lambda, float* final_dist, editor_stream_t stream)
 {
-    if (N <= 0 || Q <= 0 || Q >= N) return (int)hipErrorInvalidValue;
+    if (N <= 0 || N > kMaxImages || Q <= 0 || Q >= N || !V || !Vt || !od || !final_dist) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     transpose_u16_kernel<<<dim3((N + 63) / 64, (N + 63) / 64), 256, 0, st>>>(V, N, Vt);
     rerank_final_kernel<<<dim3((N - Q + 1023) / 1024, Q), 256, 0, st>>>(V, Vt, od, N, Q, (uint16_t)one_minus_lambda_f16_bits, lambda, final_dist);

@@ -62,13 +62,22 @@ def argsort_rows(distmat):
 
 def re_ranking(probFea, galFea, k1, k2, lambda_value, local_distmat=None, only_local=False):
     """k-reciprocal re-ranking (utils/reranking.py:30-101) on the device: (Q, G) fp32 final distance, a device tensor.
-    Dense N x N stages over all N = Q + G images (csrc/rerank.hip); the float16 storage / arithmetic of the reference is reproduced."""
+    Dense N x N stages over all N = Q + G images (csrc/rerank.hip).  The reference's float16 storage / arithmetic is followed
+    operation by operation: every stage is bit-equal to numpy's FROM THE SAME INPUTS (tests/test_gpu_retrieval.py); end to end the
+    result is tolerance-close, not bit-equal - expf differs from numpy's exp in the last place and near-tied distances can order
+    differently.  Limits (checked here, documented divergences from the reference, which slices short neighbour lists silently and
+    takes any k1): k1 <= 63, N >= k1 + 1, N <= 65 535; local_distmat / only_local are not implemented - the evaluator's call
+    (utils/metrics.py:278: k1=50, k2=15, lambda=0.3, no local distances) is inside all of them."""
     if local_distmat is not None or only_local:
         raise NotImplementedError("re_ranking: local_distmat / only_local are not used by the path (utils/metrics.py:278)")
     qf, gf = _rows(probFea), _rows(galFea)
     if not qf.is_cuda:
         raise RuntimeError("re_ranking: features must be on the GPU (there is no CPU fallback)")
     nq, n = qf.shape[0], qf.shape[0] + gf.shape[0]
+    if n > 65535:
+        raise ValueError("re_ranking: at most 65 535 images (query + gallery) - the device stages index rows through grid.y")
+    if int(k1) > 63 or int(k1) + 1 > n:
+        raise ValueError("re_ranking: k1 <= 63 and k1 + 1 <= Q + G (the device kernel holds a neighbour list of k1 + 1 in LDS)")
     dev = qf.device
     feat = torch.cat([qf, gf]).contiguous()
     dist = euclidean_distance(feat, feat)

@@ -77,7 +77,7 @@ def test_fc2_on_compacted_rows_scatters_the_same_bits(dtype):
              aux=x1)
     gc = torch.zeros_like(g)
     gc[p.long()] = g                                                               # compacted operand (dropped rows behind the prefix)
-    gc[int(lv):] = 0
+    gc[int(lv):] = float("nan")              # behind the live prefix: whatever the allocator left (fc1 skips those tiles) - must not be read into a result
     out = torch.full_like(x1, float("nan"))
     dead = rs == 0
     out[dead] = x1[dead]                                                           # what LayerNorm-2 leaves for the dropped rows

@@ -108,7 +108,15 @@ def test_config2_eval_b128_vs_oracle(dtype, oracle_eval_c2):
     assert torch.equal(aux["mask_fre"].cpu().bool(), o["aux"]["mask_fre"])              # integer path: exact in any mode
     masks = [aux["attn_masks"][i].cpu().bool() for i in range(3)]
     if dtype in ("f32", "f16x2", "f16x2s"):
-        if _check_selection_f32(aux, o["aux"]):
+        ties = _check_selection_f32(aux, o["aux"])
+        if dtype == "f16x2s":
+            # the mode `value_at_parity` is quoted on - on THIS batch (seeds 61 / 62, the bench's accuracy protocol at
+            # the benchmarked size) not one of the 4 608 (sample, head) rows may differ: no verified-tie allowance, every mask equal
+            assert ties == 0
+            for i in range(3):
+                assert torch.equal(masks[i], o["aux"]["attn_masks"][i])
+            assert torch.equal(aux["index"].cpu().bool(), o["aux"]["index"])
+        if ties:
             m.teacher_index = o["aux"]["index"]
             with torch.no_grad():
                 out = m(gimg, cam_label=cam.cuda(), view_label=view.cuda())

@@ -845,3 +845,86 @@ def test_resid_add_layernorm_fwd(ops, m, d, dtype):
     with pytest.raises(RuntimeError):                      # D = 384: not a multiple of 256 - an error, not a silent fallback
         ops.resid_add_layernorm_fwd(torch.zeros(8, 384, device="cuda"), torch.zeros(8, 384, dtype=dtype, device="cuda"), None,
                                     torch.ones(384, device="cuda"), torch.zeros(384, device="cuda"), 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_stagger_and_tile_height_do_not_change_a_bit(ops, dtype):
+    """EDITOR_EPI_STAGGER (the first round's workgroups start spread in time: a per-workgroup s_memtime spin, ON by default
+    for the dense qkv forward) and the counted-vmcnt choreography behind it must leave every output bit as it was - plain, bias,
+    GELU + saved gelu', fp32 residual, 208-row tiles, column sums - at a size with more than one round of workgroups."""
+    m, k = 3 * 32 * 129, 768                                        # 12 384 rows: 49 x 9 = 441 tiles of a 2304-wide output
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn(m, k, device="cuda", generator=g).to(dtype)
+    st = ops.EPI_STAGGER(24)
+
+    def run(n, epilogue, c_dtype, **kw):
+        w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).to(dtype)
+        bias = torch.randn(n, device="cuda", generator=g)
+        outs = []
+        for extra in (0, st):
+            c = torch.empty(m, n, dtype=c_dtype, device="cuda")
+            aux = kw.get("aux")
+            kw2 = dict(kw)
+            if aux == "new":
+                kw2["aux"] = torch.empty(m, n, dtype=dtype, device="cuda")
+            cs = torch.empty(n, dtype=torch.float32, device="cuda") if kw.get("colsum") else None
+            if cs is not None:
+                kw2["colsum"] = cs
+            ops.gemm(a, w, c, m, n, k, k, k, n, 0, 0, bias=bias, epilogue=epilogue | extra | ops.EPI_FORCE_PP, **kw2)
+            outs.append((c, kw2.get("aux") if aux == "new" else None, cs))
+        torch.cuda.synchronize()
+        for x, y in zip(outs[0], outs[1]):
+            if x is not None:
+                assert torch.equal(x, y), (n, epilogue)
+
+    run(2304, 0, dtype)                                               # qkv forward (+ bias): the product the stagger ships for
+    run(3072, ops.EPI_GELU | ops.EPI_AUX_GRAD, dtype, aux="new")      # fc1 + GELU, saved gelu'
+    resid = torch.randn(m, 768, device="cuda", generator=g)
+    run(768, ops.EPI_RESIDUAL, torch.float32, aux=resid, rowscale=torch.rand(m, device="cuda", generator=g))
+    run(768, ops.EPI_RESIDUAL | ops.EPI_TILE_ROWS(208), torch.float32, aux=resid)
+    run(3072, 0, dtype, colsum=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_k_tile_choreographies_agree_bit_for_bit(dtype):
+    """the two-phase K-tile (32-MFMA clusters; default for the weight-gradient layout) against the four-phase one, built
+    as libeditor_gemm_alt.so by `python -m editor_amd.build --alt` (EDITOR_ALT_PHASES=4): a block's grouped weight gradients and a
+    forward product, every bit.  Skipped when the alternative library was not built / is older than the kernel source."""
+    import ctypes
+    import os
+    from editor_amd import _lib, build, ops as ops_mod
+    src = os.path.join(build.CSRC, "gemm_bf16.hip")
+    if not os.path.exists(build.LIB_ALT) or os.path.getmtime(build.LIB_ALT) < os.path.getmtime(src):
+        pytest.skip("libeditor_gemm_alt.so not built from the current gemm_bf16.hip (python -m editor_amd.build --alt)")
+    lib = _lib.lib()
+    names = ("editor_gemm_bf16", "editor_gemm_f16", "editor_gemm_wgrad_group")
+
+    def route(alt):
+        srcl = ctypes.CDLL(build.LIB_ALT) if alt else lib.cdll
+        for name in names:
+            fn_ = getattr(srcl, name)
+            fn_.argtypes = lib.protos[name]
+            fn_.restype = ctypes.c_int
+            lib._fn[name] = fn_
+    m = 3 * 32 * 129
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x768 = torch.randn(m, 768, device="cuda", generator=g).to(dtype)
+    x3072 = torch.randn(m, 3072, device="cuda", generator=g).to(dtype)
+    dy2304 = torch.randn(m, 2304, device="cuda", generator=g).to(dtype)
+    dy768 = torch.randn(m, 768, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(2304, 768, device="cuda", generator=g) * 0.05).to(dtype)
+    res = []
+    try:
+        for alt in (False, True):
+            route(alt)
+            dws = [torch.empty(2304, 768, device="cuda"), torch.empty(768, 768, device="cuda"), torch.empty(3072, 768, device="cuda"),
+                   torch.empty(768, 3072, device="cuda")]
+            ops_mod.gemm_wgrad_group([(dy2304, x768, dws[0]), (dy768, x768, dws[1]), (x3072, x768, dws[2]), (dy768, x3072, dws[3])], m)
+            y = torch.empty(m, 2304, dtype=dtype, device="cuda")
+            ops_mod.gemm(x768, w, y, m, 2304, 768, 768, 768, 2304, 0, 0, epilogue=ops_mod.EPI_FORCE_PP)
+            torch.cuda.synchronize()
+            res.append(dws + [y])
+    finally:
+        route(False)
+    for p_, q_ in zip(*res):
+        assert torch.equal(p_, q_)
