@@ -120,9 +120,9 @@ class _GemmProbe:
 
         def recorded_split(a, b, c, c_lo, m, n, k, **kw):
             if probe.recording:
-                probe.calls.append(["fwd", (m, n, k, kw.get("m_live"), False), ("split", a, b, c, c_lo, m, n, k), dict(kw)])
+                probe.calls.append(["fwd", probe._work(m, n, k, kw, False), ("split", a, b, c, c_lo, m, n, k), dict(kw)])
             if probe.timing is not None:
-                return probe._timed("fwd", (m, n, k, kw.get("m_live"), False), lambda: probe._orig_split(a, b, c, c_lo, m, n, k, **kw))
+                return probe._timed("fwd", probe._work(m, n, k, kw, False), lambda: probe._orig_split(a, b, c, c_lo, m, n, k, **kw))
             return probe._orig_split(a, b, c, c_lo, m, n, k, **kw)
         ops.gemm_split = recorded_split
         # the four weight gradients of a block as one grouped launch (editor_gemm_wgrad_group)
@@ -1131,7 +1131,7 @@ def main():
                 other = {k: v for k, v in probe.entries.items() if not k.startswith("editor_gemm")}
                 roof["non_gemm_in_situ"] = {"ms_per_step": round(sum(v[0] for v in other.values()), 3),
                                             "top": {k: [round(v[0], 3), round(v[1], 1)] for k, v in
-                                                    sorted(other.items(), key=lambda kv: -kv[1][0])[:14]}}
+                                                    sorted(other.items(), key=lambda kv: -kv[1][0])[:(200 if os.environ.get("EDITOR_BENCH_ENTRIES") else 14)]}}
             roof["hbm_kernels_note"] = ("us / frac: this run, HIP events, every kernel rotating over `sets` operand sets > 512 MB (HBM, not the "
                                         "256 MB Infinity Cache); in_situ_*: the same kernel's average duration inside the step (source: "
                                         "hbm_kernels_in_situ_source) - there its operands were written by the previous kernel and are partly "

@@ -1822,7 +1822,7 @@ int gemm_h16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, in
 // GELU), A (M,K) and B (N,K) k-major half pairs, always on the 256x256 ping-pong kernel (any M, N; K % 64 == 0).
 int gemm_f16x2(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi, const uint16_t* B_lo, void* C, void* C_lo,
     int c_f32, int M, int N, int K, long lda, long ldb, long ldc, float alpha, const float* bias, const float* rowscale,
-    int epilogue, void* aux, long ldaux, const int* m_live, hipStream_t stream)
+    int epilogue, void* aux, long ldaux, const int* m_live, hipStream_t stream, const int* rowmap = nullptr)
 {
     if (M <= 0 || N < 8 || K <= 0 || (K % BK) || (N & 7) || (lda & 7) || (ldb & 7) || (ldc & 7) || (ldaux & 7))
         return (int)hipErrorInvalidValue;
@@ -1838,9 +1838,11 @@ int gemm_f16x2(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi,
     if (epilogue != EDITOR_EPI_NONE && !aux && epilogue != EDITOR_EPI_GELU) return (int)hipErrorInvalidValue;   // (GELU, aux NULL: no-grad forward)
     if (epilogue == EDITOR_EPI_GELU && (c_f32 || !aux_grad)) return (int)hipErrorInvalidValue;   // aux = gelu'(x) for the backward
     if (epilogue == EDITOR_EPI_RESIDUAL && !c_f32) return (int)hipErrorInvalidValue;
+    if (rowmap && (epilogue != EDITOR_EPI_RESIDUAL || M < 256 || N < 256)) return (int)hipErrorInvalidValue;   // (see GemmB16Args::rowmap)
     GemmB16Args g{(const bf16_t*)A_hi, (const bf16_t*)B_hi, C, M, N, K, lda, ldb, ldc, alpha, 0.f, bias, rowscale, 1, 0, 0,
                   epilogue, aux, ldaux, 0, m_live, 0, 1, nullptr, nullptr, 1, 1, tile_frags,
                   (const bf16_t*)A_lo, (const bf16_t*)B_lo, C_lo};
+    g.rowmap = rowmap;
     if (tile_frags == 13)
         return c_f32 ? launch_pp_t<true, true, true, true, 7, 6, true>(g, stream) : launch_pp_t<true, true, true, false, 7, 6, true>(g, stream);
     return c_f32 ? launch_pp_t<true, true, true, true, 8, 8, true>(g, stream) : launch_pp_t<true, true, true, false, 8, 8, true>(g, stream);
@@ -2084,6 +2086,16 @@ extern "C" int editor_gemm_f16x2(const uint16_t* A_hi, const uint16_t* A_lo, con
 {
     return gemm_f16x2(A_hi, A_lo, B_hi, B_lo, C, C_lo, c_f32, M, N, K, lda, ldb, ldc, alpha, bias, rowscale, epilogue, aux, ldaux,
                       m_live, stream);
+}
+
+// editor_gemm_f16x2 (fp32 C, EDITOR_EPI_RESIDUAL) with an output ROW MAP: the split-precision fc2 of a stochastic-depth-compacted MLP
+extern "C" int editor_gemm_f16x2_rows(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi, const uint16_t* B_lo, void* C,
+    int M, int N, int K, long lda, long ldb, long ldc, float alpha, const float* bias, const float* rowscale, int epilogue, void* aux,
+    long ldaux, const int* m_live, const int* rowmap, hipStream_t stream)
+{
+    if (!rowmap) return (int)hipErrorInvalidValue;
+    return gemm_f16x2(A_hi, A_lo, B_hi, B_lo, C, nullptr, 1, M, N, K, lda, ldb, ldc, alpha, bias, rowscale, epilogue, aux, ldaux,
+                      m_live, stream, rowmap);
 }
 
 extern "C" int editor_gemm_bf16(const uint16_t* A, const uint16_t* B, void* C, int c_f32, int M, int N, int K, long lda,

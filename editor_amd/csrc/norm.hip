@@ -121,10 +121,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // copies its x row to copy_out - the block output of a dropped sample is its input (the fc2 epilogue scatters the live rows
 // only).  mean / rstd stay indexed by the original row.  Same per-row arithmetic as layernorm_fwd_kernel.  D % 256 == 0.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool SPLIT = false>       // SPLIT: y as the half pair (y, y_lo) of the split-precision forward
 __global__ __launch_bounds__(256) void layernorm_fwd_perm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, long M, int D, T* __restrict__ y, float* __restrict__ mean_out,
-    float* __restrict__ rstd_out, const int* __restrict__ perm, const float* __restrict__ rowscale, float* __restrict__ copy_out)
+    float* __restrict__ rstd_out, const int* __restrict__ perm, const float* __restrict__ rowscale, float* __restrict__ copy_out,
+    T* __restrict__ y_lo = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -147,13 +148,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_perm_kernel(const float* __
         q += (a * a + b * b) + (c * c + d * d);
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-    T* yr = y + (long)perm[row] * D;
+    const long slot = perm[row];
+    T* yr = y + slot * D;
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
     if (dead) {                                       // (wave-uniform: one wave per row)
 #pragma unroll
         for (int i = 0; i < kMaxV; ++i) if (i < nv) {
             const int c0 = (i * 64 + lane) * 4;
             Vec4<T>::st(yr + c0, make_float4(0.f, 0.f, 0.f, 0.f));
+            if constexpr (SPLIT) Vec4<T>::st(y_lo + slot * D + c0, make_float4(0.f, 0.f, 0.f, 0.f));
             *reinterpret_cast<float4*>(copy_out + row * D + c0) = v[i];
         }
         return;
@@ -168,7 +171,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_perm_kernel(const float* __
         o.y = (v[i].y - mean) * rstd * g.y + bt.y;
         o.z = (v[i].z - mean) * rstd * g.z + bt.z;
         o.w = (v[i].w - mean) * rstd * g.w + bt.w;
-        Vec4<T>::st(yr + c0, o);
+        if constexpr (SPLIT) st_split(yr + c0, y_lo + slot * D + c0, o);
+        else Vec4<T>::st(yr + c0, o);
     }
 }
 
@@ -1016,6 +1020,18 @@ extern "C" int editor_layernorm_fwd_perm(const float* x, const float* gamma, con
         return (int)hipErrorInvalidValue;
     DISPATCH_T(y_bf16, hipLaunchKernelGGL(layernorm_fwd_perm_kernel<TT>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream,
                x, gamma, beta, eps, M, D, (TT*)y, mean, rstd, perm, rowscale, copy_out));
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int editor_layernorm_fwd_perm_f16x2(const float* x, const float* gamma, const float* beta, float eps, long M, int D,
+    uint16_t* y_hi, uint16_t* y_lo, float* mean, float* rstd, const int* perm, const float* rowscale, float* copy_out,
+    hipStream_t stream)
+{
+    if ((D & 255) || D > 256 * kMaxV || M <= 0 || !perm || !rowscale || !copy_out || !mean || !rstd || !y_hi || !y_lo)
+        return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((layernorm_fwd_perm_kernel<f16_t, true>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream,
+                       x, gamma, beta, eps, M, D, (f16_t*)y_hi, mean, rstd, perm, rowscale, copy_out, (f16_t*)y_lo);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

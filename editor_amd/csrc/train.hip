@@ -232,21 +232,31 @@ __global__ __launch_bounds__(256) void droppath_plan_kernel(const float* __restr
                                                             int* __restrict__ inv, int* __restrict__ live)
 {
     extern __shared__ int slot[];                              // [B] compacted sample position
+    __shared__ int part[256];                                  // live samples in each thread's chunk -> exclusive prefix
     const long u = blockIdx.x;                                 // (block, branch) unit
     const float* sc = scales + u * B * T;
-    for (long s = threadIdx.x; s < B; s += blockDim.x) slot[s] = sc[s * T] != 0.f ? 1 : 0;
+    const int per = (int)((B + 255) / 256);                    // consecutive samples per thread (order-preserving scan)
+    const long s0 = (long)threadIdx.x * per, s1 = min(B, s0 + per);
+    int mine = 0;
+    for (long s = s0; s < s1; ++s) { const int k = sc[s * T] != 0.f ? 1 : 0; slot[s] = k; mine += k; }
+    part[threadIdx.x] = mine;
     __syncthreads();
-    if (threadIdx.x == 0) {                                    // B is a few hundred samples: a serial scan is microseconds
-        int nl = 0;
-        for (long s = 0; s < B; ++s) nl += slot[s];
-        int pl = 0, pd = nl;
-        for (long s = 0; s < B; ++s) { const int k = slot[s]; slot[s] = k ? pl++ : pd++; }
-        live[u] = nl * T;
+    for (int off = 1; off < 256; off <<= 1) {                  // Hillis-Steele inclusive scan over the 256 chunk counts
+        const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
     }
+    const int nl = part[255];
+    int pl = part[threadIdx.x] - mine;                         // live samples before this chunk
+    int pd = nl + (int)s0 - pl;                                // dropped samples before it, behind all live ones
+    for (long s = s0; s < s1; ++s) { const int k = slot[s]; slot[s] = k ? pl++ : pd++; }
+    if (threadIdx.x == 0 && blockIdx.y == 0) live[u] = nl * T;
     __syncthreads();
     int* pu = perm + u * B * T;
     int* iu = inv + u * B * T;
-    for (long e = threadIdx.x; e < B * T; e += blockDim.x) {
+    // (every workgroup of a unit repeats the scan - a few hundred samples - and fills its share of the rows)
+    for (long e = (long)blockIdx.y * blockDim.x + threadIdx.x; e < B * T; e += (long)gridDim.y * blockDim.x) {
         const long s = e / T;
         const int tok = (int)(e - s * T);
         const int c = slot[s] * T + tok;
@@ -328,8 +338,8 @@ extern "C" int editor_droppath_scales(const float* rates, int L, long B, int T, 
 extern "C" int editor_droppath_plan(const float* scales, int L, long B, int T, int* perm, int* inv, int* live, hipStream_t stream)
 {
     if (L < 1 || B < 1 || T < 1 || B > 12288 || B * T > 0x7FFFFFFFL || !scales || !perm || !inv || !live) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(droppath_plan_kernel, dim3((unsigned)(L * 2)), dim3(256), (size_t)B * sizeof(int), stream, scales, B, T, perm,
-                       inv, live);
+    hipLaunchKernelGGL(droppath_plan_kernel, dim3((unsigned)(L * 2), 16), dim3(256), (size_t)B * sizeof(int), stream, scales, B, T,
+                       perm, inv, live);
     EDITOR_LAUNCH_CHECK();
     return 0;
 }

@@ -498,8 +498,9 @@ class TransformerBlockFn(torch.autograd.Function):
         # draw dropped the branch (rowscale_mlp == 0: x2 = x1 + 0, no gradient through it - vit_pytorch.py:66-68,218) are not
         # computed: LayerNorm-2 writes the live samples' rows compacted, fc1 / fc2 and the whole MLP backward run on that prefix
         # (`live` rows, a device scalar: tiles beyond it exit), the fc2 epilogue scatters back.  Same bits for every live row.
-        plan = drop_plan if _plan_ok(act_dtype, m, d, fc1w.shape[0], cu, mask, m_live, branch16, defer_out, pend_branch,
-                                     rowscale_mlp) else None
+        # (the split-precision modes: the MLP's forward on half pairs - or, F16X2H, as plain f16 - and an f16 backward either way)
+        plan = drop_plan if _plan_ok(torch.float16 if act_dtype in (F16X2, F16X2H) else act_dtype, m, d, fc1w.shape[0], cu, mask,
+                                     m_live, branch16, defer_out, pend_branch, rowscale_mlp) else None
         ctx.plan = plan
         head_done = split_all = False
         if act_dtype in (F16X2, F16X2H):
@@ -530,16 +531,21 @@ class TransformerBlockFn(torch.autograd.Function):
             ops.gemm_split((ao, aol), wp, x1, None, m, d, d, alpha=inv_ws, bias=projb, rowscale=rowscale_attn,
                            epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)
             del aol
-            h2, h2l, mean2, rstd2 = ops.layernorm_fwd_split(x1, n2w, n2b, eps, mask, m_live)
+            x2 = torch.empty_like(x2d)
+            if plan is not None:         # stochastic-depth compaction (see above): the same three launches on the live prefix
+                h2, h2l, mean2, rstd2 = ops.layernorm_fwd_split_perm(x1, n2w, n2b, eps, plan[0], rowscale_mlp, x2)
+            else:
+                h2, h2l, mean2, rstd2 = ops.layernorm_fwd_split(x1, n2w, n2b, eps, mask, m_live)
+            live = plan[2] if plan is not None else m_live
             a = torch.empty(m, hidden, dtype=act_dtype, device=x.device) if (FWD_GRAD and any(ctx.needs_input_grad)) else None
             g = torch.empty(m, hidden, dtype=act_dtype, device=x.device)
             gl = torch.empty_like(g)
             ops.gemm_split((h2, h2l), w1, g, gl, m, hidden, d, alpha=inv_ws, bias=fc1b, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD,
-                           aux=a, m_live=m_live)
+                           aux=a, m_live=live, live_dense=plan is not None)
             del h2l
-            x2 = torch.empty_like(x2d)
             ops.gemm_split((g, gl), w2, x2, None, m, d, hidden, alpha=inv_ws, bias=fc2b, rowscale=rowscale_mlp,
-                           epilogue=ops.EPI_RESIDUAL, aux=x1, m_live=m_live)
+                           epilogue=ops.EPI_RESIDUAL, aux=x1, m_live=live, live_dense=plan is not None,
+                           rowmap=plan[1] if plan is not None else None)
             del gl
             ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, ao, x1, mean2, rstd2, h2, a, g, n1w, n2w,
                                   qkvw, projw, fc1w, fc2w, mask, attn_saved, rowscale_attn, rowscale_mlp, cu, m_live)
@@ -548,7 +554,8 @@ class TransformerBlockFn(torch.autograd.Function):
             ctx.meta = (b, t, d, heads, act_dtype, qkvb is not None, projb is not None, fc1b is not None, fc2b is not None,
                         tuple(x.shape), qk_scale, sink)
             out = x2.view(x.shape)
-            _cast_boxes(ctx, x, out, m, d, act_dtype, mask, cu, m_live, rowscale_mlp, fc2b is not None, sink, True)
+            _cast_boxes(ctx, x, out, m, d, act_dtype, mask, cu, m_live, rowscale_mlp, fc2b is not None, sink, True,
+                        plan[0] if plan is not None else None)
             return out
         wp, w1, w2 = (act_weight(w, act_dtype) for w in (projw, fc1w, fc2w))
         if not head_done:

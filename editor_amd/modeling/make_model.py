@@ -420,7 +420,7 @@ class EDITOR(nn.Module):
                     self._drop_state = torch.full((1,), seed0, dtype=torch.int64, device=dev)
                 scales = ops.droppath_scales_dev(self._drop_rates_dev, btot, t, self._drop_state)
             self.last_drop_scales = scales             # (depth, 2, nmod*B*T) per-row branch scales of this forward (tests read them)
-            if self.drop_skip and self.act_dtype in ops.HALF_DTYPES and not self.split_fwd and not self.branch16:
+            if self.drop_skip and self.act_dtype in ops.HALF_DTYPES and not self.branch16:
                 # round 6: the samples a branch's draw dropped are not computed (functional.TransformerBlockFn `drop_plan`):
                 # token rows of every (block, branch) ordered live samples first, one small launch for the whole backbone
                 plans = ops.droppath_plan(scales, base.depth, btot, t)

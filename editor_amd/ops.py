@@ -593,6 +593,17 @@ def layernorm_fwd_split(x2d, gamma, beta, eps, rowmask=None, m_live=None):
     return hi, lo, mean, rstd
 
 
+def layernorm_fwd_split_perm(x2d, gamma, beta, eps, perm, rowscale, copy_out):
+    """layernorm_fwd_perm as the half pair of the split-precision forward -> hi, lo, mean, rstd."""
+    m, d = x2d.shape
+    hi = torch.empty(m, d, dtype=torch.float16, device=x2d.device)
+    lo = torch.empty(m, d, dtype=torch.float16, device=x2d.device)
+    mean = torch.empty(m, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(m, dtype=torch.float32, device=x2d.device)
+    call("editor_layernorm_fwd_perm_f16x2", x2d, gamma, beta, float(eps), m, d, hi, lo, mean, rstd, perm, rowscale, copy_out)
+    return hi, lo, mean, rstd
+
+
 def im2col16_split(img):
     imgs = list(img) if isinstance(img, (list, tuple)) else [img]
     b, c, h, w = imgs[0].shape
@@ -606,13 +617,19 @@ def im2col16_split(img):
     return hi, lo
 
 
-def gemm_split(a, b, c, c_lo, m, n, k, alpha=1.0, bias=None, rowscale=None, epilogue=0, aux=None, m_live=None):
+def gemm_split(a, b, c, c_lo, m, n, k, alpha=1.0, bias=None, rowscale=None, epilogue=0, aux=None, m_live=None, live_dense=False,
+               rowmap=None):
     """c (fp32, c_lo None) or (c, c_lo) half pair = alpha * (a_hi + a_lo)(b_hi + b_lo)^T (+bias) (*rowscale) (+epilogue);
-    a = (hi, lo) (M,K), b = (hi, lo) (N,K), all contiguous."""
-    if SHORT_TILES and m >= 2048 and n >= 512 and m_live is None and not (int(epilogue) & 0xF000):
+    a = (hi, lo) (M,K), b = (hi, lo) (N,K), all contiguous.  live_dense / rowmap: as ops.gemm (stochastic-depth-compacted rows)."""
+    if SHORT_TILES and m >= 2048 and n >= 512 and (m_live is None or live_dense) and not (int(epilogue) & 0xF000):
         th = gemm_tile_rows(m, n)
         if th != 256:
             epilogue = int(epilogue) | EPI_TILE_ROWS(th)
+    if rowmap is not None:
+        assert c.dtype == torch.float32 and c_lo is None and (int(epilogue) & 0xFF) == EPI_RESIDUAL
+        call("editor_gemm_f16x2_rows", a[0], a[1], b[0], b[1], c, m, n, k, k, k, n, float(alpha), bias, rowscale, int(epilogue), aux,
+             n, m_live, rowmap)
+        return
     call("editor_gemm_f16x2", a[0], a[1], b[0], b[1], c, c_lo, 1 if c.dtype == torch.float32 else 0, m, n, k, k, k, n,
          float(alpha), bias, rowscale, int(epilogue), aux, n, m_live)
 

@@ -560,6 +560,14 @@ int editor_cast_rows_colsum_perm_parts(const float* in, const float* rowscale, l
 int editor_gemm_h16_rows(int dtype, const uint16_t* A, const uint16_t* B, void* C, int M, int N, int K, long lda, long ldb, long ldc,
                          float alpha, const float* bias, const float* rowscale, int epilogue, void* aux, long ldaux,
                          const int* m_live, const int* rowmap, editor_stream_t stream);
+/* the split-precision ('f16x2') forms of the two: LayerNorm onto compacted rows as the half pair (y_hi, y_lo); editor_gemm_f16x2
+ * (fp32 C, EDITOR_EPI_RESIDUAL) with the output row map */
+int editor_layernorm_fwd_perm_f16x2(const float* x, const float* gamma, const float* beta, float eps, long M, int D, uint16_t* y_hi,
+                                    uint16_t* y_lo, float* mean, float* rstd, const int* perm, const float* rowscale,
+                                    float* copy_out, editor_stream_t stream);
+int editor_gemm_f16x2_rows(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi, const uint16_t* B_lo, void* C, int M,
+                           int N, int K, long lda, long ldb, long ldc, float alpha, const float* bias, const float* rowscale,
+                           int epilogue, void* aux, long ldaux, const int* m_live, const int* rowmap, editor_stream_t stream);
 /* editor_gemm_wgrad_group with one live-row count PER problem (host array of `count` device scalars; NULL entry = all M rows) */
 int editor_gemm_wgrad_group_live(int dtype, int count, const uint16_t* const* dy, const uint16_t* const* x, float* const* dw,
                                  const int* N, const int* K, int M, float alpha, int splitk, float* ws,

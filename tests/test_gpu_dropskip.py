@@ -112,7 +112,7 @@ def _step(skip, dtype, b=64, seed=17):
     return [o.detach().clone() for o in out], loss.detach().clone(), grads, m.last_drop_scales.clone(), m.last_aux["index"].clone()
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f16x2", "f16x2s"])
 def test_training_step_with_skipping_equals_the_step_without(dtype):
     assert fn.DROP_SKIP
     out0, loss0, g0, sc0, idx0 = _step(False, dtype)
