@@ -70,6 +70,8 @@ __global__ void sum_scalar_kernel(const float* __restrict__ v, int n, float scal
     if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + scale * s;
 }
 
+__global__ void add_const_kernel(float* v, float c) { v[0] += c; }
+
 __global__ void row_sqnorm_kernel(const float* __restrict__ f, long ldf, int D, float* __restrict__ sq)
 {
     __shared__ float red[16];
@@ -186,7 +188,77 @@ __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restric
 
 }  // namespace
 
+// CenterLoss.forward (layers/center_loss.py:30-51): distmat[i,k] = |x_i|^2 + |c_k|^2 - 2 x_i . c_k (the expanded form the reference
+// computes with addmm_), masked to k = label_i, EVERY entry clamped to [1e-12, 1e12] - the B (C - 1) masked-out zeros each contribute
+// 1e-12 - summed and divided by B.  One workgroup per sample: row[i] = clamp(d_i) with d_i kept for the backward's clamp gate.
+__global__ __launch_bounds__(256) void center_loss_fwd_kernel(const float* __restrict__ x, const float* __restrict__ centers,
+    const long* __restrict__ label, int D, float* __restrict__ dist, float* __restrict__ row)
+{
+    __shared__ float red[16];
+    const int i = blockIdx.x;
+    const float* xi = x + (long)i * D;
+    const float* ck = centers + label[i] * D;
+    float xx = 0.f, cc = 0.f, xc = 0.f;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) { const float a = xi[c], b = ck[c]; xx += a * a; cc += b * b; xc += a * b; }
+    xx = block_sum(xx, red); __syncthreads();
+    cc = block_sum(cc, red); __syncthreads();
+    xc = block_sum(xc, red);
+    if (threadIdx.x == 0) {
+        const float d = (xx + cc) - 2.f * xc;
+        dist[i] = d;
+        row[i] = fminf(fmaxf(d, 1e-12f), 1e12f);
+    }
+}
+// dx_i = dloss * 2 (x_i - c_{y_i}) / B where d_i lies inside the clamp range, else 0
+__global__ __launch_bounds__(256) void center_loss_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ centers,
+    const long* __restrict__ label, const float* __restrict__ dist, const float* __restrict__ dloss, int B, int D, float* __restrict__ dx)
+{
+    const int i = blockIdx.x;
+    const float gate = (dist[i] >= 1e-12f && dist[i] <= 1e12f) ? 2.f * dloss[0] / (float)B : 0.f;
+    const float* xi = x + (long)i * D;
+    const float* ck = centers + label[i] * D;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) dx[(long)i * D + c] = gate * (xi[c] - ck[c]);
+}
+// dc_k = -dloss * 2 / B * sum_{i: y_i = k} (x_i - c_k), samples in index order (deterministic); classes without a sample get zeros
+__global__ __launch_bounds__(256) void center_loss_bwd_c_kernel(const float* __restrict__ x, const float* __restrict__ centers,
+    const long* __restrict__ label, const float* __restrict__ dist, const float* __restrict__ dloss, int B, int D, float* __restrict__ dc)
+{
+    const long k = blockIdx.x;
+    const float sc = -2.f * dloss[0] / (float)B;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float s = 0.f;
+        const float ckc = centers[k * D + c];
+        for (int i = 0; i < B; ++i)
+            if (label[i] == k && dist[i] >= 1e-12f && dist[i] <= 1e12f) s += x[(long)i * D + c] - ckc;
+        dc[k * D + c] = sc * s;
+    }
+}
+
 extern "C" {
+
+int editor_center_loss_fwd(const float* x, const float* centers, const long* label, int B, int C, int D, float* dist, float* row,
+                           float* loss, editor_stream_t stream)
+{
+    if (B <= 0 || C <= 0 || D <= 0 || !x || !centers || !label || !dist || !row || !loss) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    center_loss_fwd_kernel<<<B, 256, 0, st>>>(x, centers, label, D, dist, row);
+    sum_scalar_kernel<<<1, 256, 0, st>>>(row, B, 1.f / (float)B, loss, 0);
+    // the masked-out entries of the reference's (B, C) matrix: B (C - 1) zeros clamped to 1e-12, / B
+    add_const_kernel<<<1, 1, 0, st>>>(loss, (float)((double)(C - 1) * 1e-12));
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
+
+int editor_center_loss_bwd(const float* x, const float* centers, const long* label, const float* dist, const float* dloss, int B, int C,
+                           int D, float* dx, float* dcenters, editor_stream_t stream)
+{
+    if (B <= 0 || C <= 0 || D <= 0 || !x || !centers || !label || !dist || !dloss) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) center_loss_bwd_x_kernel<<<B, 256, 0, st>>>(x, centers, label, dist, dloss, B, D, dx);
+    if (dcenters) center_loss_bwd_c_kernel<<<C, 256, 0, st>>>(x, centers, label, dist, dloss, B, D, dcenters);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
 
 int editor_ce_smooth_fwd(const float* logits, const long* target, int B, int C, float eps, float* row_loss, float* loss,
                          int accumulate, editor_stream_t stream)

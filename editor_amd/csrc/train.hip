@@ -222,6 +222,54 @@ __global__ void droppath_dev_kernel(const float* __restrict__ rates, int L, long
 }
 __global__ void advance_state_kernel(long* state) { state[0] += 1; }
 
+// torch.optim.AdamW (solver/make_optimizer.py:23-24: OPTIMIZER_NAME 'AdamW', per-parameter lr / weight decay groups, betas (0.9, 0.999),
+// eps 1e-8, no amsgrad) over the same chunk tables as sgd_multi_kernel, the operations of torch's single-tensor path in its order:
+//   p *= 1 - lr * wd ; m = lerp(m, g, 1 - b1) ; v = b2 * v + (1 - b2) g g ; p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// t lives in device memory (step[0], advanced by adam_advance_kernel before the update: hipGraph-replay safe).  Overflow skip,
+// loss-scale and 16-bit shadow as sgd_multi_kernel; a skipped step does not advance t (adam_advance_kernel reads the flag too).
+template <bool F16>
+__global__ __launch_bounds__(256) void adamw_multi_kernel(float* const* __restrict__ p_ptrs, const float* const* __restrict__ g_ptrs,
+    float* const* __restrict__ m_ptrs, float* const* __restrict__ v_ptrs, const int* __restrict__ chunk_tensor,
+    const long* __restrict__ chunk_off, const long* __restrict__ numel, const float* __restrict__ lr, const float* __restrict__ wd,
+    double beta1d, double beta2d, float eps, const float* __restrict__ step, uint16_t* const* __restrict__ h_ptrs,
+    int* __restrict__ nonfinite, const float* __restrict__ inv_scale_dev, const int* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    const float gsc = inv_scale_dev ? *inv_scale_dev : 1.f;
+    const int t = chunk_tensor[blockIdx.x];
+    if (!g_ptrs[t]) return;
+    const long off = chunk_off[blockIdx.x];
+    const long n = min((long)kChunk, numel[t] - off);
+    float* __restrict__ p = p_ptrs[t] + off;
+    const float* __restrict__ g = g_ptrs[t] + off;
+    float* __restrict__ m = m_ptrs[t] + off;
+    float* __restrict__ v = v_ptrs[t] + off;
+    uint16_t* __restrict__ h = (h_ptrs && h_ptrs[t]) ? h_ptrs[t] + off : nullptr;
+    const float l = lr[t], decay = 1.f - l * wd[t];
+    // the scalar factors in double, as torch computes them on the host (1 - 0.999f differs from 0.001 by 1.3e-5: too coarse in float)
+    const double tt = (double)step[0];
+    const float beta1 = (float)beta1d, beta2 = (float)beta2d;
+    const float omb1 = (float)(1.0 - beta1d), omb2 = (float)(1.0 - beta2d);
+    const float bc2s = (float)sqrt(1.0 - pow(beta2d, tt));
+    const float step_size = (float)((double)l / (1.0 - pow(beta1d, tt)));
+    bool bad = false;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const float gr = g[i];
+        bad |= !isfinite(gr);
+        const float gv = gr * gsc;
+        float pv = p[i] * decay;
+        float mv = m[i];
+        mv = mv + omb1 * (gv - mv);                            // lerp_(grad, 1 - beta1)
+        const float vv = beta2 * v[i] + omb2 * (gv * gv);       // mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        const float denom = sqrtf(vv) / bc2s + eps;
+        pv -= step_size * (mv / denom);
+        m[i] = mv; v[i] = vv; p[i] = pv;
+        if (h) h[i] = H16<F16>::from_f32(pv);
+    }
+    if (nonfinite && __builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(nonfinite, 1);
+}
+__global__ void adam_advance_kernel(float* step, const int* skip) { if (!(skip && *skip)) step[0] += 1.f; }
+
 // Stochastic-depth COMPACTION plan (round 6): for every (block, branch) the token rows ordered live samples first - a sample
 // whose draw is 0 contributes nothing to the branch (vit_pytorch.py:66-68: x.div(keep_prob) * 0) and gets no gradient through
 // it, so the branch's LayerNorm / products / their backward run on the live prefix only.  One workgroup per (block, branch):
@@ -314,6 +362,24 @@ extern "C" int editor_split_multi(const float* const* p_ptrs, uint16_t* const* h
     return 0;
 }
 extern "C" int editor_sgd_chunk_elems(void) { return kChunk; }
+
+extern "C" int editor_adamw_multi(float* const* p_ptrs, const float* const* g_ptrs, float* const* m_ptrs, float* const* v_ptrs,
+    const int* chunk_tensor, const long* chunk_off, const long* numel, const float* lr, const float* wd, double beta1, double beta2,
+    float eps, float* step, long nchunks, uint16_t* const* h_ptrs, int shadow_dtype, int* nonfinite, const float* inv_scale,
+    const int* skip, hipStream_t stream)
+{
+    if (nchunks < 1) return 0;
+    if (!step || !v_ptrs || (h_ptrs && shadow_dtype != 1 && shadow_dtype != 2)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, stream, step, skip);
+    if (shadow_dtype == 2)
+        hipLaunchKernelGGL(adamw_multi_kernel<true>, dim3((unsigned)nchunks), dim3(256), 0, stream, p_ptrs, g_ptrs, m_ptrs, v_ptrs,
+                           chunk_tensor, chunk_off, numel, lr, wd, beta1, beta2, eps, step, h_ptrs, nonfinite, inv_scale, skip);
+    else
+        hipLaunchKernelGGL(adamw_multi_kernel<false>, dim3((unsigned)nchunks), dim3(256), 0, stream, p_ptrs, g_ptrs, m_ptrs, v_ptrs,
+                           chunk_tensor, chunk_off, numel, lr, wd, beta1, beta2, eps, step, h_ptrs, nonfinite, inv_scale, skip);
+    EDITOR_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int editor_transpose_multi(const uint16_t* const* src, uint16_t* const* dst, const int* rows, const int* cols,
     const int* tile_tensor, const int* tile_r, const int* tile_c, long ntiles, hipStream_t stream)

@@ -1002,6 +1002,24 @@ class CrossEntropyLabelSmoothFn(torch.autograd.Function):
         return ops.ce_smooth_bwd(logits, target, ctx.eps, dloss.contiguous().view(1).float()), None, None
 
 
+class CenterLossFn(torch.autograd.Function):
+    """CenterLoss.forward (layers/center_loss.py:30-51)."""
+
+    @staticmethod
+    def forward(ctx, x, centers, label):
+        x, centers = x.contiguous().float(), centers.contiguous().float()
+        loss, dist = ops.center_loss_fwd(x, centers, label.contiguous())
+        ctx.save_for_backward(x, centers, label, dist)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        x, centers, label, dist = ctx.saved_tensors
+        dx, dc = ops.center_loss_bwd(x, centers, label, dist, dloss.contiguous().view(1).float(), ctx.needs_input_grad[0],
+                                     ctx.needs_input_grad[1])
+        return dx, dc, None
+
+
 class TripletSoftMarginFn(torch.autograd.Function):
     """TripletLoss(margin=None).forward (layers/triplet_loss.py:121-136): batch-hard mining + SoftMarginLoss."""
 

@@ -21,19 +21,24 @@ def triplet_soft_margin(feat, labels):
 
 
 class CenterLoss(torch.nn.Module):
-    """Parameter holder with the reference's name and shape (layers/center_loss.py:19-29: `centers` (C, feat_dim),
-    N(0,1), on the CPU as make_loss builds it with use_gpu=False).  train_net.py:72-74 hands it to make_optimizer and
-    do_train; with the shipped METRIC_LOSS_TYPE ('triplet') its forward is never called (processor.py:97-100 touches
-    it only when 'center' is in the loss type), so no kernel exists for it."""
+    """layers/center_loss.py:9-51: `centers` (C, feat_dim) ~ N(0,1) and forward(x, labels) = sum of the masked (B, C) squared-distance
+    matrix, every entry clamped to [1e-12, 1e12], / B - as HIP kernels (csrc/loss.hip: editor_center_loss_fwd / _bwd).  make_loss builds
+    it with use_gpu=False (the parameter starts on the CPU, train_net.py:72-74 hands it to make_optimizer); with the shipped
+    METRIC_LOSS_TYPE ('triplet') its forward is never called (layers/make_loss.py:36-56 has no centre term; processor.py:97-100 only
+    rescales its gradient when 'center' is in the loss type) - it is here so that a harness which does call it runs.  Like every op of
+    this package it needs GPU tensors: move the module with .cuda() / .to(device) first."""
 
-    def __init__(self, num_classes=751, feat_dim=2048):
+    def __init__(self, num_classes=751, feat_dim=2048, use_gpu=False):
         super().__init__()
-        self.num_classes, self.feat_dim = num_classes, feat_dim
-        self.centers = torch.nn.Parameter(torch.randn(num_classes, feat_dim))
+        self.num_classes, self.feat_dim, self.use_gpu = num_classes, feat_dim, use_gpu
+        c = torch.randn(num_classes, feat_dim)
+        self.centers = torch.nn.Parameter(c.cuda() if use_gpu else c)
 
     def forward(self, x, labels):
-        raise NotImplementedError("center loss is not on the EDITOR hot path (METRIC_LOSS_TYPE is 'triplet' in every "
-                                  "shipped config)")
+        assert x.size(0) == labels.size(0), "features.size(0) is not equal to labels.size(0)"
+        if not (x.is_cuda and self.centers.is_cuda):
+            raise RuntimeError("CenterLoss (MI355X build): features and centers must be on the GPU; there is no CPU fallback path")
+        return Fn.CenterLossFn.apply(x, self.centers, labels)
 
 
 def _loss_func(cfg=None):

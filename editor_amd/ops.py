@@ -1034,6 +1034,23 @@ def ocfr_bwd(fn, inv, centers, label, dloss):
     return df
 
 
+def center_loss_fwd(x, centers, label):
+    """-> loss (1) fp32, dist (B) (own-class squared distances, saved for the backward)."""
+    b, d = x.shape
+    dist = torch.empty(b, dtype=torch.float32, device=x.device)
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    call("editor_center_loss_fwd", x, centers, label, b, centers.shape[0], d, dist, workspace(x.device, b), loss)
+    return loss, dist
+
+
+def center_loss_bwd(x, centers, label, dist, dloss, want_x=True, want_c=True):
+    b, d = x.shape
+    dx = torch.empty_like(x) if want_x else None
+    dc = torch.empty_like(centers) if want_c else None
+    call("editor_center_loss_bwd", x, centers, label, dist, dloss, b, centers.shape[0], d, dx, dc)
+    return dx, dc
+
+
 def ce_smooth_fwd(logits, target, eps, loss, accumulate):
     b, c = logits.shape
     call("editor_ce_smooth_fwd", logits, target, b, c, float(eps), workspace(logits.device, b), loss,

@@ -236,10 +236,8 @@ class FusedSGD:
                     self._found.zero_()              # (the scaler's update kernel clears its own flag)
                 _lib.call("editor_grad_check_multi", dev_tab, self.chunk_t, self.chunk_o, self.numel, self.nchunks, found,
                           self._nonfinite)
-            _lib.call("editor_sgd_multi", self.p_ptrs, dev_tab, self.m_ptrs, self.chunk_t, self.chunk_o, self.numel,
-                      self.lr, self.wd, float(self.momentum), self.nchunks, self.h_ptrs,
-                      2 if self.shadow_dtype == torch.float16 else 1, None if check else self._nonfinite,
-                      sc._inv_scale if sc is not None else None, found if check else None)
+            self._launch_update(dev_tab, None if check else self._nonfinite, sc._inv_scale if sc is not None else None,
+                                found if check else None)
             if self.pairs is not None:
                 from . import ops
                 _lib.call("editor_split_multi", self.p_ptrs, self.hi_ptrs, self.lo_ptrs, self.chunk_t, self.chunk_o, self.numel,
@@ -263,6 +261,58 @@ class FusedSGD:
                                               if h is not None and p.grad is not None), transposed=True)
         if self.pairs is not None:
             functional.install_weight_pairs((p, pr[0], pr[1]) for (_, p), pr in zip(self.params, self.pairs) if pr is not None)
+
+
+    def _launch_update(self, g_tab, nonfinite, inv_scale, skip):
+        _lib.call("editor_sgd_multi", self.p_ptrs, g_tab, self.m_ptrs, self.chunk_t, self.chunk_o, self.numel,
+                  self.lr, self.wd, float(self.momentum), self.nchunks, self.h_ptrs,
+                  2 if self.shadow_dtype == torch.float16 else 1, nonfinite, inv_scale, skip)
+
+
+class FusedAdamW(FusedSGD):
+    """torch.optim.AdamW as solver/make_optimizer.py:23-24 builds it (OPTIMIZER_NAME 'AdamW': the per-parameter groups keep their own
+    lr / weight decay, betas (0.9, 0.999), eps 1e-8, decoupled weight decay) in ONE HIP launch (editor_adamw_multi) - everything else
+    (gradient buckets, 16-bit shadows, overflow protocol, hipGraph-replay safety: the step count lives on the device) is FusedSGD's.
+    `state_dict()` uses torch.optim.AdamW's layout: {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups'}."""
+
+    def __init__(self, named_params, base_lr=1e-3, weight_decay=1e-2, bias_lr_factor=1.0, weight_decay_bias=None, betas=(0.9, 0.999),
+                 eps=1e-8, **kw):
+        super().__init__(named_params, base_lr=base_lr, weight_decay=weight_decay, bias_lr_factor=bias_lr_factor,
+                         weight_decay_bias=weight_decay if weight_decay_bias is None else weight_decay_bias, momentum=0.0, **kw)
+        self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+        self.defaults = dict(lr=base_lr, betas=self.betas, eps=self.eps, weight_decay=weight_decay, amsgrad=False)
+        for g in self.param_groups:
+            for k in ("momentum", "dampening", "nesterov"):
+                g.pop(k, None)
+            g.update(betas=self.betas, eps=self.eps, amsgrad=False)
+        self.bufs_sq = [torch.zeros_like(b) for b in self.bufs]                       # exp_avg_sq (self.bufs = exp_avg)
+        self.v_ptrs = torch.tensor([b.data_ptr() for b in self.bufs_sq], dtype=torch.int64, device=self.device)
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def _launch_update(self, g_tab, nonfinite, inv_scale, skip):
+        _lib.call("editor_adamw_multi", self.p_ptrs, g_tab, self.m_ptrs, self.v_ptrs, self.chunk_t, self.chunk_o, self.numel,
+                  self.lr, self.wd, self.betas[0], self.betas[1], self.eps, self.step_count, self.nchunks, self.h_ptrs,
+                  2 if self.shadow_dtype == torch.float16 else 1, nonfinite, inv_scale, skip)
+
+    def state_dict(self):
+        sd = super().state_dict()
+        t = self.step_count.detach().clone().cpu().view(())
+        sd["state"] = {i: {"step": t.clone(), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
+                       for i, (m, v) in enumerate(zip(self.bufs, self.bufs_sq))}
+        return sd
+
+    def load_state_dict(self, sd):
+        state = sd["state"]
+        super().load_state_dict({"state": {}, "param_groups": sd["param_groups"]})
+        t = 0.0
+        for i, (m, v) in enumerate(zip(self.bufs, self.bufs_sq)):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                m.zero_(); v.zero_()
+                continue
+            m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+            t = max(t, float(st["step"]))
+        self.step_count.fill_(t)
 
 
 class DeviceGradScaler:

@@ -15,7 +15,7 @@ import math
 
 import torch
 
-from .optim import FusedSGD
+from .optim import FusedAdamW, FusedSGD
 
 
 def param_group_table(cfg, names):
@@ -37,12 +37,18 @@ def make_optimizer(cfg, model, center_criterion=None):
     """solver/make_optimizer.py:4-29 -> (FusedSGD over the groups of param_group_table, SGD of the centre criterion)."""
     s = cfg.SOLVER
     name = getattr(s, "OPTIMIZER_NAME", "SGD")
-    if name != "SGD":
-        raise NotImplementedError("the fused HIP update implements the reference's shipped optimizer (SGD, "
-                                  "configs/*/EDITOR.yml OPTIMIZER_NAME: 'SGD'); got %r" % (name,))
-    opt = FusedSGD(model.named_parameters(), base_lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY,
-                   bias_lr_factor=s.BIAS_LR_FACTOR, weight_decay_bias=s.WEIGHT_DECAY_BIAS, momentum=s.MOMENTUM,
-                   shadow_dtype=_shadow_dtype(model), split_pairs=bool(getattr(getattr(model, "module", model), "split_fwd", False)))
+    common = dict(shadow_dtype=_shadow_dtype(model), split_pairs=bool(getattr(getattr(model, "module", model), "split_fwd", False)))
+    if name == "SGD":
+        opt = FusedSGD(model.named_parameters(), base_lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY,
+                       bias_lr_factor=s.BIAS_LR_FACTOR, weight_decay_bias=s.WEIGHT_DECAY_BIAS, momentum=s.MOMENTUM, **common)
+    elif name == "AdamW":
+        # make_optimizer.py:23-24: torch.optim.AdamW(params, lr=BASE_LR, weight_decay=WEIGHT_DECAY) - the per-parameter groups built
+        # above it (:6-19) carry their own lr / weight decay, which override those defaults; betas / eps are torch's
+        opt = FusedAdamW(model.named_parameters(), base_lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY,
+                         bias_lr_factor=s.BIAS_LR_FACTOR, weight_decay_bias=s.WEIGHT_DECAY_BIAS, **common)
+    else:
+        raise NotImplementedError("the fused HIP update implements the optimizers the reference names (solver/make_optimizer.py:21-24: "
+                                  "'SGD', 'AdamW'); got %r" % (name,))
     for g, (n, lr, wd) in zip(opt.param_groups, param_group_table(cfg, [g["name"] for g in opt.param_groups])):
         g["lr"], g["weight_decay"] = lr, wd
     opt.sync_param_groups()

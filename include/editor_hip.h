@@ -390,6 +390,13 @@ int editor_ocfr_bwd(const float* fnorm, const float* inv_norm, const float* cent
 
 /* ---- loss head (layers/make_loss.py:36-56 consumes the hot path's train-mode outputs) ------- */
 
+/* CenterLoss.forward (layers/center_loss.py:30-51): loss = sum over the (B, C) matrix [k == label_i] (|x_i|^2 + |c_k|^2 - 2 x_i.c_k), every
+ * entry clamped to [1e-12, 1e12], / B.  x (B,D), centers (C,D) fp32, label (B) int64; dist (B) receives the unclamped own-class
+ * distances (saved for the backward's clamp gate), row (B) is scratch.  Backward: dx (B,D) and / or dcenters (C,D) (either may be NULL). */
+int editor_center_loss_fwd(const float* x, const float* centers, const long* label, int B, int C, int D, float* dist, float* row,
+                           float* loss, editor_stream_t stream);
+int editor_center_loss_bwd(const float* x, const float* centers, const long* label, const float* dist, const float* dloss, int B, int C,
+                           int D, float* dx, float* dcenters, editor_stream_t stream);
 /* CrossEntropyLabelSmooth(eps).forward (layers/softmax_loss.py:21-34): loss (+)= mean_b( -sum_c soft_bc log_softmax_bc ),
  * soft = (1-eps) onehot + eps/C.  row_loss: B floats of scratch.  bwd: dlogits = dloss[0]/B * (softmax - soft). */
 int editor_ce_smooth_fwd(const float* logits, const long* target, int B, int C, float eps, float* row_loss, float* loss,
@@ -503,6 +510,13 @@ int editor_sgd_multi(float* const* p_ptrs, const float* const* g_ptrs, float* co
                      const float* inv_scale /* device scalar multiplied into every gradient (1 / loss scale); NULL = 1 */,
                      const int* skip /* device flag: nonzero -> the whole update is skipped (GradScaler.step); NULL = never */,
                      editor_stream_t stream);
+/* torch.optim.AdamW over the same tables (solver/make_optimizer.py:23-24): m_ptrs = exp_avg, v_ptrs = exp_avg_sq (fp32, zero at start);
+ * step: device scalar holding the step count t as a float, advanced by one by this call BEFORE the update (not when *skip is set);
+ * betas / eps by value.  p *= 1 - lr wd; m = lerp(m, g, 1 - b1); v = b2 v + (1 - b2) g^2; p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps). */
+int editor_adamw_multi(float* const* p_ptrs, const float* const* g_ptrs, float* const* m_ptrs, float* const* v_ptrs,
+                       const int* chunk_tensor, const long* chunk_off, const long* numel, const float* lr, const float* wd,
+                       double beta1, double beta2, float eps, float* step, long nchunks, uint16_t* const* h_ptrs, int shadow_dtype,
+                       int* nonfinite, const float* inv_scale, const int* skip, editor_stream_t stream);
 /* amp.GradScaler's overflow check (engine/processor.py:94-96 -> torch/amp/grad_scaler.py): found[0] |= 1 (and sticky[0] |= 1,
  * optional) when any gradient element of the tensors in the chunk tables is inf / nan.  Run BEFORE editor_sgd_multi with
  * skip = found. */

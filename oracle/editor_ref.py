@@ -422,6 +422,16 @@ def triplet_soft_margin(feat, labels):
     return F.soft_margin_loss(d_an - d_ap, torch.ones_like(d_an))
 
 
+def center_loss(x, centers, labels):
+    """CenterLoss.forward (layers/center_loss.py:30-51): expanded squared distances, masked to the own class, EVERY entry of the
+    (B, C) matrix clamped to [1e-12, 1e12] (the masked-out zeros become 1e-12 each), summed, / B."""
+    b, c = x.shape[0], centers.shape[0]
+    distmat = x.pow(2).sum(dim=1, keepdim=True).expand(b, c) + centers.pow(2).sum(dim=1, keepdim=True).expand(c, b).t()
+    distmat = distmat - 2.0 * (x @ centers.t())
+    mask = labels.unsqueeze(1).expand(b, c).eq(torch.arange(c).long().expand(b, c))
+    return (distmat * mask.float()).clamp(min=1e-12, max=1e12).sum() / b
+
+
 def loss_pairs(output, target):
     """engine/processor.py:82-92: (score_i, feat_i) pairs + trailing aux loss."""
     loss = output[-1] if len(output) % 2 == 1 else 0.0

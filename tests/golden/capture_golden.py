@@ -524,3 +524,24 @@ def f17_rerank(seed=171):
 
 if __name__ == "__main__" and "f17" in sys.argv[1:]:
     f17_rerank()
+
+
+def f18_center_loss(seed=181):
+    """F18: CenterLoss.forward (layers/center_loss.py:30-51) - value and both gradients, from the reference class itself."""
+    ref_shims.install()
+    from layers.center_loss import CenterLoss
+    b, c, d = 32, 50, 768
+    x = synth.normal(seed, "cl/x", (b, d), 1.0).requires_grad_(True)
+    cen = synth.normal(seed, "cl/c", (c, d), 1.0)
+    lab = torch.arange(4).repeat_interleave(8) * 7 + 3
+    cl = CenterLoss(num_classes=c, feat_dim=d, use_gpu=False)
+    with torch.no_grad():
+        cl.centers.copy_(cen)
+    loss = cl(x, lab)
+    (3.0 * loss).backward()
+    save("f18_center_loss", loss=loss, dx=x.grad[:, :64], dx_norm=x.grad.norm(), dc=cl.centers.grad[lab.unique()][:, :64],
+         dc_norm=cl.centers.grad.norm(), label=lab, seed=seed, shape=np.asarray([b, c, d]))
+
+
+if __name__ == "__main__" and "f18" in sys.argv[1:]:
+    f18_center_loss()

@@ -74,3 +74,42 @@ def test_loss_rejects_cpu_tensors():
     from editor_amd import losses
     with pytest.raises(Exception):
         losses.cross_entropy_label_smooth(torch.randn(4, 5), torch.tensor([0, 1, 2, 3]))
+
+
+def test_center_loss_vs_reference_golden_and_oracle(oracle):
+    """CenterLoss (layers/center_loss.py:30-51) on the device: the reference's own value / gradients (golden f18), then a second shape
+    against the oracle, through the module with the reference's name (editor_amd.losses.CenterLoss)."""
+    from conftest import load_golden
+    from editor_amd import losses
+    g = load_golden("f18_center_loss")
+    seed = int(g["seed"])
+    b, c, d = (int(v) for v in g["shape"])
+    x = synth.normal(seed, "cl/x", (b, d), 1.0).cuda().requires_grad_(True)
+    lab = torch.from_numpy(g["label"]).cuda()
+    cl = losses.CenterLoss(num_classes=c, feat_dim=d).cuda()
+    with torch.no_grad():
+        cl.centers.copy_(synth.normal(seed, "cl/c", (c, d), 1.0))
+    loss = cl(x, lab)
+    assert rel_err(loss.detach().cpu(), g["loss"]) < 1e-5
+    (3.0 * loss).backward()
+    assert rel_err(x.grad[:, :64].cpu(), g["dx"]) < 1e-5 and abs(x.grad.norm().item() / float(g["dx_norm"]) - 1) < 1e-5
+    uniq = lab.unique()
+    assert rel_err(cl.centers.grad[uniq][:, :64].cpu(), g["dc"]) < 1e-5
+    assert abs(cl.centers.grad.norm().item() / float(g["dc_norm"]) - 1) < 1e-5
+    # B = 128, 2304-wide features (cls4t), 171 classes
+    x2 = synth.normal(7, "cl2/x", (128, 2304), 1.0)
+    c2 = synth.normal(7, "cl2/c", (171, 2304), 1.0)
+    lab2 = torch.arange(8).repeat_interleave(16) * 5
+    xr, cr = x2.clone().requires_grad_(True), c2.clone().requires_grad_(True)
+    lr = oracle.center_loss(xr, cr, lab2)
+    lr.backward()
+    cl2 = losses.CenterLoss(num_classes=171, feat_dim=2304).cuda()
+    with torch.no_grad():
+        cl2.centers.copy_(c2)
+    xg = x2.cuda().requires_grad_(True)
+    lg = cl2(xg, lab2.cuda())
+    lg.backward()
+    assert rel_err(lg.detach().cpu(), lr.detach()) < 1e-5
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-5 and rel_err(cl2.centers.grad.cpu(), cr.grad) < 1e-5
+    with pytest.raises(RuntimeError):
+        losses.CenterLoss(4, 8)(torch.zeros(2, 8), torch.zeros(2, dtype=torch.long))          # CPU tensors: no fallback

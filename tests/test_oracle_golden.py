@@ -174,3 +174,18 @@ def test_f17_rerank_oracle_equals_reference():
     assert np.array_equal(g["dist"], g["final_a"])
     cmc, m_ap, _ = mr.eval_func(g["dist"], pids[:nq], pids[nq:], camids[:nq], camids[nq:], 50)
     assert np.array_equal(cmc, g["cmc"]) and m_ap == float(g["mAP"])
+
+
+def test_f18_center_loss(oracle):
+    """oracle.center_loss against the reference's CenterLoss (layers/center_loss.py:30-51): value and both gradients."""
+    g = load_golden("f18_center_loss")
+    seed = int(g["seed"])
+    b, c, d = (int(v) for v in g["shape"])
+    x = synth.normal(seed, "cl/x", (b, d), 1.0).requires_grad_(True)
+    cen = synth.normal(seed, "cl/c", (c, d), 1.0).requires_grad_(True)
+    lab = torch.from_numpy(g["label"])
+    loss = oracle.center_loss(x, cen, lab)
+    assert rel_err(loss.detach(), g["loss"]) < 1e-6
+    (3.0 * loss).backward()
+    assert rel_err(x.grad[:, :64], g["dx"]) < 1e-5 and abs(x.grad.norm().item() / float(g["dx_norm"]) - 1) < 1e-5
+    assert rel_err(cen.grad[lab.unique()][:, :64], g["dc"]) < 1e-5 and abs(cen.grad.norm().item() / float(g["dc_norm"]) - 1) < 1e-5

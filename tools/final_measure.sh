@@ -1,8 +1,9 @@
 #!/bin/bash
 # usage (GPU box, via gpurun): tools/final_measure.sh <round-tag>   -> gpurun_out/<tag>_*  (copy what is to be judged into profiles/)
-tag=${1:-r05}
+tag=${1:-r06}
 mkdir -p gpurun_out
 python bench.py 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_line_default.json
+EDITOR_DROP_SKIP=0 python bench.py --no-cpu-baseline --no-modes --no-eval 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_line_noskip.json
 python bench.py --dtype f16x2 --no-cpu-baseline --no-modes 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_line_f16x2.json
 python bench.py --dtype f16 --no-cpu-baseline --no-modes 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_line_f16.json
 python bench.py --dtype f16x2s --no-cpu-baseline --no-modes 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_line_f16x2s.json
@@ -36,6 +37,6 @@ TAG=${tag} bash tools/pmc_traffic.sh > gpurun_out/${tag}_pmc_traffic.log 2>&1
 GEMM_EPI=1 GEMM_SPLIT=1 python tools/gemm_bench.py > gpurun_out/${tag}_gemm_bench.txt 2>&1
 python tools/attn_bench.py > gpurun_out/${tag}_attn_bench.txt 2>&1
 head -c 700 gpurun_out/${tag}_bench_line_default.json; echo
-for f in f16x2 f16x2s f16 rgbnt100 msvr310 synth4l b16 b32 b64 spawn1 spawn1_wire16; do head -c 330 gpurun_out/${tag}_bench_line_$f.json; echo; done
+for f in noskip f16x2 f16x2s f16 rgbnt100 msvr310 synth4l b16 b32 b64 spawn1 spawn1_wire16; do head -c 330 gpurun_out/${tag}_bench_line_$f.json; echo; done
 tail -4 gpurun_out/${tag}_repro_check.txt
 tail -3 gpurun_out/${tag}_pmc_traffic.log
