@@ -100,11 +100,19 @@ def numbers_block():
                                                                                   for k, v in list(ng["top"].items())[:7])))
     s = serial_summary()
     if s:
-        out.append("| rocprofv3 `--kernel-trace --stats` of the bench command, weight gradients on the main stream (%d steps) | %.2f ms of kernels "
-                   "per step in %.0f launches; GEMM kernels %.2f ms (+ %.2f ms slab folds) -> %.0f TFLOP/s = %.3f (%.3f with the folds) | "
-                   "`profiles/%s_bench_kernel_stats_serial.csv` |"
-                   % (s["steps"], s["total"], s["launches"], s["gemm"], s["slab"], r["alg_tflop_per_step"] / s["gemm"] * 1e3,
+        out.append("| rocprofv3 `--kernel-trace --stats` of the bench command, weight gradients on the main stream (%d steps, one-time "
+                   "launches included) | %.2f ms of kernels per step; GEMM kernels %.2f ms (+ %.2f ms slab folds) -> %.0f TFLOP/s = %.3f "
+                   "(%.3f with the folds) | `profiles/%s_bench_kernel_stats_serial.csv` |"
+                   % (s["steps"], s["total"], s["gemm"], s["slab"], r["alg_tflop_per_step"] / s["gemm"] * 1e3,
                       r["alg_tflop_per_step"] / s["gemm"] * 1e3 / 2500.0, r["alg_tflop_per_step"] / (s["gemm"] + s["slab"]) * 1e3 / 2500.0, TAG))
+    lf = os.path.join(P, "%s_launches_per_step.txt" % TAG)
+    if os.path.exists(lf):
+        m = re.search(r"launches\s+([\d.]+)\s+kernel ms\s+([\d.]+)\s+16-bit GEMM family:\s+([\d.]+) launches,\s+([\d.]+) ms\s+everything else:\s+([\d.]+) launches,\s+([\d.]+) ms",
+                      open(lf).read())
+        if m:
+            out.append("| launches and kernel time per step, by difference of a 7-step and a 3-step eager profile | %s launches, %s ms of kernels = "
+                       "%s ms in %s GEMM-family launches + %s ms in %s others | `profiles/%s_launches_per_step.txt` |"
+                       % (m.group(1), m.group(2), m.group(4), m.group(3), m.group(6), m.group(5), TAG))
     for k in r.get("hbm_kernels", []):
         pass
     if r.get("hbm_kernels"):
@@ -144,7 +152,7 @@ def serial_block():
     out = ["| kernel | ms per step | launches per step | average us |", "|---|---|---|---|"]
     for n, ms, calls, us in s["top"]:
         out.append("| `%s` | %.3f | %.0f | %.1f |" % (n.replace("|", "/"), ms, calls, us))
-    out.append("| all kernels | %.2f | %.0f | |" % (s["total"], s["launches"]))
+    out.append("| all kernels (one-time launches of the %d profiled steps included) | %.2f | %.0f | |" % (s["steps"], s["total"], s["launches"]))
     return "\n".join(out) + "\n"
 
 
