@@ -441,7 +441,7 @@ __global__ void cast_rows_kernel(const float* __restrict__ in, const float* __re
     const int d4 = D >> 2;
     if (m_live) M = min(M, (long)((*m_live + 63) & ~63));
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < M * d4; e += (long)gridDim.x * blockDim.x) {
-        const float r = (rowscale ? rowscale[e / d4] : 1.f) * scale;
+        const float r = (rowscale ? rowscale[(uint32_t)e / (uint32_t)d4] : 1.f) * scale;      // (M * D / 4 < 2^32: host check; 32-bit division)
         float4 v = *reinterpret_cast<const float4*>(in + e * 4);
         v.x *= r; v.y *= r; v.z *= r; v.w *= r;
         Vec4<TO>::st(out + e * 4, v);
@@ -494,11 +494,13 @@ __global__ void im2col16_kernel(const float* __restrict__ img, int B, int C, int
     const long total4 = (long)B * py * px * C * 64;                 // float4 groups
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (long)gridDim.x * blockDim.x) {
         const int j4 = (int)(e & 3);
-        long r = e >> 2;
-        const int i = (int)(r & 15); r >>= 4;
-        const int c = (int)(r % C); r /= C;
-        const int p = (int)(r % (py * px));
-        const int b = (int)(r / (py * px));
+        // (32-bit index arithmetic: the 64-bit divisions this replaces were most of the kernel - round 6: 55 us per modality at B = 128
+        //  for 75 MB; the host checks that the (patch, channel, row) count fits)
+        uint32_t r = (uint32_t)(e >> 2);
+        const int i = (int)(r & 15u); r >>= 4;
+        const int c = (int)(r % (uint32_t)C); r /= (uint32_t)C;
+        const int p = (int)(r % (uint32_t)(py * px));
+        const int b = (int)(r / (uint32_t)(py * px));
         const int y = (p / px) * 16 + i, x0 = (p % px) * 16 + j4 * 4;
         const float4 v = *reinterpret_cast<const float4*>(img + (((long)b * C + c) * H + y) * W + x0);
         const long o = ((long)b * py * px + p) * (C * 256) + c * 256 + i * 16 + j4 * 4;
@@ -529,16 +531,18 @@ __global__ void embed_assemble_kernel(const T* __restrict__ patch, const float* 
     const int d4 = D >> 2;
     const long total = Btot * Tn * d4;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(e % d4) * 4;
-        const long rt = e / d4;
-        const int tk = (int)(rt % Tn);
-        const long b = rt / Tn;
+        // (32-bit index arithmetic - total < 2^32 is checked by the host; 64-bit divisions were most of these glue kernels)
+        const uint32_t e32 = (uint32_t)e;
+        const int c0 = (int)(e32 % (uint32_t)d4) * 4;
+        const long rt = e32 / (uint32_t)d4;
+        const int tk = (int)((uint32_t)rt % (uint32_t)Tn);
+        const long b = (uint32_t)rt / (uint32_t)Tn;
         float4 v = tk == 0 ? *reinterpret_cast<const float4*>(cls + c0)
                            : Vec4<T>::ld(patch + (b * (Tn - 1) + tk - 1) * D + c0);
         const float4 p = *reinterpret_cast<const float4*>(pos + (long)tk * D + c0);
         v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
         if (sie) {
-            const float4 s = *reinterpret_cast<const float4*>(sie + cam[b % Bcam] * D + c0);
+            const float4 s = *reinterpret_cast<const float4*>(sie + cam[(uint32_t)b % (uint32_t)Bcam] * D + c0);
             v.x += coef * s.x; v.y += coef * s.y; v.z += coef * s.z; v.w += coef * s.w;
         }
         *reinterpret_cast<float4*>(x + rt * D + c0) = v;
@@ -552,10 +556,11 @@ __global__ void embed_bwd_patch_kernel(const float* __restrict__ dx, long Btot, 
     const int d4 = D >> 2;
     const long total = Btot * (Tn - 1) * d4;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(e % d4) * 4;
-        const long rp = e / d4;
-        const long b = rp / (Tn - 1);
-        const int p = (int)(rp % (Tn - 1));
+        const uint32_t e32 = (uint32_t)e;
+        const int c0 = (int)(e32 % (uint32_t)d4) * 4;
+        const long rp = e32 / (uint32_t)d4;
+        const long b = (uint32_t)rp / (uint32_t)(Tn - 1);
+        const int p = (int)((uint32_t)rp % (uint32_t)(Tn - 1));
         float4 v = *reinterpret_cast<const float4*>(dx + (b * Tn + p + 1) * D + c0);
         v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
         Vec4<T>::st(dpatch + rp * D + c0, v);
@@ -1110,7 +1115,7 @@ extern "C" int editor_cast_bf16_to_f32(const uint16_t* in, float* out, long n, h
 extern "C" int editor_cast_rows(const float* in, const float* rowscale, long M, int D, void* out, int out_bf16,
                                 const int* m_live, float scale, hipStream_t stream)
 {
-    if (D % 4) return (int)hipErrorInvalidValue;
+    if (D % 4 || M * (D / 4) >= (1L << 32)) return (int)hipErrorInvalidValue;      // (32-bit element index in the kernel)
     DISPATCH_T(out_bf16, hipLaunchKernelGGL(cast_rows_kernel<TT>, dim3(grid_for(M * (D / 4))), dim3(256), 0, stream,
                in, rowscale, M, D, (TT*)out, m_live, scale));
     EDITOR_LAUNCH_CHECK();
@@ -1180,6 +1185,7 @@ extern "C" int editor_im2col16_f16x2(const float* img, int B, int C, int H, int 
 {
     if ((H & 15) || (W & 15) || !out_hi || !out_lo) return (int)hipErrorInvalidValue;
     const long total4 = (long)B * (H >> 4) * (W >> 4) * C * 64;
+    if (total4 >= (1L << 33)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(im2col16_kernel<f16_t>, dim3(grid_for(total4)), dim3(256), 0, stream, img, B, C, H, W, (f16_t*)out_hi,
                        (f16_t*)out_lo);
     EDITOR_LAUNCH_CHECK();
@@ -1198,6 +1204,7 @@ extern "C" int editor_im2col16(const float* img, int B, int C, int H, int W, voi
 {
     if ((H & 15) || (W & 15)) return (int)hipErrorInvalidValue;
     const long total4 = (long)B * (H >> 4) * (W >> 4) * C * 64;
+    if (total4 >= (1L << 33)) return (int)hipErrorInvalidValue;          // (the kernel's row index is 32-bit: total4 / 4 < 2^31)
     DISPATCH_T(out_bf16, hipLaunchKernelGGL(im2col16_kernel<TT>, dim3(grid_for(total4)), dim3(256), 0, stream, img, B, C, H, W, (TT*)out));
     EDITOR_LAUNCH_CHECK();
     return 0;
@@ -1208,6 +1215,7 @@ extern "C" int editor_embed_assemble(const void* patch, int patch_bf16, const fl
 {
     if (D % 4) return (int)hipErrorInvalidValue;
     const long total = Btot * T * (D / 4);
+    if (total >= (1L << 32)) return (int)hipErrorInvalidValue;                       // (32-bit element index in the kernel)
     DISPATCH_T(patch_bf16, hipLaunchKernelGGL(embed_assemble_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, stream,
                (const TT*)patch, cls, pos, sie, cam, Bcam, coef, Btot, T, D, x));
     EDITOR_LAUNCH_CHECK();
@@ -1220,6 +1228,7 @@ extern "C" int editor_embed_assemble_bwd(const float* dx, const long* cam, int B
 {
     if (D % 4) return (int)hipErrorInvalidValue;
     const long total = Btot * (T - 1) * (D / 4);
+    if (total >= (1L << 32)) return (int)hipErrorInvalidValue;                       // (32-bit element index in the kernel)
     DISPATCH_T(dpatch_bf16, hipLaunchKernelGGL(embed_bwd_patch_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, stream,
                dx, Btot, T, D, (TT*)dpatch, dpatch_scale));
     EDITOR_LAUNCH_CHECK();

@@ -195,8 +195,8 @@ __global__ void droppath_kernel(const float* __restrict__ rates, int L, long B, 
 {
     const long total = (long)L * 2 * B * T;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long s = e / T;                                 // (layer, branch, sample)
-        const int l = (int)(s / (2 * B));
+        const long s = (uint32_t)e / (uint32_t)T;             // (layer, branch, sample); total < 2^32: host check, 32-bit division
+        const int l = (int)((uint32_t)s / (uint32_t)(2 * B));
         const float keep_prob = 1.f - rates[l];
         const uint64_t r = mix64(seed * 0x100000001B3ull + (uint64_t)s);
         const float u = (float)(r >> 40) * (1.f / 16777216.f);
@@ -212,8 +212,8 @@ __global__ void droppath_dev_kernel(const float* __restrict__ rates, int L, long
     const uint64_t seed = (uint64_t)state[0];
     const long total = (long)L * 2 * B * T;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long s = e / T;
-        const int l = (int)(s / (2 * B));
+        const long s = (uint32_t)e / (uint32_t)T;
+        const int l = (int)((uint32_t)s / (uint32_t)(2 * B));
         const float keep_prob = 1.f - rates[l];
         const uint64_t r = mix64(seed * 0x100000001B3ull + (uint64_t)s);
         const float u = (float)(r >> 40) * (1.f / 16777216.f);
@@ -304,9 +304,10 @@ __global__ __launch_bounds__(256) void droppath_plan_kernel(const float* __restr
     int* pu = perm + u * B * T;
     int* iu = inv + u * B * T;
     // (every workgroup of a unit repeats the scan - a few hundred samples - and fills its share of the rows)
-    for (long e = (long)blockIdx.y * blockDim.x + threadIdx.x; e < B * T; e += (long)gridDim.y * blockDim.x) {
-        const long s = e / T;
-        const int tok = (int)(e - s * T);
+    const uint32_t rows = (uint32_t)(B * T);                   // (< 2^31: checked by the host; 32-bit division)
+    for (uint32_t e = blockIdx.y * blockDim.x + threadIdx.x; e < rows; e += gridDim.y * blockDim.x) {
+        const uint32_t s = e / (uint32_t)T;
+        const int tok = (int)(e - s * (uint32_t)T);
         const int c = slot[s] * T + tok;
         pu[e] = c;
         iu[c] = (int)e;
@@ -394,6 +395,7 @@ extern "C" int editor_transpose_multi(const uint16_t* const* src, uint16_t* cons
 extern "C" int editor_droppath_scales(const float* rates, int L, long B, int T, long seed, float* scales, hipStream_t stream)
 {
     const long total = (long)L * 2 * B * T;
+    if (total >= (1L << 32)) return (int)hipErrorInvalidValue;
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(droppath_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rates, L, B, T, (uint64_t)seed, scales);
@@ -413,6 +415,7 @@ extern "C" int editor_droppath_plan(const float* scales, int L, long B, int T, i
 extern "C" int editor_droppath_scales_dev(const float* rates, int L, long B, int T, long* state, float* scales, hipStream_t stream)
 {
     const long total = (long)L * 2 * B * T;
+    if (total >= (1L << 32)) return (int)hipErrorInvalidValue;
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(droppath_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rates, L, B, T, state, scales);

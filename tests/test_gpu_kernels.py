@@ -906,7 +906,7 @@ def test_k_tile_choreographies_agree_bit_for_bit(dtype):
             fn_.argtypes = lib.protos[name]
             fn_.restype = ctypes.c_int
             lib._fn[name] = fn_
-    m = 3 * 32 * 129
+    m = 3 * 64 * 129                                                  # 24 768 token rows (the grouped launch reduces over whole 64-row K-tiles)
     g = torch.Generator(device="cuda").manual_seed(5)
     x768 = torch.randn(m, 768, device="cuda", generator=g).to(dtype)
     x3072 = torch.randn(m, 3072, device="cuda", generator=g).to(dtype)
