@@ -66,10 +66,12 @@ def re_ranking(probFea, galFea, k1, k2, lambda_value, local_distmat=None, only_l
     operation by operation: every stage is bit-equal to numpy's FROM THE SAME INPUTS (tests/test_gpu_retrieval.py); end to end the
     result is tolerance-close, not bit-equal - expf differs from numpy's exp in the last place and near-tied distances can order
     differently.  Limits (checked here, documented divergences from the reference, which slices short neighbour lists silently and
-    takes any k1): k1 <= 63, N >= k1 + 1, N <= 65 535; local_distmat / only_local are not implemented - the evaluator's call
-    (utils/metrics.py:278: k1=50, k2=15, lambda=0.3, no local distances) is inside all of them."""
-    if local_distmat is not None or only_local:
-        raise NotImplementedError("re_ranking: local_distmat / only_local are not used by the path (utils/metrics.py:278)")
+    takes any k1): k1 <= 63, N >= k1 + 1, N <= 65 535 - the evaluator's call (utils/metrics.py:278: k1=50, k2=15, lambda=0.3) is inside
+    all of them.  local_distmat (N, N; numpy or tensor): added to the global distance matrix before the normalisation
+    (reranking.py:44-45) or, with only_local, used instead of it (:32-33) - one elementwise add on the device, the evaluator passes
+    neither."""
+    if only_local and local_distmat is None:
+        raise ValueError("re_ranking(only_local=True) needs local_distmat")
     qf, gf = _rows(probFea), _rows(galFea)
     if not qf.is_cuda:
         raise RuntimeError("re_ranking: features must be on the GPU (there is no CPU fallback)")
@@ -79,8 +81,19 @@ def re_ranking(probFea, galFea, k1, k2, lambda_value, local_distmat=None, only_l
     if int(k1) > 63 or int(k1) + 1 > n:
         raise ValueError("re_ranking: k1 <= 63 and k1 + 1 <= Q + G (the device kernel holds a neighbour list of k1 + 1 in LDS)")
     dev = qf.device
-    feat = torch.cat([qf, gf]).contiguous()
-    dist = euclidean_distance(feat, feat)
+    local = None
+    if local_distmat is not None:
+        local = torch.as_tensor(np.asarray(local_distmat) if not isinstance(local_distmat, torch.Tensor) else local_distmat)
+        local = local.to(device=dev, dtype=torch.float32).contiguous()
+        if tuple(local.shape) != (n, n):
+            raise ValueError("re_ranking: local_distmat must be (Q + G, Q + G)")
+    if only_local:
+        dist = local
+    else:
+        feat = torch.cat([qf, gf]).contiguous()
+        dist = euclidean_distance(feat, feat)
+        if local is not None:
+            dist = dist + local
     od = torch.empty(n, n, dtype=torch.float32, device=dev)
     call("editor_rerank_normalise", dist, n, torch.empty(n, dtype=torch.float32, device=dev), od)
     del dist

@@ -17,13 +17,19 @@ import numpy as np
 import torch
 
 
-def normalised_distance(qf, gf):
-    feat = torch.cat([qf, gf]).float()
-    n = feat.shape[0]
-    sq = feat.pow(2).sum(dim=1, keepdim=True)
-    dist = (sq.expand(n, n) + sq.expand(n, n).t()).clone()
-    dist.addmm_(feat, feat.t(), beta=1, alpha=-2)
-    dist = dist.numpy()
+def normalised_distance(qf, gf, local_distmat=None, only_local=False):
+    """reranking.py:32-47; local_distmat (N, N): added to the global distances (:44-45) or, only_local, used instead (:32-33)."""
+    if only_local:
+        dist = np.asarray(local_distmat)
+    else:
+        feat = torch.cat([qf, gf]).float()
+        n = feat.shape[0]
+        sq = feat.pow(2).sum(dim=1, keepdim=True)
+        dist = (sq.expand(n, n) + sq.expand(n, n).t()).clone()
+        dist.addmm_(feat, feat.t(), beta=1, alpha=-2)
+        dist = dist.numpy()
+        if local_distmat is not None:
+            dist = dist + np.asarray(local_distmat)
     return np.transpose(dist / np.max(dist, axis=0))          # od[i, j] = dist[j, i] / max_k dist[k, i]
 
 
@@ -73,9 +79,9 @@ def jaccard(v, nq):
     return out
 
 
-def re_ranking(qf, gf, k1, k2, lambda_value, stages=False):
+def re_ranking(qf, gf, k1, k2, lambda_value, stages=False, local_distmat=None, only_local=False):
     nq = qf.shape[0]
-    od = normalised_distance(qf, gf)
+    od = normalised_distance(qf, gf, local_distmat, only_local)
     rank = np.argsort(od).astype(np.int32)
     v = reciprocal_weights(od, rank, k1)
     vq = local_expansion(v, rank, k2)

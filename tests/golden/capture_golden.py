@@ -514,6 +514,11 @@ def f17_rerank(seed=171):
     out = {}
     for tag, (k1, k2) in (("a", (50, 15)), ("b", (20, 6)), ("c", (21, 1))):
         out["final_" + tag] = re_ranking(nrm[:nq], nrm[nq:], k1, k2, 0.3)
+    # reranking.py:30,32-33,44-45: an optional (N, N) matrix of local distances added to the global one / used instead of it
+    local = synth.uniform(seed, "rerank/local", (nq + ng, nq + ng)).numpy().astype(np.float32)
+    local = (local + local.T) * 0.5
+    out["final_local"] = re_ranking(nrm[:nq], nrm[nq:], 20, 6, 0.3, local_distmat=local)
+    out["final_only_local"] = re_ranking(nrm[:nq], nrm[nq:], 20, 6, 0.3, local_distmat=local + 0.25, only_local=True)
     ev = M.R1_mAP_eval(nq, max_rank=50, feat_norm=True, reranking=True)
     ev.reset()
     ev.update((feats, pids, camids))

@@ -103,6 +103,14 @@ def test_rerank_matches_reference_golden():
         final = metrics.re_ranking(nrm[:nq], nrm[nq:], k1, k2, 0.3)
         assert final.dtype == torch.float32 and tuple(final.shape) == (nq, 208)
         _rerank_check(final.cpu().numpy(), g["final_" + tag])
+    # local_distmat: added to the global distances / used instead of them (reranking.py:32-33,44-45)
+    local = synth.uniform(int(g["seed"]), "rerank/local", (nq + 208, nq + 208)).numpy().astype(np.float32)
+    local = (local + local.T) * 0.5
+    _rerank_check(metrics.re_ranking(nrm[:nq], nrm[nq:], 20, 6, 0.3, local_distmat=local).cpu().numpy(), g["final_local"], tol_frac=2e-3)
+    _rerank_check(metrics.re_ranking(nrm[:nq], nrm[nq:], 20, 6, 0.3, local_distmat=torch.from_numpy(local + 0.25), only_local=True)
+                  .cpu().numpy(), g["final_only_local"], tol_frac=2e-3)
+    with pytest.raises(ValueError):
+        metrics.re_ranking(nrm[:nq], nrm[nq:], 20, 6, 0.3, only_local=True)
     ev = metrics.R1_mAP_eval(nq, max_rank=50, feat_norm=True, reranking=True)
     ev.reset()
     for s in range(0, nq + 208, 37):

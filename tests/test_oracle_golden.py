@@ -171,6 +171,11 @@ def test_f17_rerank_oracle_equals_reference():
     for tag, (k1, k2) in (("a", (50, 15)), ("b", (20, 6)), ("c", (21, 1))):
         final = rr.re_ranking(nrm[:nq], nrm[nq:], k1, k2, 0.3)
         assert final.dtype == np.float32 and np.array_equal(final, g["final_" + tag]), tag
+    # local_distmat added to / used instead of the global distances (reranking.py:32-33,44-45)
+    local = synth.uniform(int(g["seed"]), "rerank/local", (nq + 208, nq + 208)).numpy().astype(np.float32)
+    local = (local + local.T) * 0.5
+    assert np.array_equal(rr.re_ranking(nrm[:nq], nrm[nq:], 20, 6, 0.3, local_distmat=local), g["final_local"])
+    assert np.array_equal(rr.re_ranking(nrm[:nq], nrm[nq:], 20, 6, 0.3, local_distmat=local + 0.25, only_local=True), g["final_only_local"])
     assert np.array_equal(g["dist"], g["final_a"])
     cmc, m_ap, _ = mr.eval_func(g["dist"], pids[:nq], pids[nq:], camids[:nq], camids[nq:], 50)
     assert np.array_equal(cmc, g["cmc"]) and m_ap == float(g["mAP"])
