@@ -87,16 +87,17 @@ def test_fc2_on_compacted_rows_scatters_the_same_bits(dtype):
     assert torch.equal(out[dead], x1[dead]) and torch.equal(dense[dead], x1[dead])
 
 
-def _step(skip, dtype, b=64, seed=17):
+def _step(skip, dtype, b=64, seed=17, preset="RGBNT100"):
     from editor_amd.modeling import make_model
     from editor_amd import losses
-    cfg, c, cams = config.preset("RGBNT100", compute_dtype=dtype, drop_path=0.3)   # a high rate: ~15 % of the MLP units dropped
+    cfg, c, cams = config.preset(preset, compute_dtype=dtype, drop_path=0.3)   # a high rate: ~15 % of the MLP units dropped
     cfg.MODEL.DROP_SKIP = skip
     m = make_model(cfg, c, cams)
     synth.fill_state_dict_(m.state_dict(), seed)
     m = m.cuda().train()
     buckets = m.enable_grad_buckets()
-    img, label, cam, view = synth.make_batch(seed + 1, b, 128, 256, cams, instances=16)
+    h, w = cfg.INPUT.SIZE_TRAIN
+    img, label, cam, view = synth.make_batch(seed + 1, b, h, w, cams, instances=16, keys=config.MODALITY_KEYS[:m.nmod])
     gimg = {k: v.cuda().requires_grad_(k == "RGB") for k, v in img.items()}
     m._drop_state = torch.full((1,), 4242, dtype=torch.int64, device="cuda")
 
@@ -112,11 +113,15 @@ def _step(skip, dtype, b=64, seed=17):
     return [o.detach().clone() for o in out], loss.detach().clone(), grads, m.last_drop_scales.clone(), m.last_aux["index"].clone()
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16", "f16x2", "f16x2s"])
-def test_training_step_with_skipping_equals_the_step_without(dtype):
+@pytest.mark.parametrize("dtype,preset,b", [("bf16", "RGBNT100", 64), ("f16", "RGBNT100", 64), ("f16x2", "RGBNT100", 64),
+                                            ("f16x2s", "RGBNT100", 64),
+                                            ("bf16", "MSVR310", 64),          # T = 193: 37 056 token rows, 13-key-tile attention
+                                            ("bf16", "SYNTH4L", 16)])         # 4-modal ViT-L: D = 1024, hidden 4096, T = 513, 24 blocks
+def test_training_step_with_skipping_equals_the_step_without(dtype, preset, b):
     assert fn.DROP_SKIP
-    out0, loss0, g0, sc0, idx0 = _step(False, dtype)
-    out1, loss1, g1, sc1, idx1 = _step(True, dtype)
+    out0, loss0, g0, sc0, idx0 = _step(False, dtype, b, preset=preset)
+    out1, loss1, g1, sc1, idx1 = _step(True, dtype, b, preset=preset)
+    torch.cuda.empty_cache()
     assert torch.equal(sc0, sc1) and bool((sc1[1:, 1] == 0).float().mean() > 0.05)
     assert torch.equal(idx0, idx1)
     for a, b_ in zip(out0, out1):
