@@ -19,6 +19,8 @@ LIB_PROBE = os.path.join(HERE, "libeditor_probe.so")
 LIB_TRACE = os.path.join(HERE, "libeditor_gemm_trace.so")
 LIB_ALT = os.path.join(HERE, "libeditor_gemm_alt.so")      # csrc/gemm_bf16.hip with the OTHER K-tile choreography (A/B runs, tools/gemm_bench.py)
 ALT_FLAGS = ["-DEDITOR_PP_PHASES=%s" % os.environ.get("EDITOR_ALT_PHASES", "4")]
+LIB_MI32 = os.path.join(HERE, "libeditor_gemm_mi32.so")    # ... with v_mfma_f32_32x32x16 in the full-tile forward / dgrad products (round 6 A/B)
+MI32_FLAGS = ["-DEDITOR_PP_MI32=1"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-munsafe-fp-atomics"]
@@ -52,7 +54,7 @@ def _link(lib, objs):
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
 
 
-def build(force=False, verbose=False, trace=False, alt=False):
+def build(force=False, verbose=False, trace=False, alt=False, mi32=False):
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     srcs = sorted(s for s in glob.glob(os.path.join(CSRC, "*.hip")) if os.path.basename(s) not in DEBUG_ONLY)
     objs = [s[:-4] + ".o" for s in srcs]
@@ -80,6 +82,9 @@ def build(force=False, verbose=False, trace=False, alt=False):
     alt_obj = os.path.join(CSRC, "gemm_bf16.alt.o")
     if alt and (force or _stale(alt_obj, [gemm_src] + hdrs)):
         jobs.append((gemm_src, alt_obj, ALT_FLAGS))
+    mi32_obj = os.path.join(CSRC, "gemm_bf16.mi32.o")
+    if mi32 and (force or _stale(mi32_obj, [gemm_src] + hdrs)):
+        jobs.append((gemm_src, mi32_obj, MI32_FLAGS))
     _compile(jobs, verbose)
     if force or _stale(LIB, objs):
         _link(LIB, objs)
@@ -89,8 +94,10 @@ def build(force=False, verbose=False, trace=False, alt=False):
         _link(LIB_TRACE, [trace_obj])
     if alt and (force or _stale(LIB_ALT, [alt_obj])):
         _link(LIB_ALT, [alt_obj])
+    if mi32 and (force or _stale(LIB_MI32, [mi32_obj])):
+        _link(LIB_MI32, [mi32_obj])
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, trace="--trace" in sys.argv, alt="--alt" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, trace="--trace" in sys.argv, alt="--alt" in sys.argv, mi32="--mi32" in sys.argv))

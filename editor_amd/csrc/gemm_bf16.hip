@@ -46,11 +46,26 @@ __device__ __forceinline__ float4_t mfma16(short8_t a, short8_t b, float4_t c)
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// 32x32x16 form (EDITOR_PP_MI32, round 6): the same FLOPs per matrix-core cycle in half the MFMA issues; operand lane l holds row
+// l & 31, k-slice (l >> 5) * 8 .. + 7; D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+template <bool F16>
+__device__ __forceinline__ f32x16_t mfma32(short8_t a, short8_t b, f32x16_t c)
+{
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;          // 16 KiB per operand tile per stage
 
 #ifndef EDITOR_GEMM_GM
 #define EDITOR_GEMM_GM 4
+#endif
+#ifndef EDITOR_PP_MI32
+#define EDITOR_PP_MI32 0        // 1: full-tile forward / dgrad products with 16-bit staged epilogues run on v_mfma_f32_32x32x16 (A/B: tools/gemm_alt_ab.py)
 #endif
 #ifndef EDITOR_PP_PHASES
 #define EDITOR_PP_PHASES 0      // phases per K-tile of the ping-pong kernel: 4 (16-MFMA clusters), 2 (32-MFMA clusters, round 5), 0 = per
@@ -150,11 +165,21 @@ __device__ __forceinline__ v2f_t phi2(v2f_t a)
 }
 __device__ __forceinline__ v2f_t gelu2(v2f_t a) { return a * phi2(a); }
 // d/da gelu = Phi(a) + a phi(a), phi(a) = exp(-a^2/2)/sqrt(2 pi)
-__device__ __forceinline__ v2f_t gelu_grad2(v2f_t a)
+__device__ __forceinline__ v2f_t gelu_grad2_phi(v2f_t a, v2f_t ph)             // ph = phi2(a)
 {
     const v2f_t q = a * a * -0.72134752044448170f;                           // -a^2/2 * log2(e)
     v2f_t e; e.x = __builtin_amdgcn_exp2f(q.x); e.y = __builtin_amdgcn_exp2f(q.y);
-    return __builtin_elementwise_fma(a * 0.3989422804014327f, e, phi2(a));
+    return __builtin_elementwise_fma(a * 0.3989422804014327f, e, ph);
+}
+__device__ __forceinline__ v2f_t gelu_grad2(v2f_t a) { return gelu_grad2_phi(a, phi2(a)); }
+// Both at once, Phi evaluated ONCE (round 6: the f16 fc1 epilogue - no table there - called gelu2 and gelu_grad2 in different basic
+// blocks, so the compiler kept two copies of the erfc polynomial + reciprocal per element).  The same operations in the same order
+// as the two functions above: bit-identical results.
+__device__ __forceinline__ void gelu_both2(v2f_t a, bool want_grad, v2f_t& gv, v2f_t& dv)
+{
+    const v2f_t ph = phi2(a);
+    if (want_grad) dv = gelu_grad2_phi(a, ph);
+    gv = a * ph;
 }
 // GELU lookup for bf16 pre-activations (fc1's forward epilogue, ping-pong kernel).  The epilogue evaluates gelu and gelu' on
 // values that have ALREADY been rounded to bf16 - 16 bits of input - and was VALU-bound on it (~33 instructions + 4
@@ -497,18 +522,17 @@ __device__ __forceinline__ void epilogue_copy_out(const GemmB16Args& g, const ch
                 uint4 p;
                 p.x = H16<F16>::pack2(x[0], x[1]); p.y = H16<F16>::pack2(x[2], x[3]); p.z = H16<F16>::pack2(x[4], x[5]); p.w = H16<F16>::pack2(x[6], x[7]);
                 const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
-                if (g.aux_grad) {                                // save gelu'(rounded pre-activation) for the backward instead
-                    uint32_t dw_[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { const v2f_t dv = gelu_grad2(H16<F16>::unpack2(pw[e])); dw_[e] = H16<F16>::pack2(dv.x, dv.y); }
-                    p = make_uint4(dw_[0], dw_[1], dw_[2], dw_[3]);
-                }
-                if (g.aux) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = p;
+                const bool want_grad = g.aux_grad && g.aux;      // save gelu'(rounded pre-activation) for the backward instead
+                uint32_t dw_[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const v2f_t gv = gelu2(H16<F16>::unpack2(pw[e]));
+                    v2f_t gv, dv = v2f_t{0.f, 0.f};
+                    gelu_both2(H16<F16>::unpack2(pw[e]), want_grad, gv, dv);
+                    dw_[e] = H16<F16>::pack2(dv.x, dv.y);
                     x[2 * e] = gv.x; x[2 * e + 1] = gv.y;
                 }
+                if (want_grad) p = make_uint4(dw_[0], dw_[1], dw_[2], dw_[3]);
+                if (g.aux) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.aux) + (long)m * g.ldaux + n) = p;
             } else if (EPI == EDITOR_EPI_GELU_BWD) {
                 const uint4 p = pa[it];
                 const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
@@ -848,7 +872,7 @@ __device__ __forceinline__ short8_t lds_rdtr(uint32_t addr)
 // Per-lane BYTE offsets (32-bit) of the two 1 KiB pieces this wave stages of a unit, relative to the operand's
 // k0 = 0 position.  SPAN = 64 (A: rows per wave-row half) or 32 (B); image index rho in [0,128) -> tile-local index
 // (rho / SPAN) * 2*SPAN + sub*SPAN + rho % SPAN.  The K-tile position is a wave-uniform offset added at issue time.
-template <bool KMAJOR, int SPAN>
+template <bool KMAJOR, int SPAN, bool SWZ32 = false>
 __device__ __forceinline__ void pp_unit_offsets(long ld, int r0, int R, int sub, int wu, int lane, uint32_t (&vo)[2], int g1base = 128)
 {
 #pragma unroll
@@ -858,7 +882,7 @@ __device__ __forceinline__ void pp_unit_offsets(long ld, int r0, int R, int sub,
             const int rho = piece * 8 + (lane >> 3);
             int loc = (rho / SPAN) * (2 * SPAN) + sub * SPAN + (rho % SPAN);
             if (loc >= 128) loc += g1base - 128;                // (A only: short tiles, see the kernel's F0 / F1)
-            const int c = (lane & 7) ^ (rho & 7);
+            const int c = (lane & 7) ^ (SWZ32 ? (rho >> 1) & 7 : rho & 7);   // (SWZ32: 32-row fragments, see pp_body's MI32)
             vo[j] = (uint32_t)(((long)min(r0 + loc, R - 1) * ld + c * 8) * 2);
         } else {
             const int kr = piece * 4 + (lane >> 4);
@@ -882,9 +906,18 @@ __device__ __forceinline__ void pp_unit_offsets(long ld, int r0, int R, int sub,
 // SPLIT (editor_gemm_f16x2, forward products of the 'f16x2' mode): operands are pairs x = hi + lo of half matrices; the
 // K loop runs three segments over the SAME tile pipeline - lo.hi, hi.lo, then hi.hi (small terms first) - by switching the
 // LDS-DMA source per K-tile; the accumulator, the phases and the barriers are unchanged.  Dropped: lo.lo (2^-22 relative).
-template <bool F16, bool A_KMAJOR, bool B_KMAJOR, bool C_F32, int F0 = 8, int F1 = 8, bool SPLIT = false>
+// MI32 (round 6, EDITOR_PP_MI32): the SAME tile pipeline - units, phases, barriers, LDS-DMA pieces, 24 ds_read_b128 per K-tile - on
+// v_mfma_f32_32x32x16: a phase's 64 x 32 quadrant is 2 tiles x 4 k-steps = 8 MFMAs of 32 matrix-core cycles instead of 16 of 16.
+// A fragment is 32 rows x 16 k (lane: row l & 31, 16-byte chunk 2 ks + (l >> 5)); ds_read_b128 serves lanes {0-3, 12-15, 20-27} together,
+// i.e. 16 rows of one chunk column whose numbers repeat mod 8 - so the image's XOR swizzle is over (row >> 1) & 7 instead of row & 7
+// (both halves of the bank space, eight distinct chunk positions each: conflict-free; the LDS-DMA source permutation follows).
+// Only launched with both operands k-major, a 16-bit output and the one-pass staged epilogue (launch_pp checks): a lane holds 4 rows
+// x 32 columns in groups of four consecutive columns, the same 8-byte staging writes at other coordinates.  Sums 16 k per MFMA
+// instead of 32: same value up to fp32 rounding, not bit-identical to the 16x16x32 form.
+template <bool F16, bool A_KMAJOR, bool B_KMAJOR, bool C_F32, int F0 = 8, int F1 = 8, bool SPLIT = false, bool MI32 = false>
 __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, const int by)
 {
+    static_assert(!MI32 || (A_KMAJOR && B_KMAJOR && !C_F32 && !SPLIT && F0 == 8 && F1 == 8), "32x32x16: full tiles, k-major operands, 16-bit output");
     static_assert(!SPLIT || (F16 && A_KMAJOR && B_KMAJOR), "split precision: half operands, forward layout");
     static_assert(F0 >= 5 && F0 <= 8 && F1 >= 5 && F1 <= F0, "live fragments per wave group");
     static_assert((F0 == 8 && F1 == 8) || A_KMAJOR, "short tiles: k-major A only");
@@ -955,10 +988,27 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    f32x16_t acc32[4][2];                                       // MI32: [32-row tile of the wave's 128 rows][32-column tile of its 64]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+    const int l31 = lane & 31, lh = lane >> 5;
 
     // per-lane fragment addresses inside a unit (buffer 0); [s] for k-major images, [i] / [j] for row-k images
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    uint32_t adA[4], adB[2];
+    uint32_t adA[4], adB[4];
+    if constexpr (MI32) {                                       // [ks]: k-step of 16 inside the K-tile
+        const int ra = wr * 64 + l31, rb = wc * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            adA[ks] = smem_base + ra * 128 + (((ks * 2 + lh) ^ ((ra >> 1) & 7)) << 4);
+            adB[ks] = smem_base + rb * 128 + (((ks * 2 + lh) ^ ((rb >> 1) & 7)) << 4);
+        }
+    } else {
+    adB[2] = adB[3] = 0;
     if (A_KMAJOR) {
         const int row = wr * 64 + li;
 #pragma unroll
@@ -978,12 +1028,13 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
 #pragma unroll
         for (int j = 0; j < 2; ++j) adB[j] = smem_base + k0 * 256 + (((wc * 2 + j) ^ swz_rowk(k0)) << 5) + ((li & 3) << 3);
     }
+    }
     // LDS-DMA source offsets of this wave's two pieces of each unit (A0, A1, B0, B1)
     uint32_t voA[2][2], voB[2][2];
-    pp_unit_offsets<A_KMAJOR, 64>(g.lda, m0, g.M, 0, wu, lane, voA[0], F0 * 16);
-    pp_unit_offsets<A_KMAJOR, 64>(g.lda, m0, g.M, 1, wu, lane, voA[1], F0 * 16);
-    pp_unit_offsets<B_KMAJOR, 32>(g.ldb, n0, g.N, 0, wu, lane, voB[0]);
-    pp_unit_offsets<B_KMAJOR, 32>(g.ldb, n0, g.N, 1, wu, lane, voB[1]);
+    pp_unit_offsets<A_KMAJOR, 64, MI32>(g.lda, m0, g.M, 0, wu, lane, voA[0], F0 * 16);
+    pp_unit_offsets<A_KMAJOR, 64, MI32>(g.lda, m0, g.M, 1, wu, lane, voA[1], F0 * 16);
+    pp_unit_offsets<B_KMAJOR, 32, MI32>(g.ldb, n0, g.N, 0, wu, lane, voB[0]);
+    pp_unit_offsets<B_KMAJOR, 32, MI32>(g.ldb, n0, g.N, 1, wu, lane, voB[1]);
     const long kstepA = A_KMAJOR ? (long)BK * 2 : (long)BK * g.lda * 2;       // bytes per K-tile
     const long kstepB = B_KMAJOR ? (long)BK * 2 : (long)BK * g.ldb * 2;
     const char* baseA = reinterpret_cast<const char*>(g.A) + kt0 * kstepA;
@@ -993,6 +1044,14 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
     // (DS immediate offsets are 16 bits: the second K-tile buffer, 64 KiB up, goes through the address register)
     auto read_a = [&](auto U, auto BUF, auto LIVE) {           // LIVE: fragments of the unit this wave group uses
         constexpr int base = decltype(U)::value, bo = decltype(BUF)::value * KTB;
+        if constexpr (MI32) {                                  // 32-row fragment I2, k-step KS -> fa[I2 * 2 + KS / 2][KS % 2]
+            static_for<0, decltype(LIVE)::value / 2>([&](auto i) {
+                static_for<0, 4>([&](auto s) {
+                    constexpr int I2 = decltype(i)::value, KS = decltype(s)::value;
+                    fa[I2 * 2 + (KS >> 1)][KS & 1] = lds_rd128<base + I2 * 4096>(adA[KS] + bo);
+                });
+            });
+        } else
         static_for<0, decltype(LIVE)::value>([&](auto i) {
             static_for<0, 2>([&](auto s) {
                 constexpr int I = decltype(i)::value, S = decltype(s)::value;
@@ -1003,6 +1062,12 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
     };
     auto read_b = [&](short8_t (&fbv)[2][2], auto U, auto BUF) {
         constexpr int base = decltype(U)::value, bo = decltype(BUF)::value * KTB;
+        if constexpr (MI32) {                                  // the unit's 32 columns are ONE fragment per k-step: fbv[KS / 2][KS % 2]
+            static_for<0, 4>([&](auto s) {
+                constexpr int KS = decltype(s)::value;
+                fbv[KS >> 1][KS & 1] = lds_rd128<base>(adB[KS] + bo);
+            });
+        } else
         static_for<0, 2>([&](auto j) {
             static_for<0, 2>([&](auto s) {
                 constexpr int J = decltype(j)::value, S = decltype(s)::value;
@@ -1013,6 +1078,13 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
     };
     auto mma_q = [&](short8_t (&fbv)[2][2], auto MI, auto NJ, auto LIVE) {
         constexpr int mi = decltype(MI)::value, nj = decltype(NJ)::value;
+        if constexpr (MI32) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2)
+                    acc32[mi * 2 + i2][nj] = mfma32<F16>(fbv[ks >> 1][ks & 1], fa[i2 * 2 + (ks >> 1)][ks & 1], acc32[mi * 2 + i2][nj]);
+        } else
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -1187,25 +1259,34 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
 #define PP_EBAR() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PP_BAR(); } while (0)
     const bool staged = g.pp_staged && g.beta == 0.f && (g.splitk == 1 || g.slabs) && (g.N & 7) == 0 && (g.ldc & 7) == 0 &&
                         (g.ldaux & 7) == 0;
-    if (!SPLIT && staged && !C_F32 && (g.epilogue == EDITOR_EPI_NONE || g.epilogue == EDITOR_EPI_GELU || g.epilogue == EDITOR_EPI_GELU_BWD)) {
+    if (MI32 || (!SPLIT && staged && !C_F32 && (g.epilogue == EDITOR_EPI_NONE || g.epilogue == EDITOR_EPI_GELU || g.epilogue == EDITOR_EPI_GELU_BWD))) {
         // bf16 outputs whose epilogue is per-element: scale / bias / row scale in registers, ONE pass of the whole
         // 256x256 tile through LDS as bf16 (rows padded to 528 B), then 16-byte row-contiguous stores.  GELU: the
         // staged value is the (rounded) pre-activation, which is an output anyway; the activation is computed from it
         // on the way out, as the unfused form would.
         constexpr int RB = 256 * 2 + 16;
+        // a lane's accumulators as NI row slots x NJ groups of four consecutive columns: 8 x 4 (16x16 tiles: row li of fragment i, columns
+        // lg * 4 of fragment j) or 4 x 8 (MI32: row l31 of 32-row tile i, columns (j & 3) * 8 + lh * 4 of 32-column tile j >> 2)
+        constexpr int NI = MI32 ? 4 : 8, NJ = MI32 ? 8 : 4;
+        auto e_row = [&](int i) { return MI32 ? gb + i * 32 + l31 : gb + i * 16 + li; };
+        auto e_col = [&](int j) { return MI32 ? wc * 64 + (j >> 2) * 32 + (j & 3) * 8 + lh * 4 : wc * 64 + j * 16 + lg * 4; };
+        auto e_acc = [&](int i, int j, int e) -> float {
+            if constexpr (MI32) return acc32[i][j >> 2][(j & 3) * 4 + e]; else return acc[i][j][e];
+        };
+        auto e_live = [&](int i) { return MI32 || i < fg; };
         PP_EBAR();
         const bool add_bias = g.bias && by == 0;
-        float4 bv[4];                                          // this lane's four column groups: loaded once, not per row
-        float rsv[8];
+        float4 bv[NJ];                                         // this lane's column groups: loaded once, not per row
+        float rsv[NI];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nl = wc * 64 + j * 16 + lg * 4;
+        for (int j = 0; j < NJ; ++j) {
+            const int nl = e_col(j);
             bv[j] = (add_bias && n0 + nl < g.N) ? *reinterpret_cast<const float4*>(g.bias + n0 + nl) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int ml = gb + i * 16 + li;                     // tile row (= row of the staged image)
-            rsv[i] = (g.rowscale && i < fg && m0 + ml < g.M) ? g.rowscale[m0 + ml] : 1.f;
+        for (int i = 0; i < NI; ++i) {
+            const int ml = e_row(i);                             // tile row (= row of the staged image)
+            rsv[i] = (g.rowscale && e_live(i) && m0 + ml < g.M) ? g.rowscale[m0 + ml] : 1.f;
         }
         if (g.epilogue == EDITOR_EPI_GELU_BWD) {
             // C = value * gelu'(saved pre-activation): the operand is fetched in the ACCUMULATOR layout (8 bytes per lane
@@ -1214,45 +1295,45 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
             // epilogue (the two-pass fp32 staging + per-item operand loads took 38 k cycles per tile against 30 k for the
             // K = 768 main loop).
             const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.aux);
-            uint2 pre[8][4];
+            uint2 pre[NI][NJ];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (i >= fg) continue;
-                const int m = min(m0 + gb + i * 16 + li, g.M - 1);
+            for (int i = 0; i < NI; ++i) {
+                if (!e_live(i)) continue;
+                const int m = min(m0 + e_row(i), g.M - 1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = min(n0 + wc * 64 + j * 16 + lg * 4, g.N - 4);
+                for (int j = 0; j < NJ; ++j) {
+                    const int n = min(n0 + e_col(j), g.N - 4);
                     pre[i][j] = *reinterpret_cast<const uint2*>(Ab + (long)m * g.ldaux + n);
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (i >= fg) continue;
-                const int ml = gb + i * 16 + li;
+            for (int i = 0; i < NI; ++i) {
+                if (!e_live(i)) continue;
+                const int ml = e_row(i);
                 const float rs = rsv[i];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int nl = wc * 64 + j * 16 + lg * 4;
+                for (int j = 0; j < NJ; ++j) {
+                    const int nl = e_col(j);
                     const v2f_t u0 = H16<F16>::unpack2(pre[i][j].x), u1 = H16<F16>::unpack2(pre[i][j].y);
                     const v2f_t g0 = g.aux_grad ? u0 : gelu_grad2(u0), g1 = g.aux_grad ? u1 : gelu_grad2(u1);
                     uint2 o;
-                    o.x = H16<F16>::pack2((acc[i][j][0] * g.alpha + bv[j].x) * rs * g0.x, (acc[i][j][1] * g.alpha + bv[j].y) * rs * g0.y);
-                    o.y = H16<F16>::pack2((acc[i][j][2] * g.alpha + bv[j].z) * rs * g1.x, (acc[i][j][3] * g.alpha + bv[j].w) * rs * g1.y);
+                    o.x = H16<F16>::pack2((e_acc(i, j, 0) * g.alpha + bv[j].x) * rs * g0.x, (e_acc(i, j, 1) * g.alpha + bv[j].y) * rs * g0.y);
+                    o.y = H16<F16>::pack2((e_acc(i, j, 2) * g.alpha + bv[j].z) * rs * g1.x, (e_acc(i, j, 3) * g.alpha + bv[j].w) * rs * g1.y);
                     *reinterpret_cast<uint2*>(smem + ml * RB + nl * 2) = o;
                 }
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (i >= fg) continue;
-                const int ml = gb + i * 16 + li;
+            for (int i = 0; i < NI; ++i) {
+                if (!e_live(i)) continue;
+                const int ml = e_row(i);
                 const float rs = rsv[i];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int nl = wc * 64 + j * 16 + lg * 4;
+                for (int j = 0; j < NJ; ++j) {
+                    const int nl = e_col(j);
                     uint2 o;
-                    o.x = H16<F16>::pack2((acc[i][j][0] * g.alpha + bv[j].x) * rs, (acc[i][j][1] * g.alpha + bv[j].y) * rs);
-                    o.y = H16<F16>::pack2((acc[i][j][2] * g.alpha + bv[j].z) * rs, (acc[i][j][3] * g.alpha + bv[j].w) * rs);
+                    o.x = H16<F16>::pack2((e_acc(i, j, 0) * g.alpha + bv[j].x) * rs, (e_acc(i, j, 1) * g.alpha + bv[j].y) * rs);
+                    o.y = H16<F16>::pack2((e_acc(i, j, 2) * g.alpha + bv[j].z) * rs, (e_acc(i, j, 3) * g.alpha + bv[j].w) * rs);
                     *reinterpret_cast<uint2*>(smem + ml * RB + nl * 2) = o;
                 }
             }
@@ -1306,19 +1387,18 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
                 }
             }
             if (gelu && !looked_up) {
-                uint32_t pw[4] = {p.x, p.y, p.z, p.w};
-                if (!Ab) {               // (no-grad forward: nothing is saved)
-                } else if (g.aux_grad) { // the backward only needs gelu'(pre-activation): save THAT (one multiply there instead of
-                    uint32_t dw_[4];     // an erfc + exponential per element in the dgrad epilogue)
+                // the backward only needs gelu'(pre-activation): save THAT (one multiply there instead of an erfc + exponential per
+                // element in the dgrad epilogue); a no-grad forward (Ab NULL) saves nothing.  Phi is evaluated once for both outputs.
+                uint32_t pw[4] = {p.x, p.y, p.z, p.w}, dw_[4];
+                const bool want_grad = Ab && g.aux_grad;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { const v2f_t dv = gelu_grad2(H16<F16>::unpack2(pw[e])); dw_[e] = H16<F16>::pack2(dv.x, dv.y); }
-                    *reinterpret_cast<uint4*>(Ab + (long)m * g.ldaux + n) = make_uint4(dw_[0], dw_[1], dw_[2], dw_[3]);
-                } else {
-                    *reinterpret_cast<uint4*>(Ab + (long)m * g.ldaux + n) = p;
+                for (int e = 0; e < 4; ++e) {
+                    v2f_t gv, dv = v2f_t{0.f, 0.f};
+                    gelu_both2(H16<F16>::unpack2(pw[e]), want_grad, gv, dv);
+                    dw_[e] = H16<F16>::pack2(dv.x, dv.y);
+                    pw[e] = H16<F16>::pack2(gv.x, gv.y);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                { const v2f_t gv = gelu2(H16<F16>::unpack2(pw[e])); pw[e] = H16<F16>::pack2(gv.x, gv.y); }
+                if (Ab) *reinterpret_cast<uint4*>(Ab + (long)m * g.ldaux + n) = want_grad ? make_uint4(dw_[0], dw_[1], dw_[2], dw_[3]) : p;
                 p = make_uint4(pw[0], pw[1], pw[2], pw[3]);
             }
             if (g.colsum) {
@@ -1384,10 +1464,10 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
 #undef PP_BAR
 }
 
-template <bool F16, bool A_KMAJOR, bool B_KMAJOR, bool C_F32, int F0 = 8, int F1 = 8, bool SPLIT = false>
+template <bool F16, bool A_KMAJOR, bool B_KMAJOR, bool C_F32, int F0 = 8, int F1 = 8, bool SPLIT = false, bool MI32 = false>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmB16Args g)
 {
-    pp_body<F16, A_KMAJOR, B_KMAJOR, C_F32, F0, F1, SPLIT>(g, blockIdx.x, blockIdx.y);
+    pp_body<F16, A_KMAJOR, B_KMAJOR, C_F32, F0, F1, SPLIT, MI32>(g, blockIdx.x, blockIdx.y);
 }
 
 // GROUPED weight gradients: the four dW = dy^T x products of one transformer block (qkv, proj, fc1, fc2: 27 + 9 + 36 + 36 =
@@ -1639,12 +1719,12 @@ int launch_pipe_t(GemmB16Args g, hipStream_t stream)
     return 0;
 }
 
-template <bool F16, bool AK, bool BK_, bool CF, int F0, int F1, bool SPLIT = false>
+template <bool F16, bool AK, bool BK_, bool CF, int F0, int F1, bool SPLIT = false, bool MI32 = false>
 int launch_pp_t(GemmB16Args g, hipStream_t stream)
 {
     constexpr int LDS = 256 * (256 * 2 + 16) + (int)kLutBytes;  // >= 2 K-tile buffers, the fp32 half-tile image, the bf16 tile image + GELU table
-    auto kern = gemm_bf16_pp_kernel<F16, AK, BK_, CF, F0, F1, SPLIT>;
-    if (int e = ensure_lds<gemm_bf16_pp_kernel<F16, AK, BK_, CF, F0, F1, SPLIT>>(LDS)) return e;
+    auto kern = gemm_bf16_pp_kernel<F16, AK, BK_, CF, F0, F1, SPLIT, MI32>;
+    if (int e = ensure_lds<gemm_bf16_pp_kernel<F16, AK, BK_, CF, F0, F1, SPLIT, MI32>>(LDS)) return e;
     g.tiles_m = (g.M + (F0 + F1) * 16 - 1) / ((F0 + F1) * 16);
     g.tiles_n = (g.N + 255) / 256;
     // measured: the LDS-staged epilogue (full-line 16-byte stores) beats the direct one on every layout here
@@ -1696,6 +1776,14 @@ int launch_pp(const GemmB16Args& g, hipStream_t stream)
     if constexpr (AK && BK_) {
         // short tiles (EDITOR_EPI_TILE_ROWS, see the kernel): both operands k-major and a staged epilogue (checked by the caller)
         if (g.tile_frags == 13) return launch_pp_t<F16, AK, BK_, CF, 7, 6>(g, stream);
+#if EDITOR_PP_MI32
+        // full tiles, 16-bit output through the one-pass staged epilogue (the conditions pp_body's `staged` path tests): 32x32x16 MFMAs
+        if constexpr (!CF) {
+            if (g.beta == 0.f && g.splitk == 1 && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (g.ldaux & 7) == 0 &&
+                (g.epilogue == EDITOR_EPI_NONE || g.epilogue == EDITOR_EPI_GELU || g.epilogue == EDITOR_EPI_GELU_BWD))
+                return launch_pp_t<F16, AK, BK_, CF, 8, 8, false, true>(g, stream);
+        }
+#endif
     }
     return launch_pp_t<F16, AK, BK_, CF, 8, 8>(g, stream);
 }

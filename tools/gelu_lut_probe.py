@@ -12,6 +12,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from editor_amd import ops  # noqa: E402
 
 kind = sys.argv[1]
+if os.environ.get("GEMM_ALT_LIB"):          # tools/pmc_mi32.sh: the same launches out of another build of gemm_bf16.hip
+    import ctypes
+    from editor_amd import _lib
+    _l = _lib.lib()
+    _alt = ctypes.CDLL(os.environ["GEMM_ALT_LIB"])
+    for _n in ("editor_gemm_bf16", "editor_gemm_f16"):
+        _f = getattr(_alt, _n)
+        _f.argtypes = _l.protos[_n]
+        _f.restype = ctypes.c_int
+        _l._fn[_n] = _f
 dt = torch.float16 if kind == "gelu_f16" else torch.bfloat16
 m, n, k = 3 * 128 * 129, 3072, 768
 g = torch.Generator(device="cuda").manual_seed(0)
