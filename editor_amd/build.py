@@ -21,6 +21,7 @@ LIB_ALT = os.path.join(HERE, "libeditor_gemm_alt.so")      # csrc/gemm_bf16.hip 
 ALT_FLAGS = ["-DEDITOR_PP_PHASES=%s" % os.environ.get("EDITOR_ALT_PHASES", "4")]
 LIB_MI32 = os.path.join(HERE, "libeditor_gemm_mi32.so")    # ... with v_mfma_f32_32x32x16 in the full-tile forward / dgrad products (round 6 A/B)
 MI32_FLAGS = ["-DEDITOR_PP_MI32=1"]
+LIB_MI32P2 = os.path.join(HERE, "libeditor_gemm_mi32p2.so")  # ... and the two-phase K-tile (16-MFMA clusters over four accumulators)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-munsafe-fp-atomics"]
@@ -85,6 +86,9 @@ def build(force=False, verbose=False, trace=False, alt=False, mi32=False):
     mi32_obj = os.path.join(CSRC, "gemm_bf16.mi32.o")
     if mi32 and (force or _stale(mi32_obj, [gemm_src] + hdrs)):
         jobs.append((gemm_src, mi32_obj, MI32_FLAGS))
+    mi32p2_obj = os.path.join(CSRC, "gemm_bf16.mi32p2.o")
+    if mi32 and (force or _stale(mi32p2_obj, [gemm_src] + hdrs)):
+        jobs.append((gemm_src, mi32p2_obj, MI32_FLAGS + ["-DEDITOR_PP_MI32_PHASES=2"]))
     _compile(jobs, verbose)
     if force or _stale(LIB, objs):
         _link(LIB, objs)
@@ -96,6 +100,8 @@ def build(force=False, verbose=False, trace=False, alt=False, mi32=False):
         _link(LIB_ALT, [alt_obj])
     if mi32 and (force or _stale(LIB_MI32, [mi32_obj])):
         _link(LIB_MI32, [mi32_obj])
+    if mi32 and (force or _stale(LIB_MI32P2, [mi32p2_obj])):
+        _link(LIB_MI32P2, [mi32p2_obj])
     return LIB
 
 

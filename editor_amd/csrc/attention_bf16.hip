@@ -211,6 +211,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
         }
     };
     const float sc = a.scale * kLog2e;
+    // 16 n + 1 tokens (every ViT sequence: patches + the class token): the LAST key tile of the even-sized image lies entirely beyond
+    // the sequence end - its scores are masked to -inf, its probabilities are exact zeros.  The dense (FULL) forms skip that half of
+    // their last pair of key tiles: two to four MFMAs, four exponentials and their selects per own tile, same bits (round 6).
+    const bool odd = FULL && !MASKED && NT <= 14 && T <= 16 * (NT - 1);   // (NT <= 14: the backbone sequences; the longer forms spill with the extra copy of the pair)
     const long row_idx0 = (long)hh * a.Mtot + row0;                // lse / delta index of row 0
     const long prow0 = ((long)b * a.heads + hh) * a.T;             // probability rows (dense mode only)
     char* stg = a.stage_out ? smem + 2 * Tp * ROWB + w * STG_BYTES : nullptr;     // this wave's output staging (store_tile)
@@ -241,7 +245,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
 #pragma unroll
                 for (int t = 0; t < NT; t += 2) {
                     float4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (KS == 2) {
+                    if (t == NT - 2 && odd) {                 // (wave-uniform) the pair's second tile holds no key
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) acc0 = mfma16<F16>(frag_k(kimg, t * 16, s, lane), qf[s], acc0);
+                    } else if constexpr (KS == 2) {
                         const short8_t a0 = frag_k(kimg, t * 16, 0, lane), a1 = frag_k(kimg, t * 16, 1, lane);
                         const short8_t b0 = frag_k(kimg, t * 16 + 16, 0, lane), b1 = frag_k(kimg, t * 16 + 16, 1, lane);
                         acc0 = mfma16<F16>(a0, qf[0], acc0);
@@ -293,6 +300,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (FULL || t < nt) {
+                    if (t == NT - 1 && odd) { sreg[t] = float4_t{0.f, 0.f, 0.f, 0.f}; continue; }   // exp2(-inf - Ms), l += 0
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { sreg[t][r] = __builtin_amdgcn_exp2f(sreg[t][r] - Ms); l += sreg[t][r]; }
                 }
@@ -376,11 +384,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
         for (int dt = 0; dt < ND; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
         // one pair of key tiles; CHECK = false for pairs that cannot hold a key beyond the sequence end (unmasked sequences:
         // every pair but the last) - no compare / select per key there
-        auto pair = [&](int s2, auto chk) {
+        auto pair = [&](int s2, auto chk, auto one) {
             constexpr bool CHECK = decltype(chk)::value;
-            uint2 pk[2];
+            constexpr int NH = decltype(one)::value ? 1 : 2;     // 1: the pair's second key tile is empty (`odd`)
+            uint2 pk[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int half = 0; half < NH; ++half) {
                 const int t = 2 * s2 + half;
                 float4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -414,15 +423,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
             // dense backbone call: all NT tiles populated -> compile-time trip count, so that the fragment reads of the next
             // pair are issued under the MFMAs / exponentials of this one (the rolled loop serialises read -> wait -> MFMA)
 #pragma unroll
-            for (int s2 = 0; s2 < NT / 2 - 1; ++s2) { pair(s2, std::false_type{}); __builtin_amdgcn_sched_barrier(0); }
-            pair(NT / 2 - 1, std::true_type{});
+            for (int s2 = 0; s2 < NT / 2 - 1; ++s2) { pair(s2, std::false_type{}, std::false_type{}); __builtin_amdgcn_sched_barrier(0); }
+            if (odd) pair(NT / 2 - 1, std::true_type{}, std::true_type{});
+            else pair(NT / 2 - 1, std::true_type{}, std::false_type{});
         } else if constexpr (MASKED) {
 #pragma unroll 1
-            for (int s2 = 0; s2 < npair; ++s2) pair(s2, std::true_type{});
+            for (int s2 = 0; s2 < npair; ++s2) pair(s2, std::true_type{}, std::false_type{});
         } else {
 #pragma unroll 1
-            for (int s2 = 0; s2 + 1 < npair; ++s2) pair(s2, std::false_type{});
-            if (npair > 0) pair(npair - 1, std::true_type{});
+            for (int s2 = 0; s2 + 1 < npair; ++s2) pair(s2, std::false_type{}, std::false_type{});
+            if (npair > 0) pair(npair - 1, std::true_type{}, std::false_type{});
         }
         if (BWD) {
 #pragma unroll
@@ -483,6 +493,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const float sc = a.scale * kLog2e;
+    // 16 n + 1 tokens: the last QUERY tile of the even-sized images is all padding (lse = +inf: P == 0 exactly) - the dense form skips
+    // that half of its last pair (see attn_q_pass_kernel)
+    const bool odd = FULL && NT <= 14 && T <= 16 * (NT - 1);
     float csk[CS_SLOTS], csv[CS_SLOTS];                            // column sums of this wave's dK / dV tiles (a.colparts)
 #pragma unroll
     for (int c = 0; c < CS_SLOTS; ++c) csk[c] = csv[c] = 0.f;
@@ -510,10 +523,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
                     fd[half][s] = frag_k(doimg, (2 * u2 + half) * 16, s, lane);
                 }
         };
-        auto qcompute = [&](int u2, short8_t (&fq)[2][KS], short8_t (&fd)[2][KS]) {
-            uint2 pk[2], dsk[2];
+        auto qcompute = [&](int u2, short8_t (&fq)[2][KS], short8_t (&fd)[2][KS], auto one) {
+            constexpr int NH = decltype(one)::value ? 1 : 2;     // 1: the pair's second query tile lies beyond the sequence end (`odd`)
+            uint2 pk[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)}, dsk[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int half = 0; half < NH; ++half) {
                 const int u = 2 * u2 + half;
                 float4_t s_ = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -555,7 +569,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
             for (int u2 = 0; u2 < NT / 2; ++u2) {
                 if (u2 + 1 < NT / 2) qload(u2 + 1, fq[(u2 + 1) & 1], fd[(u2 + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                qcompute(u2, fq[u2 & 1], fd[u2 & 1]);
+                if (u2 == NT / 2 - 1 && odd) qcompute(u2, fq[u2 & 1], fd[u2 & 1], std::true_type{});
+                else qcompute(u2, fq[u2 & 1], fd[u2 & 1], std::false_type{});
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -566,7 +581,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
                 short8_t fq[2][KS], fd[2][KS];
                 qload(u2, fq, fd);
                 __builtin_amdgcn_sched_barrier(0);
-                qcompute(u2, fq, fd);
+                qcompute(u2, fq, fd, std::false_type{});
             }
         }
         {
@@ -621,6 +636,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const long ld = 3L * D;
     const long row0 = (long)b * T;
     const int nt = min(NT, ((T + 31) >> 5) << 1);
+    const int nu = min(nt, (T + 15) >> 4);                       // query tiles that hold a query (the image is an even number of tiles)
     const bf16_t* qbase = qkv + row0 * ld + hh * HD;
     load_image(qimg, qbase, ld, T, nt * 16);
     for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
@@ -648,7 +664,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
         float acc = 0.f;
 #pragma unroll 2
-        for (int u = 0; u < nt; ++u) {
+        for (int u = 0; u < nu; ++u) {
             float4_t s_ = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS; ++s)

@@ -67,6 +67,9 @@ constexpr int TILE_BYTES = 128 * 64 * 2;          // 16 KiB per operand tile per
 #ifndef EDITOR_PP_MI32
 #define EDITOR_PP_MI32 0        // 1: full-tile forward / dgrad products with 16-bit staged epilogues run on v_mfma_f32_32x32x16 (A/B: tools/gemm_alt_ab.py)
 #endif
+#ifndef EDITOR_PP_MI32_PHASES
+#define EDITOR_PP_MI32_PHASES 4 // the MI32 instantiations' K-tile: 4 phases (8 MFMAs on TWO accumulators each) or 2 (16 MFMAs round-robin over FOUR)
+#endif
 #ifndef EDITOR_PP_PHASES
 #define EDITOR_PP_PHASES 0      // phases per K-tile of the ping-pong kernel: 4 (16-MFMA clusters), 2 (32-MFMA clusters, round 5), 0 = per
 #endif                          // operand layout as measured (tools/gemm_alt_ab.py): 2 for the weight gradients, 4 for everything else
@@ -1094,6 +1097,20 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
                     acc[mi * 4 + i][nj * 2 + j] =
                         mfma16<F16>(fbv[j][s], fa[i][s], acc[mi * 4 + i][nj * 2 + j]);
     };
+    // MI32, two-phase K-tile: both 32-column halves of row group MI in one cluster, the four accumulators taken round-robin - a
+    // v_mfma_f32_32x32x16 that depends on the one issued two slots earlier waits for it (measured, round 6: the four-phase form's
+    // clusters of 8 MFMAs on two accumulators take ~165 cycles more than their 256)
+    auto mma_pair32 = [&](auto MI) {
+        constexpr int mi = decltype(MI)::value;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2)
+                    acc32[mi * 2 + i2][nj] = mfma32<F16>(nj ? fb1[ks >> 1][ks & 1] : fb0[ks >> 1][ks & 1], fa[i2 * 2 + (ks >> 1)][ks & 1],
+                                                         acc32[mi * 2 + i2][nj]);
+    };
     auto dma2 = [&](const char* src, const uint32_t (&vo)[2], char* unit) {
         // The K-tile's source position stays an OPAQUE scalar pair: left visible, loop strength reduction folds it into the per-lane
         // offsets - eight 64-bit VGPR pointer pairs carried and incremented through the K loop (16 registers, eight v_lshl_add_u64 per
@@ -1204,8 +1221,8 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PP_WAIT_LGKM0(); PP_BAR();
         // M1
-        PP_MMA(fb0, c0, c0, c4);
-        PP_MMA(fb1, c0, c1, c4);
+        if constexpr (MI32) { if (!PP_ABL(2)) { __builtin_amdgcn_s_setprio(1); mma_pair32(c0{}); __builtin_amdgcn_s_setprio(0); } }
+        else { PP_MMA(fb0, c0, c0, c4); PP_MMA(fb1, c0, c1, c4); }
         PP_BAR();
         // R2
         if (!PP_ABL(4)) read_a(std::integral_constant<int, UA1>{}, B{}, L1{});
@@ -1219,11 +1236,11 @@ __device__ __forceinline__ void pp_body(const GemmB16Args& g, const int bid, con
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PP_WAIT_LGKM0(); PP_BAR();
         // M2
-        PP_MMA(fb0, c1, c0, L1);
-        PP_MMA(fb1, c1, c1, L1);
+        if constexpr (MI32) { if (!PP_ABL(2)) { __builtin_amdgcn_s_setprio(1); mma_pair32(c1{}); __builtin_amdgcn_s_setprio(0); } }
+        else { PP_MMA(fb0, c1, c0, L1); PP_MMA(fb1, c1, c1, L1); }
         PP_BAR();
     };
-    constexpr bool kTwoPhase = EDITOR_PP_PHASES == 2 || (EDITOR_PP_PHASES == 0 && !A_KMAJOR && !B_KMAJOR);
+    constexpr bool kTwoPhase = MI32 ? EDITOR_PP_MI32_PHASES == 2 : (EDITOR_PP_PHASES == 2 || (EDITOR_PP_PHASES == 0 && !A_KMAJOR && !B_KMAJOR));
     auto ktile = [&](int t, auto BUF, auto FG) __attribute__((always_inline)) {
         if constexpr (kTwoPhase) ktile2(t, BUF, FG); else ktile4(t, BUF, FG);
     };
