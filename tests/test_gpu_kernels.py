@@ -928,3 +928,62 @@ def test_k_tile_choreographies_agree_bit_for_bit(dtype):
         route(False)
     for p_, q_ in zip(*res):
         assert torch.equal(p_, q_)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_mfma_32x32x16_form_agrees_bit_for_bit(dtype):
+    """the v_mfma_f32_32x32x16 form of the ping-pong kernel (EDITOR_PP_MI32, built as libeditor_gemm_mi32.so by
+    `python -m editor_amd.build --mi32`; 32-row fragments, (row >> 1) & 7 image swizzle, the one-pass 16-bit staged epilogue at the
+    32x32 accumulator coordinates) against the shipped 16x16x32 form on the three products it applies to - qkv forward (+ bias, row
+    scale), fc1 + GELU with the saved gelu', fc2 dgrad x gelu' - plus a ragged M / N edge: every bit.  Skipped when that library was
+    not built / is older than the kernel source.  (It measures 3 - 12 % slower: profiles/r06_gemm_mi32_ab.txt; it is not shipped.)"""
+    import ctypes
+    import os
+    from editor_amd import _lib, build, ops as ops_mod
+    src = os.path.join(build.CSRC, "gemm_bf16.hip")
+    if not os.path.exists(build.LIB_MI32) or os.path.getmtime(build.LIB_MI32) < os.path.getmtime(src):
+        pytest.skip("libeditor_gemm_mi32.so not built from the current gemm_bf16.hip (python -m editor_amd.build --mi32)")
+    lib = _lib.lib()
+    names = ("editor_gemm_bf16", "editor_gemm_f16")
+    keep = {n_: lib._fn.get(n_) for n_ in names}
+
+    def route(alt):
+        srcl = ctypes.CDLL(build.LIB_MI32) if alt else lib.cdll
+        for name in names:
+            fn_ = getattr(srcl, name)
+            fn_.argtypes = lib.protos[name]
+            fn_.restype = ctypes.c_int
+            lib._fn[name] = fn_
+    g = torch.Generator(device="cuda").manual_seed(11)
+    res = []
+    try:
+        for alt in (False, True):
+            route(alt)
+            outs = []
+            for m, n, k in ((3 * 32 * 129, 2304, 768), (1000, 776, 768)):          # whole tiles + a ragged edge (M % 256, N % 256 != 0)
+                g.manual_seed(11 + m)
+                x = torch.randn(m, k, device="cuda", generator=g).to(dtype)
+                w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).to(dtype)
+                bias = torch.randn(n, device="cuda", generator=g)
+                rs = torch.rand(m, device="cuda", generator=g)
+                aux_in = torch.randn(m, n, device="cuda", generator=g).to(dtype)
+                y0 = torch.zeros(m, n, dtype=dtype, device="cuda")
+                ops_mod.gemm(x, w, y0, m, n, k, k, k, n, 0, 0, bias=bias, rowscale=rs, epilogue=ops_mod.EPI_FORCE_PP)
+                y1 = torch.zeros(m, n, dtype=dtype, device="cuda")
+                a1 = torch.zeros(m, n, dtype=dtype, device="cuda")
+                ops_mod.gemm(x, w, y1, m, n, k, k, k, n, 0, 0, bias=bias,
+                             epilogue=ops_mod.EPI_GELU | ops_mod.EPI_AUX_GRAD | ops_mod.EPI_FORCE_PP, aux=a1)
+                y2 = torch.zeros(m, n, dtype=dtype, device="cuda")
+                ops_mod.gemm(x, w, y2, m, n, k, k, k, n, 0, 0,
+                             epilogue=ops_mod.EPI_GELU_BWD | ops_mod.EPI_AUX_GRAD | ops_mod.EPI_FORCE_PP, aux=aux_in)
+                torch.cuda.synchronize()
+                outs += [y0, y1, a1, y2]
+            res.append(outs)
+    finally:
+        for n_, f_ in keep.items():
+            if f_ is not None:
+                lib._fn[n_] = f_
+        route(False)
+    for p_, q_ in zip(*res):
+        assert p_.float().abs().max() > 0
+        assert torch.equal(p_, q_)
