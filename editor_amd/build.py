@@ -28,6 +28,22 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 DEBUG_ONLY = {"probe.hip", "gemm_w4.hip"}          # libeditor_probe.so: tests / tools only
 
 
+def gemm_source_hash():
+    """sha1 of the sources the optional A/B builds of gemm_bf16.hip (--alt, --mi32) are made of.  Written beside each as <lib>.srchash at
+    link time: the tests that compare such a build with the product library skip when it does not match the CURRENT sources (file times
+    do not survive the copy to the GPU box)."""
+    import hashlib
+    hsh = hashlib.sha1()
+    for f in [os.path.join(CSRC, "gemm_bf16.hip"), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "editor_hip.h")]:
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def ab_lib_current(lib):
+    stamp = lib + ".srchash"
+    return os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == gemm_source_hash()
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -98,10 +114,13 @@ def build(force=False, verbose=False, trace=False, alt=False, mi32=False):
         _link(LIB_TRACE, [trace_obj])
     if alt and (force or _stale(LIB_ALT, [alt_obj])):
         _link(LIB_ALT, [alt_obj])
+        open(LIB_ALT + ".srchash", "w").write(gemm_source_hash() + "\n")
     if mi32 and (force or _stale(LIB_MI32, [mi32_obj])):
         _link(LIB_MI32, [mi32_obj])
+        open(LIB_MI32 + ".srchash", "w").write(gemm_source_hash() + "\n")
     if mi32 and (force or _stale(LIB_MI32P2, [mi32p2_obj])):
         _link(LIB_MI32P2, [mi32p2_obj])
+        open(LIB_MI32P2 + ".srchash", "w").write(gemm_source_hash() + "\n")
     return LIB
 
 

@@ -299,6 +299,9 @@ class _SubCtx:
 # (ops.EPI_STAGGER) - the one product the spread helped in tools/stagger_sweep.py (rotating operands: 214 -> 186 us; every other
 # product of the path is flat or slower with it).  In the step, same box, twice each: 42.56 / 42.57 -> 42.31 / 42.34 ms replay-only.
 STAGGER_QKV = ops.EPI_STAGGER(int(os.environ.get("EDITOR_STAGGER_QKV", "24")))
+# round 6 A/B switches (tools/stagger_sweep.py, rotating operands: fc2 dgrad x gelu' 295 -> 283 us at 32, proj forward + residual 132 -> 125 at 8)
+STAGGER_FC2D = ops.EPI_STAGGER(int(os.environ.get("EDITOR_STAGGER_FC2D", "0")))
+STAGGER_PROJ = ops.EPI_STAGGER(int(os.environ.get("EDITOR_STAGGER_PROJ", "0")))
 
 # LayerNorm-1's backward of block i+1 also writes what block i's backward STARTS with: the 16-bit, drop-path- and loss-scaled copy of
 # dL/dx (operand of the fc2 dgrad / wgrad) and its column sums (the fc2 bias gradient) - ops.layernorm_bwd_cast, as LayerNorm-2's
@@ -379,7 +382,8 @@ def _linear_bwd_gen(dy, x2d, w_act, need_bias, gelu_pre=None, m_live=None, db=No
                        rq=rq, live_dense=live_dense)
     else:
         ag = ops.EPI_AUX_GRAD if (dy.dtype in ops.HALF_DTYPES and aux_is_grad) else 0   # 16-bit: gelu_pre holds gelu'(pre-activation)
-        yield _GemmReq(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, epilogue=ops.EPI_GELU_BWD | ag, aux=gelu_pre, m_live=m_live,
+        yield _GemmReq(dy, wb, dx, m, k, n, n, ldb, k, 0, tb, epilogue=ops.EPI_GELU_BWD | ag | (STAGGER_FC2D if (m_live is None or live_dense) and m >= 16384 else 0),
+                       aux=gelu_pre, m_live=m_live,
                        colsum=dxcs, colsum_scale=inv, tag="dgrad", rq=rq, live_dense=live_dense)
     dw = dw_out if dw_out is not None else torch.empty(n, k, dtype=torch.float32, device=dy.device)
     if need_bias and db is None:
@@ -580,7 +584,7 @@ class TransformerBlockFn(torch.autograd.Function):
         else:
             x1 = torch.empty_like(x2d)              # x1 = x + rs * (ao Wp^T + b): residual add in the GEMM epilogue
             yield _GemmReq(ao, wp, x1, m, d, d, d, d, d, 0, 0, bias=projb, rowscale=rowscale_attn,
-                           epilogue=ops.EPI_RESIDUAL, aux=x2d, m_live=m_live)
+                           epilogue=ops.EPI_RESIDUAL | (STAGGER_PROJ if m_live is None else 0), aux=x2d, m_live=m_live)
             if plan is not None:
                 x2 = torch.empty_like(x2d)          # (dropped rows: LayerNorm-2 copies x1 there; live rows: the fc2 epilogue)
                 h2, mean2, rstd2 = ops.layernorm_fwd_perm(x1, n2w, n2b, eps, act_dtype, plan[0], rowscale_mlp, x2)

@@ -893,8 +893,7 @@ def test_k_tile_choreographies_agree_bit_for_bit(dtype):
     import ctypes
     import os
     from editor_amd import _lib, build, ops as ops_mod
-    src = os.path.join(build.CSRC, "gemm_bf16.hip")
-    if not os.path.exists(build.LIB_ALT) or os.path.getmtime(build.LIB_ALT) < os.path.getmtime(src):
+    if not build.ab_lib_current(build.LIB_ALT):
         pytest.skip("libeditor_gemm_alt.so not built from the current gemm_bf16.hip (python -m editor_amd.build --alt)")
     lib = _lib.lib()
     names = ("editor_gemm_bf16", "editor_gemm_f16", "editor_gemm_wgrad_group")
@@ -940,8 +939,7 @@ def test_mfma_32x32x16_form_agrees_bit_for_bit(dtype):
     import ctypes
     import os
     from editor_amd import _lib, build, ops as ops_mod
-    src = os.path.join(build.CSRC, "gemm_bf16.hip")
-    if not os.path.exists(build.LIB_MI32) or os.path.getmtime(build.LIB_MI32) < os.path.getmtime(src):
+    if not build.ab_lib_current(build.LIB_MI32):
         pytest.skip("libeditor_gemm_mi32.so not built from the current gemm_bf16.hip (python -m editor_amd.build --mi32)")
     lib = _lib.lib()
     names = ("editor_gemm_bf16", "editor_gemm_f16")
