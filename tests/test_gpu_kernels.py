@@ -118,7 +118,10 @@ def _attn_ref(qkv, b, t, heads, hd, mask):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("t,use_mask", [(129, False), (129, True), (193, False), (387, True), (50, False)])
+@pytest.mark.parametrize("t,use_mask", [(129, False), (129, True), (193, False), (387, True), (50, False),
+                                        # the edges of the dense kernels' "last tile of the image is all padding" skip (round 6):
+                                        # 16 (NT - 1) tokens take it, one more does not; NT = 10 and NT = 14
+                                        (144, False), (145, False), (160, False), (208, False), (209, False)])
 def test_attention_fwd_bwd(ops, dtype, t, use_mask):
     b, heads, hd = 3, 12, 64
     d = heads * hd
@@ -621,8 +624,8 @@ def test_attention_bwd_column_sums_refused_where_not_built(ops):
                           qkv[:, :768].contiguous(), colsum=torch.empty(3 * 768, device="cuda"))
 
 
-@pytest.mark.parametrize("hd,heads", [(32, 12), (96, 8)])
-@pytest.mark.parametrize("t", [129, 193])
+@pytest.mark.parametrize("hd,heads", [(32, 12), (96, 8), (64, 12)])
+@pytest.mark.parametrize("t", [129, 193, 144, 145])
 def test_rollout_recomputed_other_head_widths(ops, hd, heads, t):
     """Rollout steps that recompute P from (qkv, lse) at 32- / 96-wide heads == the rollout over the materialised probabilities;
     the one-launch form == the per-layer steps, bit for bit."""
