@@ -11,7 +11,8 @@ Host side (Python, as in the reference) + one HIP kernel (csrc/augment.hip):
 Not here: JPEG decode and T.Resize(interpolation=3) (PIL bicubic) stay on the host / in the decoder; the transform takes
 decoded, resized uint8 (B,H,W,3) images.  The flip / crop draws use torch's CPU generator the way torchvision 0.14 does
 (`torch.rand(1) < p`; `torch.randint(0, h - th + 1)`, then `w`), but torchvision is not installed in the build image, so
-that ORDER is restated from its documentation, not pinned ("parity unpinned" for those two draws only).
+that ORDER is restated from its documentation, not pinned ("parity unpinned" for those two draws only; what the draws do to the
+pixels is pinned to Pillow: tests/golden/f19_flip_pad_crop.npz).
 """
 import copy
 import ctypes

@@ -2,8 +2,10 @@
 T.RandomHorizontalFlip -> T.Pad(p) -> T.RandomCrop -> T.ToTensor -> T.Normalize -> RandomErasing(mode='pixel')
 (data/datasets/make_dataloader.py:245-253, 55-146) with the random draws supplied as parameters.  torchvision is not
 installed in the build image: flip / pad / crop / ToTensor / Normalize are restated from their documented semantics
-(torchvision==0.14.1, requirements.txt:158) - "parity unpinned" for those; the erase rectangle and the sampler are pinned
-to the reference through tests/golden/f9_input.npz.  Imported by tests/ only."""
+(torchvision==0.14.1, requirements.txt:158) and pinned, for given draws, to Pillow + torch - the implementations torchvision hands a
+PIL image to (tests/golden/f19_flip_pad_crop.npz, made by capture_golden.py f19; bit-equal).  "Parity unpinned" only for the ORDER of
+the flip / crop draws (editor_amd/data.py); the erase rectangle and the sampler are pinned to the reference through
+tests/golden/f9_input.npz.  Imported by tests/ only."""
 import torch
 import torch.nn.functional as F
 

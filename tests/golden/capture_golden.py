@@ -550,3 +550,49 @@ def f18_center_loss(seed=181):
 
 if __name__ == "__main__" and "f18" in sys.argv[1:]:
     f18_center_loss()
+
+
+def f19_flip_pad_crop(seed=191):
+    """F19 (row N3): the pixel semantics of T.RandomHorizontalFlip / T.Pad(p) / T.RandomCrop / T.ToTensor / T.Normalize
+    (make_dataloader.py:247-251) for GIVEN draws.  torchvision 0.14.1 (absent here) hands a PIL input to Pillow for the first three -
+    hflip = Image.transpose(FLIP_LEFT_RIGHT), pad (constant) = ImageOps.expand(border, fill = 0), crop = Image.crop((left, top,
+    left + w, top + h)) - and ToTensor / Normalize are uint8 -> float32 / 255, (x - mean) / std: Pillow + torch are the reference
+    implementations here, as for T.Resize (f13).  What stays restated from documentation is the ORDER of the random draws
+    (editor_amd/data.py::DeviceTrainTransform.draw), not what the draws do to the pixels."""
+    from PIL import Image, ImageOps
+    cases = [(256, 128, 10), (128, 256, 10), (384, 128, 10), (37, 53, 4)]
+    rec = {}
+    gen = np.random.RandomState(seed)
+    for ci, (h, w, pad) in enumerate(cases):
+        n = 6
+        img = synth.integers(seed, "fpc/%d" % ci, (n, h, w, 3), 256).numpy().astype(np.uint8)
+        params = np.zeros((n, 3), dtype=np.int32)
+        params[:, 0] = gen.randint(0, 2, n)
+        params[:, 1] = gen.randint(0, 2 * pad + 1, n)           # top
+        params[:, 2] = gen.randint(0, 2 * pad + 1, n)           # left
+        params[0] = (1, 0, 2 * pad)                               # corners
+        params[1] = (0, 2 * pad, 0)
+        outs = []
+        for i in range(n):
+            flip, top, left = [int(v) for v in params[i]]
+            im = Image.fromarray(img[i])
+            if flip:
+                im = im.transpose(Image.FLIP_LEFT_RIGHT)
+            im = ImageOps.expand(im, border=pad, fill=0)
+            im = im.crop((left, top, left + w, top + h))
+            x = torch.from_numpy(np.array(im)).permute(2, 0, 1).float().div(255)
+            mean = torch.tensor([0.5, 0.5, 0.5]).view(3, 1, 1)
+            std = torch.tensor([0.5, 0.5, 0.5]).view(3, 1, 1)
+            outs.append(x.sub(mean).div(std))
+        out = torch.stack(outs).numpy()
+        rec["case%d" % ci] = np.asarray([h, w, pad, n], dtype=np.int32)
+        rec["params%d" % ci] = params
+        rec["out%d" % ci] = out[:, :, ::5, ::3].copy()            # subsample + sums keep the fixture small
+        rec["sum%d" % ci] = out.astype(np.float64).sum(axis=(1, 2, 3))
+        rec["wsum%d" % ci] = (out.astype(np.float64) * (np.arange(out[0].size).reshape(out[0].shape) % 251 + 1)).sum(axis=(1, 2, 3))
+    import PIL
+    save("f19_flip_pad_crop", seed=seed, n=len(cases), pillow=np.array(PIL.__version__), **rec)
+
+
+if __name__ == "__main__" and "f19" in sys.argv[1:]:
+    f19_flip_pad_crop()

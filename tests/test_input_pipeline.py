@@ -71,6 +71,48 @@ def test_device_train_transform_matches_oracle(h, w, b):
         tf(img, params, noise)
 
 
+def _fpc_cases():
+    g = load_golden("f19_flip_pad_crop")
+    seed = int(g["seed"])
+    for ci in range(int(g["n"])):
+        h, w, pad, n = [int(v) for v in g["case%d" % ci]]
+        img = synth.integers(seed, "fpc/%d" % ci, (n, h, w, 3), 256).to(torch.uint8)
+        p3 = torch.from_numpy(g["params%d" % ci].astype(np.int64))
+        params = torch.zeros(n, 8, dtype=torch.int64)
+        params[:, :3] = p3                                     # flip, top, left; no erase
+        yield ci, g, img, params, pad
+
+
+def _fpc_check(out, g, ci):
+    out = out.double().numpy()
+    assert np.array_equal(out[:, :, ::5, ::3].astype(np.float32), g["out%d" % ci])
+    assert np.array_equal(out.sum(axis=(1, 2, 3)), g["sum%d" % ci])
+    wts = np.arange(out[0].size).reshape(out[0].shape) % 251 + 1
+    assert np.array_equal((out * wts).sum(axis=(1, 2, 3)), g["wsum%d" % ci])
+
+
+def test_flip_pad_crop_oracle_matches_pillow():
+    """F19: what the train transform's flip / pad / crop / ToTensor / Normalize do to the pixels for GIVEN draws, pinned to Pillow +
+    torch - the implementations torchvision 0.14.1 delegates to for PIL inputs (tests/golden/capture_golden.py f19).  The oracle's
+    restatement reproduces every value (subsampled image + two checksums per sample); only the ORDER of the draws stays restated."""
+    from oracle import augment_ref
+    for ci, g, img, params, pad in _fpc_cases():
+        n, h, w, _ = img.shape
+        ref = augment_ref.train_transform(img, params, pad, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5), torch.zeros(n, 3, h, w))
+        _fpc_check(ref, g, ci)
+
+
+@pytest.mark.gpu
+def test_device_flip_pad_crop_matches_pillow():
+    """The device transform (editor_augment_u8) against the same Pillow-made fixture, bit for bit."""
+    from editor_amd.data import DeviceTrainTransform
+    for ci, g, img, params, pad in _fpc_cases():
+        n, h, w, _ = img.shape
+        tf = DeviceTrainTransform((h, w), prob=0.5, padding=pad, re_prob=0.5)
+        out = tf(img.cuda(), params, torch.zeros(n, 3, h, w, device="cuda"))
+        _fpc_check(out.cpu(), g, ci)
+
+
 # ---- T.Resize (Pillow ImagingResample) ----------------------------------------------------------------------------
 def _resize_cases():
     g = load_golden("f13_resize")
