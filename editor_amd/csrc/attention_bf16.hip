@@ -636,7 +636,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const long ld = 3L * D;
     const long row0 = (long)b * T;
     const int nt = min(NT, ((T + 31) >> 5) << 1);
-    const int nu = min(nt, (T + 15) >> 4);                       // query tiles that hold a query (the image is an even number of tiles)
+    // query tiles that contribute: the populated ones (the image is an even number of tiles) - and only the FIRST when the incoming
+    // vector is the one-hot class-token row (r_in == NULL, the first step of the rollout): every other query's weight is an exact zero
+    const int nu = r_in ? min(nt, (T + 15) >> 4) : 1;
     const bf16_t* qbase = qkv + row0 * ld + hh * HD;
     load_image(qimg, qbase, ld, T, nt * 16);
     for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
