@@ -21,6 +21,7 @@ LIB_ALT = os.path.join(HERE, "libeditor_gemm_alt.so")      # csrc/gemm_bf16.hip 
 ALT_FLAGS = ["-DEDITOR_PP_PHASES=%s" % os.environ.get("EDITOR_ALT_PHASES", "4")]
 LIB_MI32 = os.path.join(HERE, "libeditor_gemm_mi32.so")    # ... with v_mfma_f32_32x32x16 in the full-tile forward / dgrad products (round 6 A/B)
 MI32_FLAGS = ["-DEDITOR_PP_MI32=1"]
+LIB_ATTN_ALT = os.path.join(HERE, "libeditor_attn_alt.so")     # csrc/attention_bf16.hip with both padding-tile switches flipped (tools/attn_ab.py)
 LIB_MI32P2 = os.path.join(HERE, "libeditor_gemm_mi32p2.so")  # ... and the two-phase K-tile (16-MFMA clusters over four accumulators)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
@@ -28,20 +29,26 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 DEBUG_ONLY = {"probe.hip", "gemm_w4.hip"}          # libeditor_probe.so: tests / tools only
 
 
-def gemm_source_hash():
-    """sha1 of the sources the optional A/B builds of gemm_bf16.hip (--alt, --mi32) are made of.  Written beside each as <lib>.srchash at
-    link time: the tests that compare such a build with the product library skip when it does not match the CURRENT sources (file times
-    do not survive the copy to the GPU box)."""
+def _ab_sources(lib):
+    stem = "attention_bf16.hip" if "attn" in os.path.basename(lib) else "gemm_bf16.hip"
+    return [os.path.join(CSRC, stem), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn_common.h"),
+            os.path.join(HERE, "..", "include", "editor_hip.h")]
+
+
+def ab_source_hash(lib):
+    """sha1 of the sources an optional A/B build (--alt, --mi32: gemm_bf16.hip; --attn-alt: attention_bf16.hip) is made of.  Written
+    beside it as <lib>.srchash at link time: the tests / tools that compare such a build with the product library skip when it does not
+    match the CURRENT sources (file times do not survive the copy to the GPU box)."""
     import hashlib
     hsh = hashlib.sha1()
-    for f in [os.path.join(CSRC, "gemm_bf16.hip"), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "editor_hip.h")]:
+    for f in _ab_sources(lib):
         hsh.update(open(f, "rb").read())
     return hsh.hexdigest()[:16]
 
 
 def ab_lib_current(lib):
     stamp = lib + ".srchash"
-    return os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == gemm_source_hash()
+    return os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == ab_source_hash(lib)
 
 
 def _stale(target, deps):
@@ -71,7 +78,7 @@ def _link(lib, objs):
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
 
 
-def build(force=False, verbose=False, trace=False, alt=False, mi32=False):
+def build(force=False, verbose=False, trace=False, alt=False, mi32=False, attn_alt=False):
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     srcs = sorted(s for s in glob.glob(os.path.join(CSRC, "*.hip")) if os.path.basename(s) not in DEBUG_ONLY)
     objs = [s[:-4] + ".o" for s in srcs]
@@ -99,6 +106,14 @@ def build(force=False, verbose=False, trace=False, alt=False, mi32=False):
     alt_obj = os.path.join(CSRC, "gemm_bf16.alt.o")
     if alt and (force or _stale(alt_obj, [gemm_src] + hdrs)):
         jobs.append((gemm_src, alt_obj, ALT_FLAGS))
+    attnalt_objs = []
+    if attn_alt:
+        attn_src = os.path.join(CSRC, "attention_bf16.hip")
+        for hd, flags in ((64, []), (32, ["-DATTN_HD=32"]), (96, ["-DATTN_HD=96"])):
+            obj = os.path.join(CSRC, "attention_bf16.alt%d.o" % hd)
+            attnalt_objs.append(obj)
+            if force or _stale(obj, [attn_src] + hdrs):
+                jobs.append((attn_src, obj, flags + ["-DATTN_PAIR_SKIP=1", "-DATTN_ROLLOUT_SKIP=0"]))
     mi32_obj = os.path.join(CSRC, "gemm_bf16.mi32.o")
     if mi32 and (force or _stale(mi32_obj, [gemm_src] + hdrs)):
         jobs.append((gemm_src, mi32_obj, MI32_FLAGS))
@@ -114,15 +129,18 @@ def build(force=False, verbose=False, trace=False, alt=False, mi32=False):
         _link(LIB_TRACE, [trace_obj])
     if alt and (force or _stale(LIB_ALT, [alt_obj])):
         _link(LIB_ALT, [alt_obj])
-        open(LIB_ALT + ".srchash", "w").write(gemm_source_hash() + "\n")
+        open(LIB_ALT + ".srchash", "w").write(ab_source_hash(LIB_ALT) + "\n")
+    if attn_alt and (force or _stale(LIB_ATTN_ALT, attnalt_objs)):
+        _link(LIB_ATTN_ALT, attnalt_objs)
+        open(LIB_ATTN_ALT + ".srchash", "w").write(ab_source_hash(LIB_ATTN_ALT) + "\n")
     if mi32 and (force or _stale(LIB_MI32, [mi32_obj])):
         _link(LIB_MI32, [mi32_obj])
-        open(LIB_MI32 + ".srchash", "w").write(gemm_source_hash() + "\n")
+        open(LIB_MI32 + ".srchash", "w").write(ab_source_hash(LIB_MI32) + "\n")
     if mi32 and (force or _stale(LIB_MI32P2, [mi32p2_obj])):
         _link(LIB_MI32P2, [mi32p2_obj])
-        open(LIB_MI32P2 + ".srchash", "w").write(gemm_source_hash() + "\n")
+        open(LIB_MI32P2 + ".srchash", "w").write(ab_source_hash(LIB_MI32P2) + "\n")
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, trace="--trace" in sys.argv, alt="--alt" in sys.argv, mi32="--mi32" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, trace="--trace" in sys.argv, alt="--alt" in sys.argv, mi32="--mi32" in sys.argv, attn_alt="--attn-alt" in sys.argv))

@@ -22,6 +22,14 @@
 
 namespace {
 
+// Round 6, the all-padding last tile of a 16 n + 1 token image (tools/attn_ab.py: same-box A/B against libeditor_attn_alt.so, which is
+// this source with BOTH switches flipped; every output bit-identical either way):
+#ifndef ATTN_ROLLOUT_SKIP
+#define ATTN_ROLLOUT_SKIP 1            // rollout step: the query loop ends at the last populated tile, the one-hot first step reads ONE tile:
+#endif                                 //   two layers 74.7 -> 66.2 us (T = 129), 124.4 -> 103.1 (T = 193) - shipped
+#ifndef ATTN_PAIR_SKIP
+#define ATTN_PAIR_SKIP 0               // q / kv passes: the last tile PAIR taken with one tile.  Less arithmetic, not less time: forward 77.5 ->
+#endif                                 //   77.8 us, backward 223.3 -> 225.3 (T = 129), 381.1 -> 393.7 (T = 193) - measured, NOT shipped
 #ifndef ATTN_UNROLL_BWD
 #define ATTN_UNROLL_BWD 1              // dense backward passes with compile-time trip counts (measured: tools/attn_bench.py)
 #endif
@@ -212,9 +220,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
     };
     const float sc = a.scale * kLog2e;
     // 16 n + 1 tokens (every ViT sequence: patches + the class token): the LAST key tile of the even-sized image lies entirely beyond
-    // the sequence end - its scores are masked to -inf, its probabilities are exact zeros.  The dense (FULL) forms skip that half of
-    // their last pair of key tiles: two to four MFMAs, four exponentials and their selects per own tile, same bits (round 6).
-    const bool odd = FULL && !MASKED && NT <= 14 && T <= 16 * (NT - 1);   // (NT <= 14: the backbone sequences; the longer forms spill with the extra copy of the pair)
+    // the sequence end - its scores are masked to -inf, its probabilities are exact zeros.  With ATTN_PAIR_SKIP the dense (FULL) forms
+    // skip that half of their last pair of key tiles: two to four MFMAs, four exponentials and their selects per own tile, same bits
+    // (round 6) - and the same time: a measured non-win, compiled out by default (the branches below fold away).
+    const bool odd = ATTN_PAIR_SKIP && FULL && !MASKED && NT <= 14 && T <= 16 * (NT - 1);   // (NT <= 14: the backbone sequences; the longer forms spill with the extra copy of the pair)
     const long row_idx0 = (long)hh * a.Mtot + row0;                // lse / delta index of row 0
     const long prow0 = ((long)b * a.heads + hh) * a.T;             // probability rows (dense mode only)
     char* stg = a.stage_out ? smem + 2 * Tp * ROWB + w * STG_BYTES : nullptr;     // this wave's output staging (store_tile)
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 
     const float sc = a.scale * kLog2e;
     // 16 n + 1 tokens: the last QUERY tile of the even-sized images is all padding (lse = +inf: P == 0 exactly) - the dense form skips
     // that half of its last pair (see attn_q_pass_kernel)
-    const bool odd = FULL && NT <= 14 && T <= 16 * (NT - 1);
+    const bool odd = ATTN_PAIR_SKIP && FULL && NT <= 14 && T <= 16 * (NT - 1);
     float csk[CS_SLOTS], csv[CS_SLOTS];                            // column sums of this wave's dK / dV tiles (a.colparts)
 #pragma unroll
     for (int c = 0; c < CS_SLOTS; ++c) csk[c] = csv[c] = 0.f;
@@ -638,7 +647,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int nt = min(NT, ((T + 31) >> 5) << 1);
     // query tiles that contribute: the populated ones (the image is an even number of tiles) - and only the FIRST when the incoming
     // vector is the one-hot class-token row (r_in == NULL, the first step of the rollout): every other query's weight is an exact zero
-    const int nu = r_in ? min(nt, (T + 15) >> 4) : 1;
+    const int nu = !ATTN_ROLLOUT_SKIP ? nt : (r_in ? min(nt, (T + 15) >> 4) : 1);
     const bf16_t* qbase = qkv + row0 * ld + hh * HD;
     load_image(qimg, qbase, ld, T, nt * 16);
     for (int t = threadIdx.x; t < Tp; t += blockDim.x) {

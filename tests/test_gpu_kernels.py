@@ -119,8 +119,8 @@ def _attn_ref(qkv, b, t, heads, hd, mask):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("t,use_mask", [(129, False), (129, True), (193, False), (387, True), (50, False),
-                                        # the edges of the dense kernels' "last tile of the image is all padding" skip (round 6):
-                                        # 16 (NT - 1) tokens take it, one more does not; NT = 10 and NT = 14
+                                        # the edges of "the last tile of the even-sized image is all padding" (round 6: the rollout
+                                        # step's skip, the ATTN_PAIR_SKIP builds): 16 (NT - 1) tokens, one more; NT = 10 and NT = 14
                                         (144, False), (145, False), (160, False), (208, False), (209, False)])
 def test_attention_fwd_bwd(ops, dtype, t, use_mask):
     b, heads, hd = 3, 12, 64
@@ -980,6 +980,52 @@ def test_mfma_32x32x16_form_agrees_bit_for_bit(dtype):
                 torch.cuda.synchronize()
                 outs += [y0, y1, a1, y2]
             res.append(outs)
+    finally:
+        for n_, f_ in keep.items():
+            if f_ is not None:
+                lib._fn[n_] = f_
+        route(False)
+    for p_, q_ in zip(*res):
+        assert p_.float().abs().max() > 0
+        assert torch.equal(p_, q_)
+
+
+@pytest.mark.parametrize("t", [129, 144, 145, 193])
+def test_attention_padding_tile_switches_do_not_change_a_bit(t):
+    """Round 6: csrc/attention_bf16.hip's two padding-tile switches - ATTN_ROLLOUT_SKIP (shipped: the rollout step ends at the last
+    populated query tile, its one-hot first step reads one) and ATTN_PAIR_SKIP (not shipped: the q / kv passes take their last tile pair
+    with one tile; measured no gain) - against the build with both flipped (libeditor_attn_alt.so, `python -m editor_amd.build
+    --attn-alt`): forward output + log-sum-exps, backward dqkv + its column sums, a three-layer rollout - every bit.  Skipped when that
+    library was not built from the current source."""
+    import ctypes
+    from editor_amd import _lib, build, ops as ops_mod
+    if not build.ab_lib_current(build.LIB_ATTN_ALT):
+        pytest.skip("libeditor_attn_alt.so not built from the current attention_bf16.hip (python -m editor_amd.build --attn-alt)")
+    lib = _lib.lib()
+    names = ("editor_attention_fwd_bf16", "editor_attention_bwd_bf16", "editor_attention_bwd_colsum_bf16", "editor_attn_rollout_step_bf16")
+    keep = {n_: lib._fn.get(n_) for n_ in names}
+
+    def route(alt):
+        srcl = ctypes.CDLL(build.LIB_ATTN_ALT) if alt else lib.cdll
+        for name in names:
+            fn_ = getattr(srcl, name)
+            fn_.argtypes = lib.protos[name]
+            fn_.restype = ctypes.c_int
+            lib._fn[name] = fn_
+    b, heads, hd = 16, 12, 64
+    g = torch.Generator(device="cuda").manual_seed(t)
+    qkv = (torch.randn(b * t, 3 * heads * hd, device="cuda", generator=g) * 0.7).bfloat16()
+    do = torch.randn(b * t, heads * hd, device="cuda", generator=g).bfloat16()
+    res = []
+    try:
+        for alt in (False, True):
+            route(alt)
+            o, lse = ops_mod.attention_fwd(qkv, b, t, heads, hd, None, None)
+            cs = torch.zeros(3 * heads * hd, device="cuda")
+            dqkv = ops_mod.attention_bwd(qkv, do, b, t, heads, hd, None, lse, o, colsum=cs)
+            roll = ops_mod.attn_rollout_qk([(qkv, lse)] * 3, b, t, heads, hd)
+            torch.cuda.synchronize()
+            res.append([o, lse, dqkv, cs, roll])
     finally:
         for n_, f_ in keep.items():
             if f_ is not None:

@@ -18,7 +18,10 @@ print("fwd no probs    %.1f us" % bench(lambda: ops.attention_fwd(qkv, b, t, hea
 o, lse = ops.attention_fwd(qkv, b, t, heads, hd, None, None)
 do = torch.randn_like(o)
 print("bwd (dq + dk/dv)  %.1f us" % bench(lambda: ops.attention_bwd(qkv, do, b, t, heads, hd, None, lse, o)))
-print("rollout step      %.1f us" % bench(lambda: ops.attn_rollout_qk([(qkv, lse)], b, t, heads, hd)))
+# (round 6: the first step of a rollout - the one-hot class-token vector - reads one query tile; a later step all of them: two layers minus one)
+r1 = bench(lambda: ops.attn_rollout_qk([(qkv, lse)], b, t, heads, hd))
+r2 = bench(lambda: ops.attn_rollout_qk([(qkv, lse), (qkv, lse)], b, t, heads, hd))
+print("rollout step      %.1f us   (first, one-hot step: %.1f us)" % (r2 - r1, r1))
 for tt in (193,):
     q2 = (torch.randn(b * tt, 3 * heads * hd, device='cuda') * 0.5).bfloat16()
     print("T=%d fwd no probs %.1f us" % (tt, bench(lambda: ops.attention_fwd(q2, b, tt, heads, hd, None, None))))
@@ -30,7 +33,8 @@ for heads2, hd2 in ((8, 96), (24, 32)):
     do3 = torch.randn_like(o3)
     f16 = bench(lambda: ops.attention_fwd(q3, b, t, heads2, hd2, None, None))
     b16 = bench(lambda: ops.attention_bwd(q3, do3, b, t, heads2, hd2, None, lse3, o3))
-    r16 = bench(lambda: ops.attn_rollout_qk([(q3, lse3)], b, t, heads2, hd2))
+    r16 = (bench(lambda: ops.attn_rollout_qk([(q3, lse3), (q3, lse3)], b, t, heads2, hd2))
+           - bench(lambda: ops.attn_rollout_qk([(q3, lse3)], b, t, heads2, hd2)))
     q32 = q3.float()
     def detour_fwd():
         o_, p_ = ops.attention_fwd(q3.float(), b, t, heads2, hd2, None, None)
