@@ -29,6 +29,9 @@ One JSON line on rank 0.
   modes         every compute mode beside the benchmarked one - bf16, f16, f16x2 (split-precision forward), f32 (exact-f32
                 parity mode): images/sec of the same timed loop (child process each) AND its accuracy against the oracle
                 (cls4t relative error, token-selection agreement), so the speed is never read without the parity it buys.
+  other_configs BASELINE.json configs 3 / 4 / 5 (RGBNT100, MSVR310 384x128, the synthetic 4-modal ViT-L) on this one GPU: the same timed loop
+                in a child process per preset - per-GPU workloads of configs quoted on 8 GPUs, so that the driver's own run carries
+                a number for each; not part of `value`.  N = 1 default line only (--no-others skips it).
   cpu_baseline  the oracle (CPU restatement pinned to the reference) timed on this host's cores: the same step at B=128
                 (1 warm-up + 3 timed iterations: forward, the reference's loss, backward, SGD) and config 1 (`c1`: B=32,
                 RGB only, backbone forward).  N = 1 only.
@@ -486,6 +489,27 @@ def modes_block(args, cfg, cams, own_value, own_eval=None):
     return out
 
 
+def other_configs_block(args):
+    """BASELINE.json configs 3 / 4 / 5 on this one GPU (they had builder-run lines only): the same timed loop of
+    this file in a child process per preset, so that the driver's own run carries a number for each.  They are per-GPU workloads of
+    configs the reference quotes on 8 GPUs - not the headline, not part of `value`."""
+    import subprocess
+    out = {"what": "the same timed loop (hipGraph replay, H2D per batch, sync per iteration) per BASELINE preset, one child process each, "
+                   "this GPU; per-GPU batch as the preset's default"}
+    for preset, label in (("RGBNT100", "config 3"), ("MSVR310", "config 4"), ("SYNTH4L", "config 5")):
+        cmd = [sys.executable, os.path.abspath(__file__), "--dtype", args.dtype, "--preset", preset, "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--graph", "--no-cpu-baseline", "--no-replay", "--no-modes", "--no-eval", "--no-others"]
+        try:
+            cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+            j = json.loads(lines[-1])
+            out[preset] = {"baseline_config": label, "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                           "workload": j["config"]["workload"]}
+        except Exception as e:                           # reported, not hidden; never fails the headline
+            out[preset] = {"baseline_config": label, "value": None, "error": type(e).__name__}
+    return out
+
+
 def shader_clock_mhz(work, busy_ms=60.0, n=3000, sleep=6):
     """The clock the CUs run at while `work` (a callable launching on the current stream) keeps the chip busy: one resident
     wave samples (s_memtime = shader-clock cycles, s_memrealtime = the constant 100 MHz reference) on a second stream
@@ -761,6 +785,7 @@ def main():
     ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"], help="N > 1: dtype of the gradient buckets on the wire "
                     "(bf16: 237.8 instead of 475.7 MB per step over the xGMI ring; the strong-scaling series needs it)")
     ap.add_argument("--no-eval", action="store_true", help="skip the forward-only (do_inference) throughput block")
+    ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configs' child runs (`other_configs`)")
     ap.add_argument("--spawn", action="store_true", help="go through the rank launcher even for --gpus 1 (a real 1-rank RCCL group; "
                     "also EDITOR_BENCH_SPAWN=1)")
     args = ap.parse_args()
@@ -1169,6 +1194,9 @@ def main():
         if world == 1 and not args.no_modes and not force_ddp and args.preset in ("RGBNT201", "RGBNT100", "MSVR310"):
             out["modes"] = modes_block(args, cfg, cams, out["value"], eval_block)
             out["value_at_parity"] = out["modes"].pop("value_at_parity")
+        if (world == 1 and not force_ddp and not args.no_others and not args.no_modes and args.preset == "RGBNT201" and b == 128
+                and args.dtype != "f32"):
+            out["other_configs"] = other_configs_block(args)       # (with the full default line only: the modes' children pass --no-modes)
         if world == 1 and not args.no_cpu_baseline and not force_ddp:
             out["cpu_baseline"] = cpu_baseline(model, cfg, cams, b, args.cpu_iters)
             if args.preset == "RGBNT201" and b == 128:
