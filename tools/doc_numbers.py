@@ -138,6 +138,13 @@ def numbers_block():
         if e:
             out.append("| `bench.py` %s | %.0f %s = %.2f ms per step | `profiles/%s_bench_line_%s.json` |"
                        % (label, e["value"], e["unit"].replace("tri-modal ", ""), e["ms_per_step"], TAG, name))
+    oc = d.get("other_configs")
+    if oc:
+        parts = ["%s %s: %.0f %s (%.2f ms)" % (v["baseline_config"], k, v["value"], v["unit"].replace("tri-modal ", ""), v["ms_per_step"])
+                 for k, v in oc.items() if isinstance(v, dict) and v.get("value")]
+        if parts:
+            out.append("| the other BASELINE configs inside the default line's own run (child process each, same box) | " + "; ".join(parts)
+                       + " | `other_configs` |")
     cb = d.get("cpu_baseline")
     if cb:
         out.append("| CPU baseline (the oracle on the GPU box's host cores, same run) | %.2f %s on %s cores (%s) | `cpu_baseline` |"
